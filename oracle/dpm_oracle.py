@@ -1,0 +1,484 @@
+"""TEST INFRASTRUCTURE -- NOT PART OF THE PRODUCT PATH.
+
+CPU restatement (torch fp32 on the host) of the reference's encode -> match -> register hot
+path.  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may
+import this file; the shipped package (`deeppointmap_amd/`) never does and fails loudly if
+its HIP library is missing.
+
+Parity pin: this restatement is checked against outputs of the reference itself, produced in
+the build container by importing /root/reference (tests/golden/make_golden.py) and committed
+as fixtures under tests/golden/*.npz (tests/test_oracle_golden.py).  The reference has no
+tests or golden vectors of its own.  The information matrix (a18) can
+run in neither of its reference branches here (pytorch3d / open3d are absent), so for that one
+function parity is *unpinned* by the reference: it is pinned on hand-computed cases only.
+
+Everything is written functionally over a flat state dict `sd` (the reference checkpoints'
+key names) and in point-major layout (points x channels); citations give the reference
+file:line each function follows (paths relative to /root/reference).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# ----------------------------------------------------------------------------------------------
+# a3  farthest point sampling                          network/encoder/utils.py:210-270
+# ----------------------------------------------------------------------------------------------
+def fps_indices(xyz: Tensor, length: int, K: int) -> Tensor:
+    """xyz (N,3) f32 -> idx (K,) int64, -1 where fewer than K valid points.
+
+    Start at index 0 (utils.py:249, random_start_point=False); every round
+    closest = min(closest, (dx^2+dy^2)+dz^2) and the next pick is the FIRST argmax
+    (utils.py:254-259).  torch evaluates `(d**2).sum(-1)` left to right without FMA
+    contraction, which is what the HIP kernel reproduces bit for bit.
+    """
+    idx = torch.full((K,), -1, dtype=torch.int64)
+    if length <= 0:
+        return idx
+    p = xyz[:length, :3].contiguous()
+    closest = torch.full((length,), float("inf"), dtype=torch.float32)
+    sel = 0
+    idx[0] = 0
+    for i in range(1, min(length, K)):
+        d = p[sel] - p
+        closest = torch.minimum((d * d).sum(-1), closest)
+        sel = int(torch.argmax(closest))
+        idx[i] = sel
+    return idx
+
+
+_CLIB = None
+
+
+def _clib():
+    """oracle/libdpm_oracle.so (oracle/dpm_oracle.c), built on demand with `make -C oracle`."""
+    global _CLIB
+    if _CLIB is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        so = os.path.join(here, "libdpm_oracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", here, "libdpm_oracle.so"], stdout=subprocess.DEVNULL)
+        lib = ctypes.CDLL(so)
+        lib.dpm_oracle_fps.restype = ctypes.c_int
+        lib.dpm_oracle_fps.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        lib.dpm_oracle_nn1.restype = None
+        lib.dpm_oracle_nn1.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p]
+        _CLIB = lib
+    return _CLIB
+
+
+def fps_indices_fast(xyz: Tensor, length: int, K: int) -> Tensor:
+    """Same contract and same bits as fps_indices, through the C restatement (dpm_oracle.c)."""
+    p = xyz[:max(length, 0), :3].contiguous().float()
+    idx = torch.empty(K, dtype=torch.int64)
+    scratch = torch.empty(max(length, 1), dtype=torch.float32)
+    _clib().dpm_oracle_fps(p.data_ptr(), int(length), int(K), idx.data_ptr(), scratch.data_ptr())
+    return idx
+
+
+def gather_masked(points: Tensor, idx: Tensor) -> Tensor:
+    """points (N,D), idx (K,) with -1 = padding -> (K,D), zeros at padding (utils.py:298-343)."""
+    out = points[idx.clamp(min=0)]
+    out[idx < 0] = 0.0
+    return out
+
+
+def fps(points: Tensor, padding: Tensor, K: int, fast: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+    """Batched: points (B,N,3), padding (B,N) -> (new (B,K,3), mask (B,K), idx (B,K))."""
+    lengths = (~padding).sum(1)
+    one = fps_indices_fast if fast else fps_indices
+    idx = torch.stack([one(points[b], int(lengths[b]), K) for b in range(points.shape[0])])
+    new = torch.stack([gather_masked(points[b], idx[b]) for b in range(points.shape[0])])
+    return new, idx < 0, idx
+
+
+# ----------------------------------------------------------------------------------------------
+# a4  kNN-within-radius ("hybrid") grouping             network/encoder/utils.py:76-89, 288-295
+# ----------------------------------------------------------------------------------------------
+def expanded_sqdist(a: Tensor, b: Tensor) -> Tensor:
+    """(B,M,3),(B,N,3) -> (B,M,N): -2ab + |a|^2 + |b|^2, in that order (utils.py:288-295)."""
+    d = -2 * torch.matmul(a, b.transpose(1, 2))
+    d += (a ** 2).sum(-1).unsqueeze(2)
+    d += (b ** 2).sum(-1).unsqueeze(1)
+    return d
+
+
+def push_padding_far(points: Tensor, padding: Tensor) -> Tensor:
+    """padded rows -> 3*max|coord| of the whole tensor (utils.py:80-81)."""
+    p = points.clone()
+    p[padding] = points.abs().max() * 3
+    return p
+
+
+def hybrid_query(radius: float, K: int, points: Tensor, centers: Tensor, padding: Tensor,
+                 return_dist: bool = False, chunk: int = 512):
+    """idx (B,S,K) int64: K nearest, those farther than radius replaced by the nearest."""
+    pts = push_padding_far(points, padding)
+    out_i, out_d = [], []
+    for s0 in range(0, centers.shape[1], chunk):  # chunking only bounds the (S,N) temporary
+        d = expanded_sqdist(centers[:, s0:s0 + chunk, :3], pts[..., :3])
+        dk, ik = torch.topk(d, k=K, dim=-1, largest=False)
+        ik = torch.where(dk > radius ** 2, ik[..., :1].expand_as(ik), ik)
+        out_i.append(ik)
+        out_d.append(dk)
+    idx = torch.cat(out_i, 1)
+    return (idx, torch.cat(out_d, 1)) if return_dist else idx
+
+
+# ----------------------------------------------------------------------------------------------
+# a9  channel LayerNorm + MLP helpers                   network/encoder/utils.py:358-413
+# ----------------------------------------------------------------------------------------------
+def _lin(sd: SD, key: str, x: Tensor) -> Tensor:
+    w = sd[key + ".weight"]
+    return F.linear(x, w.reshape(w.shape[0], w.shape[1]), sd.get(key + ".bias"))
+
+
+def _ln(sd: SD, key: str, x: Tensor) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[key + ".weight"], sd[key + ".bias"], 1e-5)
+
+
+# ----------------------------------------------------------------------------------------------
+# a5/a6  grouped MLP -> LayerNorm -> ReLU -> max over K  network/encoder/pointnext.py:38-64, 84-109
+# ----------------------------------------------------------------------------------------------
+def grouped_mlp_max(sd: SD, prefix: str, radius: float, xyz: Tensor, fea: Tensor, centers: Tensor,
+                    idx: Tensor) -> Tensor:
+    """xyz (B,N,3), fea (B,N,C), centers (B,S,3), idx (B,S,K) -> (B,S,Cout).
+
+    Per neighbour the input vector is [fea_0..fea_{C-1}, (x-cx)/r, (y-cy)/r, (z-cz)/r]
+    (pointnext.py:52-56); Conv2d 1x1 + LayerNorm over channels + ReLU (`prefix.0`, `prefix.1.ln`),
+    then max over the K neighbours (pointnext.py:59-61).
+    """
+    B = xyz.shape[0]
+    bi = torch.arange(B).view(B, 1, 1)
+    rel = (xyz[bi, idx] - centers.unsqueeze(2)) / radius
+    g = torch.cat([fea[bi, idx], rel], dim=-1)
+    h = torch.relu(_ln(sd, prefix + ".1.ln", _lin(sd, prefix + ".0", g)))
+    return h.max(dim=2)[0]
+
+
+# ----------------------------------------------------------------------------------------------
+# a7  inverted-residual MLP                              network/encoder/pointnext.py:130-138
+# ----------------------------------------------------------------------------------------------
+def inv_res_mlp(sd: SD, prefix: str, radius: float, K: int, xyz: Tensor, fea: Tensor, padding: Tensor,
+                trace: Optional[dict] = None) -> Tensor:
+    idx = hybrid_query(radius, K, xyz, xyz, padding)
+    if trace is not None:
+        trace[prefix + ".la.idx"] = idx
+    t = grouped_mlp_max(sd, prefix + ".la.mlp", radius, xyz, fea, xyz, idx)
+    if trace is not None:
+        trace[prefix + ".la.out"] = t
+    u = torch.relu(_ln(sd, prefix + ".pw_conv.1.ln", _lin(sd, prefix + ".pw_conv.0", t)))
+    v = _ln(sd, prefix + ".pw_conv.4.ln", _lin(sd, prefix + ".pw_conv.3", u))
+    return torch.relu(v + fea)
+
+
+# ----------------------------------------------------------------------------------------------
+# a8  feature propagation                                network/encoder/pointnext.py:188-218
+# ----------------------------------------------------------------------------------------------
+def feature_propagation(sd: SD, prefix: str, xyz1: Tensor, xyz2: Tensor, fea1: Tensor, fea2: Tensor,
+                        padding2: Tensor) -> Tensor:
+    """fine (B,N,3)/(B,N,D1) <- coarse (B,S,3)/(B,S,D2): 3-NN inverse-distance interpolation."""
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    if S == 1:
+        interp = fea2.expand(B, N, fea2.shape[-1])
+    else:
+        p2 = push_padding_far(xyz2, padding2)
+        d, i = torch.topk(expanded_sqdist(xyz1, p2), k=3, dim=-1, largest=False)
+        w = 1.0 / d.clamp(min=1e-8)
+        w = w / w.sum(dim=2, keepdim=True)
+        bi = torch.arange(B).view(B, 1, 1)
+        interp = (fea2[bi, i] * w.unsqueeze(-1)).sum(dim=2)
+    x = torch.cat([fea1, interp], dim=-1)
+    x = torch.relu(_ln(sd, prefix + ".mlp.1.ln", _lin(sd, prefix + ".mlp.0", x)))
+    x = torch.relu(_ln(sd, prefix + ".mlp.4.ln", _lin(sd, prefix + ".mlp.3", x)))
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# a1  Encoder.forward                                    network/encoder/encoder.py:51-69
+# ----------------------------------------------------------------------------------------------
+def encoder_forward(sd: SD, cfg, points: Tensor, padding: Tensor, trace: Optional[dict] = None,
+                    fast_fps: bool = False) -> List[Tensor]:
+    """points (B,C>=3,N) channel-first f32, padding (B,N) bool -> [coor (B,3,S), fea (B,128,S), pad (B,S)]."""
+    enc = cfg.encoder
+    xyz = points[:, :3, :].transpose(1, 2).contiguous()
+    fea = _lin(sd, "point_mlp0", points[:, :enc.in_channel, :].transpose(1, 2))
+    levels = [(xyz, fea, padding)]
+    for i, npoint in enumerate(enc.npoint):
+        xyz, fea, pad = levels[-1]
+        radii, ks = enc.radius_list[i], enc.nsample_list[i]
+        pre = f"downsampler.{i}"
+        new_xyz, new_pad, fidx = fps(xyz, pad, npoint, fast=fast_fps)
+        gidx = hybrid_query(radii[0], ks[0], xyz, new_xyz, pad)
+        new_fea = grouped_mlp_max(sd, pre + ".sa.mlp", radii[0], xyz, fea, new_xyz, gidx)
+        if trace is not None:
+            trace[pre + ".fps.idx"] = fidx
+            trace[pre + ".sa.idx"] = gidx
+            trace[pre + ".sa.out"] = new_fea
+        for j in range(1, len(radii)):
+            new_fea = inv_res_mlp(sd, f"{pre}.irm.{j - 1}", radii[j], ks[j], new_xyz, new_fea, new_pad, trace)
+            if trace is not None:
+                trace[f"{pre}.irm.{j - 1}.out"] = new_fea
+        levels.append((new_xyz, new_fea, new_pad))
+    L = len(enc.npoint)
+    for i in range(enc.upsample_layers):
+        xyz1, fea1, pad1 = levels[L - i - 1]
+        xyz2, fea2, pad2 = levels[-1]
+        new_fea = feature_propagation(sd, f"upsampler.{i}", xyz1, xyz2, fea1, fea2, pad2)
+        if trace is not None:
+            trace[f"upsampler.{i}.out"] = new_fea
+        levels.append((xyz1, new_fea, pad1))
+    xyz, fea, pad = levels[-1]
+    return [xyz.transpose(1, 2).contiguous(), fea.transpose(1, 2).contiguous(), pad.clone()]
+
+
+def extract_descriptors(sd: SD, cfg, points: Tensor, padding: Tensor) -> Tensor:
+    """a10: (B,131,S) = cat[fea, xyz*coor_scale]   system/modules/odometry.py:36-54."""
+    coor, fea, _ = encoder_forward(sd, cfg, points, padding)
+    return torch.cat([fea, coor * cfg.slam_system.coor_scale], dim=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# a11  sine position embedding                          network/decoder/descriptor_attention.py:54-83
+# ----------------------------------------------------------------------------------------------
+def position_embedding(xyz: Tensor, emb_dim: int = 256, temperature: float = 10000.0) -> Tensor:
+    """xyz (B,M,3) metres -> (B,M,emb_dim): channel axis*F+i = sin/cos(p*pi / T^(2*(i//2)/F))."""
+    nf = emb_dim // 3 // 2 * 2
+    i = torch.arange(nf, dtype=xyz.dtype)
+    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="trunc") / nf)
+    ang = (xyz * math.pi).unsqueeze(-1) / dim_t
+    emb = torch.stack([ang[..., 0::2].sin(), ang[..., 1::2].cos()], dim=-1).reshape(*xyz.shape[:-1], -1)
+    return F.pad(emb, (0, emb_dim - nf * 3))
+
+
+# ----------------------------------------------------------------------------------------------
+# a12  descriptor attention                              descriptor_attention.py:24-51, decoder.py:145-162
+# ----------------------------------------------------------------------------------------------
+def _mha(sd: SD, prefix: str, q_in: Tensor, kv_in: Tensor, heads: int = 8) -> Tensor:
+    """nn.MultiheadAttention(batch_first) with key=value=kv_in, no masks, dropout 0."""
+    E = q_in.shape[-1]
+    w, b = sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"]
+    q = F.linear(q_in, w[:E], b[:E])
+    k = F.linear(kv_in, w[E:2 * E], b[E:2 * E])
+    v = F.linear(kv_in, w[2 * E:], b[2 * E:])
+    B, M, _ = q.shape
+    N = k.shape[1]
+    hd = E // heads
+    q = q.view(B, M, heads, hd).transpose(1, 2)
+    k = k.view(B, N, heads, hd).transpose(1, 2)
+    v = v.view(B, N, heads, hd).transpose(1, 2)
+    a = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(B, M, E)
+    return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
+
+
+def attention_layer(sd: SD, prefix: str, x: Tensor, y: Tensor, px: Tensor, py: Tensor) -> Tuple[Tensor, Tensor]:
+    """x (B,M,256), y (B,N,256) token-major; both cross calls read the pre-update x, y."""
+    x, y = x + px, y + py
+    x = _ln(sd, prefix + ".norm1", x + _mha(sd, prefix + ".self_attn", x, x))
+    y = _ln(sd, prefix + ".norm1", y + _mha(sd, prefix + ".self_attn", y, y))
+    x, y = x + px, y + py
+    xo = _mha(sd, prefix + ".cross_attn", x, y)
+    yo = _mha(sd, prefix + ".cross_attn", y, x)
+    x = _ln(sd, prefix + ".norm2", x + xo)
+    y = _ln(sd, prefix + ".norm2", y + yo)
+
+    def mlp(t):
+        return F.linear(torch.relu(F.linear(t, sd[prefix + ".mlp.0.weight"], sd[prefix + ".mlp.0.bias"])),
+                        sd[prefix + ".mlp.2.weight"], sd[prefix + ".mlp.2.bias"])
+
+    x = _ln(sd, prefix + ".norm3", mlp(x) + x)
+    y = _ln(sd, prefix + ".norm3", mlp(y) + y)
+    return x, y
+
+
+def descriptor_attention(sd: SD, cfg, src: Tensor, dst: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """src (B,131,M), dst (B,131,N) -> token-major (fea_s (B,M,256), xyz_s (B,M,3), fea_d, xyz_d)."""
+    sf, sx = src[:, :-3].transpose(1, 2), src[:, -3:].transpose(1, 2)
+    df, dx = dst[:, :-3].transpose(1, 2), dst[:, -3:].transpose(1, 2)
+    E = cfg.decoder.model_channel
+    ps, pd = position_embedding(sx, E), position_embedding(dx, E)
+    x, y = _lin(sd, "projection", sf), _lin(sd, "projection", df)
+    for l in range(cfg.decoder.attention_layers):
+        x, y = attention_layer(sd, f"descriptor_attention.{l}", x, y, ps, pd)
+    return x, sx, y, dx
+
+
+# ----------------------------------------------------------------------------------------------
+# a13  similarity -> dual softmax -> top-k                network/decoder/decoder.py:164-200
+# ----------------------------------------------------------------------------------------------
+def num_pairs(num_sample, M: int, N: int) -> int:
+    if isinstance(num_sample, int):
+        k = num_sample
+    elif isinstance(num_sample, float) and num_sample > 1:
+        k = int(num_sample)
+    elif isinstance(num_sample, float) and 0 < num_sample <= 1:
+        k = int(num_sample * (M + N))
+    else:
+        raise ValueError(f"Argument `num_sample` with value {num_sample} is not supported")
+    return k // 2
+
+
+def _head2(sd: SD, prefix: str, x: Tensor) -> Tensor:
+    return _lin(sd, prefix + ".2", torch.relu(_lin(sd, prefix + ".0", x)))
+
+
+def descriptor_pairing(sd: SD, cfg, x: Tensor, y: Tensor, num_sample) -> Tuple[Tensor, Tensor, Tensor]:
+    """x (1,M,256), y (1,N,256) -> (src_index (k,), dst_index (k,), conf (k,)) in top-k order."""
+    assert x.shape[0] == 1, "batch size in inference must be 1"
+    M, N = x.shape[1], y.shape[1]
+    k = num_pairs(num_sample, M, N)
+    a = F.normalize(_head2(sd, "similarity_head", x), p=2, dim=2)
+    b = F.normalize(_head2(sd, "similarity_head", y), p=2, dim=2)
+    S = a @ b.transpose(1, 2)
+    P = F.softmax(S / cfg.loss.tau, dim=2) * F.softmax(S / cfg.loss.tau, dim=1)
+    val, flat = torch.topk(P.reshape(1, M * N), k=k, dim=1)
+    return (flat // N).squeeze(0), (flat % N).squeeze(0), val.squeeze(0)
+
+
+# ----------------------------------------------------------------------------------------------
+# a14  offset head -> correspondence sets                 decoder.py:202-225, heads.py:22-42
+# ----------------------------------------------------------------------------------------------
+def offset_head(sd: SD, f: Tensor) -> Tensor:
+    """f (k,512) -> (k,3)."""
+    h = torch.relu(_lin(sd, "offset_head.mlp.0", f))
+    h = torch.relu(_lin(sd, "offset_head.mlp.2", h))
+    h = _lin(sd, "offset_head.mlp.4", h)
+    return _lin(sd, "offset_head.head", torch.relu(h + _lin(sd, "offset_head.downsample", f)))
+
+
+def correspondence_sets(sd: SD, cfg, xs: Tensor, ps: Tensor, yd: Tensor, pd: Tensor, conf: Tensor):
+    """paired features (k,256) / coordinates (k,3) -> (src (3,n), dst (3,n), w (n,)), n <= 2k."""
+    off_s2d = offset_head(sd, torch.cat([xs, yd], dim=1))
+    off_d2s = offset_head(sd, torch.cat([yd, xs], dim=1))
+    src = torch.cat([ps + off_s2d, ps], dim=0)
+    dst = torch.cat([pd, pd + off_d2s], dim=0)
+    w = conf.repeat(2)
+    lim = cfg.loss.eps_offset ** 2
+    keep = torch.cat([(off_s2d ** 2).sum(1) <= lim, (off_d2s ** 2).sum(1) <= lim])
+    return src[keep].t().contiguous(), dst[keep].t().contiguous(), w[keep]
+
+
+# ----------------------------------------------------------------------------------------------
+# a15  iterative weighted Kabsch                           decoder.py:227-265
+# ----------------------------------------------------------------------------------------------
+def solve_svd(w: Tensor, src: Tensor, dst: Tensor, num_iter: int = 3, std_ratio: float = 3.0):
+    """w (n,), src/dst (3,n) -> (R (3,3) f32, T (3,1) f32, inlier mask (n,), rmse float).
+
+    R = V U^T from torch.svd of the fp64 covariance, no reflection fix (decoder.py:242-243).
+    """
+    it = 0
+    inl = w > 0.5
+    inl[torch.topk(w, k=min(64, len(w)), dim=0)[1]] = True
+    while True:
+        s, d, ww = src[:, inl], dst[:, inl], w[inl]
+        cs = (s * ww).sum(dim=1, keepdim=True) / ww.sum()
+        cd = (d * ww).sum(dim=1, keepdim=True) / ww.sum()
+        cov = (s - cs) @ torch.diag(ww) @ (d - cd).T
+        u, _, v = torch.svd(cov.double())
+        R = v @ u.T
+        T = cd.double() - R @ cs.double()
+        R, T = R.to(src.dtype), T.to(src.dtype)
+        err = torch.norm(R @ src + T - dst, p=2, dim=0)
+        new = err <= (err[inl].mean() + std_ratio * err[inl].std())
+        it += 1
+        stop = it >= num_iter or bool((inl == new).all()) or int(new.sum()) < 30
+        inl = new
+        if stop:
+            break
+    rmse = (R @ src[:, inl] + T - dst[:, inl]).pow(2).sum(0).mean().sqrt().item()
+    return R, T, inl, rmse
+
+
+# ----------------------------------------------------------------------------------------------
+# a16 / a17  public decoder calls                          decoder.py:91-143, heads.py:45-69
+# ----------------------------------------------------------------------------------------------
+def registration_forward(sd: SD, cfg, src_desc: Tensor, dst_desc: Tensor, num_sample=0.5, trace=None):
+    """(131,M),(131,N) -> (R (3,3), T (3,1), conf (n_inlier,), rmse float)."""
+    x, ps, y, pd = descriptor_attention(sd, cfg, src_desc.unsqueeze(0), dst_desc.unsqueeze(0))
+    si, di, conf = descriptor_pairing(sd, cfg, x, y, num_sample)
+    src, dst, w = correspondence_sets(sd, cfg, x[0, si], ps[0, si], y[0, di], pd[0, di], conf)
+    R, T, inl, rmse = solve_svd(w, src, dst)
+    if trace is not None:
+        trace.update(x=x, y=y, src_index=si, dst_index=di, conf=conf, src=src, dst=dst, w=w, inlier=inl)
+    return R, T, w[inl], rmse
+
+
+def loop_detection_forward(sd: SD, cfg, src_desc: Tensor, dst_desc: Tensor) -> Tensor:
+    """(C,131,M),(C,131,N) -> (C,) loop probabilities."""
+    if src_desc.ndim == 2:
+        src_desc, dst_desc = src_desc.unsqueeze(0), dst_desc.unsqueeze(0)
+    x, _, y, _ = descriptor_attention(sd, cfg, src_desc, dst_desc)
+    fx = _head2(sd, "loop_head.mlp", x).mean(dim=1)
+    fy = _head2(sd, "loop_head.mlp", y).mean(dim=1)
+    h = torch.relu(_lin(sd, "loop_head.projection.0", torch.cat([fx, fy], dim=-1)))
+    return torch.sigmoid(_lin(sd, "loop_head.projection.2", h)).flatten()
+
+
+# ----------------------------------------------------------------------------------------------
+# a18  information matrix                                  system/modules/utils.py:60-104
+# ----------------------------------------------------------------------------------------------
+def nn1(p1: Tensor, p2: Tensor, chunk: int = 2048) -> Tuple[Tensor, Tensor]:
+    """p1 (N1,3), p2 (N2,3) -> (sqdist (N1,), idx (N1,)) exact brute force, direct-form distance
+    (what pytorch3d's knn_points computes at utils.py:80)."""
+    if p1.shape[0] * p2.shape[0] > (1 << 24) and p1.dtype == torch.float32:  # big: C restatement
+        a, b = p1.contiguous(), p2.contiguous()
+        d = torch.empty(a.shape[0], dtype=torch.float32)
+        i = torch.empty(a.shape[0], dtype=torch.int32)
+        _clib().dpm_oracle_nn1(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], d.data_ptr(), i.data_ptr())
+        return d, i.long()
+    ds, ix = [], []
+    for s in range(0, p1.shape[0], chunk):
+        diff = p1[s:s + chunk, None, :] - p2[None, :, :]
+        d = (diff * diff).sum(-1)
+        m, i = d.min(dim=1)
+        ds.append(m)
+        ix.append(i)
+    return torch.cat(ds), torch.cat(ix)
+
+
+def information_matrix(pcd1: Tensor, pcd2: Tensor, SE3: Tensor, radius: float = 1.0) -> Tensor:
+    """pcd1 (3,N1), pcd2 (3,N2) metres, SE3 (4,4) -> (6,6) f32: sum over matched target points
+    t=(x,y,z) of the outer products of the rows [0,z,-y,1,0,0], [-z,0,x,0,1,0], [y,-x,0,0,0,1]
+    (utils.py:86-103)."""
+    R, T = SE3[:3, :3], SE3[:3, 3:]
+    p1 = (R @ pcd1 + T).T
+    d, i = nn1(p1, pcd2.T.contiguous())
+    t = pcd2[:, i[d <= radius ** 2]].T
+    x, y, z = t[:, 0], t[:, 1], t[:, 2]
+    o, l = torch.zeros_like(x), torch.ones_like(x)
+    rows = [torch.stack([o, z, -y, l, o, o], 1), torch.stack([-z, o, x, o, l, o], 1),
+            torch.stack([y, -x, o, o, o, l], 1)]
+    G = torch.zeros(6, 6)
+    for g in rows:
+        G += (g.unsqueeze(2) @ g.unsqueeze(1)).sum(0)
+    return G
+
+
+# a19 helpers                                              system/modules/utils.py:18, 30-57
+def se3(R: Tensor, t: Tensor) -> Tensor:
+    m = torch.eye(4)
+    m[:3, :3] = R
+    m[:3, 3:4] = t.reshape(3, 1)
+    return m
+
+
+def rotation_angle(R: Tensor) -> float:
+    return torch.arccos((torch.trace(R) - 1) / 2).item()
+
+
+def simvec_to_num(v: Tensor) -> float:
+    return v.flatten()[:30].mean().item()

@@ -1,0 +1,147 @@
+"""CPU: the oracle (oracle/dpm_oracle.py) against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, idx_rows_equal_as_sets, load_golden, rot_angle
+from oracle import dpm_oracle as O
+from deeppointmap_amd import synthetic
+
+
+def test_fps_bit_exact_vs_reference():
+    g = load_golden("fps.npz")
+    names = sorted({k.rsplit(".", 1)[0] for k in g if k.endswith(".points")})
+    assert len(names) >= 6
+    for n in names:
+        pts, length, K = T(g[n + ".points"]), int(g[n + ".length"]), g[n + ".new"].shape[0]
+        idx = O.fps_indices(pts, length, K)
+        new = O.gather_masked(pts, idx)
+        assert np.array_equal(new.numpy(), g[n + ".new"]), n
+        assert np.array_equal((idx < 0).numpy(), g[n + ".mask"]), n
+
+
+def test_fps_full_size_synthetic():
+    g = load_golden("fps.npz")
+    pts = synthetic.frame(0).t().contiguous()
+    idx = O.fps_indices_fast(pts, 65536, 4096)
+    assert np.array_equal(pts[idx].numpy(), g["synthetic0_k4096.new"])
+
+
+def test_fps_c_equals_torch_loop():
+    gen = torch.Generator().manual_seed(1)
+    pts = torch.rand(3000, 3, generator=gen)
+    assert torch.equal(O.fps_indices(pts, 2500, 300), O.fps_indices_fast(pts, 2500, 300))
+
+
+def test_hybrid_query_vs_reference():
+    g = load_golden("knn.npz")
+    names = sorted({k.rsplit(".", 1)[0] for k in g if k.endswith(".idx")})
+    assert len(names) == 4
+    for n in names:
+        pts, ctr = T(g[n + ".points"]).unsqueeze(0), T(g[n + ".centers"]).unsqueeze(0)
+        pad = torch.arange(pts.shape[1]).unsqueeze(0) >= int(g[n + ".length"])
+        idx = O.hybrid_query(float(g[n + ".radius"]), g[n + ".idx"].shape[1], pts, ctr, pad)[0]
+        assert np.array_equal(idx.numpy(), g[n + ".idx"]), n
+
+
+@pytest.mark.parametrize("fixture", ["encoder_reduced.npz", "encoder_reduced_padded.npz"])
+def test_encoder_reduced_per_stage(fixture, cfg_reduced, sd_enc):
+    g = load_golden(fixture)
+    pts = T(g["points"])
+    if "length" in g:
+        pad = torch.arange(pts.shape[2]).unsqueeze(0) >= int(g["length"])
+    else:
+        pad = torch.zeros(pts.shape[0], pts.shape[2], dtype=torch.bool)
+    tr = {}
+    coor, fea, mask = O.encoder_forward(sd_enc, cfg_reduced, pts, pad, trace=tr)
+    assert np.array_equal(coor.numpy(), g["coor"]) and np.array_equal(mask.numpy(), g["mask"])
+    for k, v in g.items():
+        if k.endswith(".idx"):
+            assert idx_rows_equal_as_sets(tr[k].numpy(), v).mean() > 0.999, k
+        elif k.endswith(".out"):
+            np.testing.assert_allclose(tr[k].numpy(), v, rtol=0, atol=2e-4, err_msg=k)
+    np.testing.assert_allclose(fea.numpy(), g["fea"], rtol=0, atol=2e-4)
+
+
+def test_encoder_full_descriptors(cfg_full, sd_enc):
+    g = load_golden("encoder_full.npz")
+    p = T(g["kitti0.points"]).unsqueeze(0)
+    coor, fea, _ = O.encoder_forward(sd_enc, cfg_full, p, torch.zeros(1, p.shape[2], dtype=torch.bool),
+                                     fast_fps=True)
+    assert np.array_equal(coor[0].numpy(), g["kitti0.coor"])
+    np.testing.assert_allclose(fea[0].numpy(), g["kitti0.fea"], rtol=0, atol=2e-4)
+
+
+def test_position_embedding():
+    g = load_golden("decoder.npz")
+    out = O.position_embedding(T(g["posemb.xyz"]).unsqueeze(0))[0]
+    np.testing.assert_allclose(out.numpy(), g["posemb.out"], rtol=0, atol=1e-6)
+    assert np.all(out.numpy()[:, 252:] == 0)
+
+
+@pytest.mark.parametrize("name", ["synthetic01", "kitti01", "map1024_vs_256"])
+def test_registration_stages(name, cfg_full, sd_dec):
+    g = load_golden("decoder.npz")
+    s, d = T(g[name + ".src_desc"]), T(g[name + ".dst_desc"])
+    tr = {}
+    R, Tt, conf, rmse = O.registration_forward(sd_dec, cfg_full, s, d, 0.5, trace=tr)
+    np.testing.assert_allclose(tr["x"][0].t().numpy(), g[name + ".src_corr"][:-3], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(tr["y"][0].t().numpy(), g[name + ".dst_corr"][:-3], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(tr["conf"].numpy(), g[name + ".pair_conf"], rtol=2e-3, atol=0)
+    assert tr["src"].shape == g[name + ".corr_src"].shape
+    np.testing.assert_allclose(tr["src"].numpy(), g[name + ".corr_src"], atol=2e-3, rtol=0)
+    np.testing.assert_allclose(tr["dst"].numpy(), g[name + ".corr_dst"], atol=2e-3, rtol=0)
+    # the pose tolerance north_star states: 1e-4 m / 1e-4 rad
+    assert float((Tt - T(g[name + ".T"])).norm()) < 1e-4
+    assert rot_angle(R, g[name + ".R"]) < 1e-4
+    assert conf.shape == g[name + ".conf"].shape
+    assert abs(rmse - float(g[name + ".rmse"])) < 1e-4
+
+
+def test_loop_detection(cfg_full, sd_dec):
+    g = load_golden("decoder.npz")
+    p = O.loop_detection_forward(sd_dec, cfg_full, T(g["loop.src"]), T(g["loop.dst"]))
+    np.testing.assert_allclose(p.numpy(), g["loop.prob"], atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["svd_clean200", "svd_outliers300", "svd_few40", "svd_reflect120", "svd_lowconf100"])
+def test_kabsch_loop(name):
+    g = load_golden("decoder.npz")
+    R, Tt, mask, rmse = O.solve_svd(T(g[name + ".w"]), T(g[name + ".src"]), T(g[name + ".dst"]))
+    assert np.array_equal(mask.numpy(), g[name + ".mask"])
+    np.testing.assert_allclose(R.numpy(), g[name + ".R"], atol=1e-6)
+    np.testing.assert_allclose(Tt.numpy(), g[name + ".T"], atol=1e-5)
+    assert abs(rmse - float(g[name + ".rmse"])) < 1e-5
+    if name == "svd_reflect120":  # R = V U^T is left uncorrected by the reference (decoder.py:243)
+        assert np.linalg.det(g[name + ".R"].astype(np.float64)) < 0
+
+
+def test_num_pairs_rule():
+    assert O.num_pairs(0.5, 256, 256) == 128
+    assert O.num_pairs(0.5, 4096, 256) == 1088
+    assert O.num_pairs(300, 10, 10) == 150 and O.num_pairs(300.0, 10, 10) == 150
+    with pytest.raises(ValueError):
+        O.num_pairs(0.0, 4, 4)
+    with pytest.raises(ValueError):
+        O.num_pairs("x", 4, 4)
+
+
+def test_information_matrix_hand_computed():
+    # two target points, three source points: one matches t0, one matches t1, one is > 1 m away
+    tgt = torch.tensor([[1.0, 2.0, 3.0], [-4.0, 0.5, 2.0]]).t().contiguous()
+    src = torch.tensor([[1.1, 2.0, 3.0], [-4.0, 0.6, 2.2], [30.0, 0.0, 0.0]]).t().contiguous()
+    G = O.information_matrix(src, tgt, torch.eye(4))
+    want = np.zeros((6, 6))
+    for x, y, z in [(1.0, 2.0, 3.0), (-4.0, 0.5, 2.0)]:
+        for row in ([0, z, -y, 1, 0, 0], [-z, 0, x, 0, 1, 0], [y, -x, 0, 0, 0, 1]):
+            r = np.array(row, dtype=np.float64)
+            want += np.outer(r, r)
+    np.testing.assert_allclose(G.numpy(), want, rtol=1e-6)
+    # with the pose that moves the far point next to t0 it is counted (and t0 twice)
+    SE3 = torch.eye(4)
+    G0 = O.information_matrix(src[:, 2:], tgt, SE3)
+    assert float(G0.abs().sum()) == 0.0
+    SE3[:3, 3] = torch.tensor([-29.0, 2.0, 3.0])
+    G1 = O.information_matrix(src[:, 2:], tgt, SE3)
+    assert G1[3, 3] == 1.0 and G1[0, 0] == 3.0 ** 2 + 2.0 ** 2
