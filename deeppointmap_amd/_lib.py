@@ -1,0 +1,65 @@
+"""ctypes binding of libdpm_hip.so (the C ABI declared in include/dpm_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, this module raises.  ctypes
+releases the GIL for the duration of every foreign call, so the SLAM threads of the reference
+(system/core.py:82-109) can drive the kernels concurrently.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdpm_hip.so")
+
+P, I, D = c_void_p, c_int, c_double
+
+# name -> (restype, argtypes); mirrors include/dpm_hip.h one to one (tests check the symbol list)
+SIGNATURES = {
+    "dpm_version": (I, []),
+    "dpm_error_string": (c_char_p, [I]),
+    "dpm_prepare_points": (I, [P, P, I, I, I, P, P, P]),
+    "dpm_to_channel_first": (I, [P, I, I, I, P, P]),
+    "dpm_fps_workspace_bytes": (c_size_t, [I, I, I]),
+    "dpm_fps": (I, [P, P, I, I, I, P, P, P, P, P]),
+    "dpm_fps_ex": (I, [P, P, I, I, I, P, P, P, P, I, P]),
+    "dpm_knn_hybrid": (I, [P, P, P, I, I, I, I, D, P, P]),
+    "dpm_group_mlp_max": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, D, P, P]),
+    "dpm_linear": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
+    "dpm_layernorm": (I, [P, I, P, P, P, P, P, I, I, I, I, P]),
+    "dpm_three_interp_cat": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),
+}
+
+
+class DpmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DpmError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run `python deeppointmap_amd/csrc/build.py` (there is no CPU fallback)."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so is stale
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    """0 ok; <0 -> ValueError (invalid argument / unsupported shape); >0 -> DpmError (HIP error)."""
+    if status == 0:
+        return
+    msg = load().dpm_error_string(status).decode()
+    if status < 0:
+        raise ValueError(f"{what}: {msg} (status {status})")
+    raise DpmError(f"{what}: HIP error {status}: {msg}")

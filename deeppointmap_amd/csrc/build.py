@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Build libdpm_hip.so (gfx950) in-tree with hipcc.  `python deeppointmap_amd/csrc/build.py`.
+
+hipcc cross-compiles without a GPU.  fps.hip is compiled with -ffp-contract=off (bit-exact
+distance arithmetic); everything else uses explicit fmaf where fusion is wanted.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "libdpm_hip.so")
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+SOURCES = {
+    "fps.hip": ["-ffp-contract=off"],
+    "knn.hip": [],
+    "encoder_ops.hip": [],
+}
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "dpm_hip.h"))
+    jobs = []
+    for src, extra in SOURCES.items():
+        s = os.path.join(HERE, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + headers):
+            jobs.append([hipcc, *COMMON, *extra, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(OUT, objs):
+        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT, *objs])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,318 @@
+// Dense / gather kernels of the encoder (and the small linear algebra the decoder shares):
+// input staging, grouped MLP + LayerNorm + ReLU + max (SetAbstraction / LocalAggregation),
+// linear, LayerNorm, 3-NN feature propagation.  fp32 throughout, like the reference.
+#include "dpm_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// (B,C,N) channel-first + padding mask -> xyz (B,N,3), lengths (B)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prepare_points_kernel(const float *__restrict__ pcf,
+                                                             const uint8_t *__restrict__ pad, int C, int N,
+                                                             float *__restrict__ xyz,
+                                                             int32_t *__restrict__ lengths) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int valid = 0;
+    if (i < N) {
+        const float *p = pcf + (size_t)b * C * N;
+        float *o = xyz + ((size_t)b * N + i) * 3;
+        o[0] = p[i], o[1] = p[(size_t)N + i], o[2] = p[2 * (size_t)N + i];
+        valid = pad[(size_t)b * N + i] ? 0 : 1;
+    }
+    const unsigned long long m = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&lengths[b], __popcll(m));
+}
+
+__global__ __launch_bounds__(256) void to_channel_first_kernel(const float *__restrict__ x, int R, int C,
+                                                               float *__restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const float *xi = x + (size_t)b * R * C;
+    float *oi = out + (size_t)b * R * C;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < R && c0 + tx < C) tile[k][tx] = xi[(size_t)(r0 + k) * C + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < C && r0 + tx < R) oi[(size_t)(c0 + k) * R + r0 + tx] = tile[tx][k];
+}
+
+// ------------------------------------------------------------------------------------------
+// grouped MLP: one workgroup per centre.  v1 (plain VALU): gather K neighbour rows into LDS,
+// y[r][c] = b[c] + sum_k g[r][k] Wt[k][c], LayerNorm over c, ReLU, max over r.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_mlp_max_kernel(
+    const float *__restrict__ xyz_all, const float *__restrict__ fea_all, const float *__restrict__ ctr_all,
+    const int32_t *__restrict__ idx_all, const float *__restrict__ Wt, const float *__restrict__ bias,
+    const float *__restrict__ gamma, const float *__restrict__ beta, int N, int S, int K, int Cin, int Cout,
+    float inv_r, float *__restrict__ out_all) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int C3 = Cin + 3;
+    float *G = smem;                    // [K][C3]
+    float *Y = G + K * C3;              // [K][Cout]
+    float *mean = Y + K * Cout;         // [K]
+    float *rstd = mean + K;             // [K]
+    int *nidx = (int *)(rstd + K);      // [K]
+    const int b = blockIdx.y, s = blockIdx.x, t = threadIdx.x;
+    const float *xyz = xyz_all + (size_t)b * N * 3;
+    const float *fea = fea_all + (size_t)b * N * Cin;
+    const float *ctr = ctr_all + ((size_t)b * S + s) * 3;
+    const int32_t *idx = idx_all + ((size_t)b * S + s) * K;
+
+    if (t < K) nidx[t] = min(max(idx[t], 0), N - 1);
+    __syncthreads();
+    for (int e = t; e < K * Cin; e += 256) {
+        const int r = e / Cin, k = e - r * Cin;
+        G[r * C3 + k] = fea[(size_t)nidx[r] * Cin + k];
+    }
+    if (t < K * 3) {
+        const int r = t / 3, a = t - r * 3;
+        G[r * C3 + Cin + a] = (xyz[(size_t)nidx[r] * 3 + a] - ctr[a]) * inv_r;
+    }
+    __syncthreads();
+    for (int o = t; o < K * Cout; o += 256) {
+        const int r = o / Cout, c = o - r * Cout;
+        float acc = bias[c];
+        const float *g = G + r * C3;
+        for (int k = 0; k < C3; ++k) acc = fmaf(g[k], Wt[(size_t)k * Cout + c], acc);
+        Y[o] = acc;
+    }
+    __syncthreads();
+    const int w = t >> 6, lane = t & 63;
+    for (int r = w; r < K; r += 4) {
+        float sum = 0.f;
+        for (int c = lane; c < Cout; c += 64) sum += Y[r * Cout + c];
+        const float mu = wave_sum(sum) / (float)Cout;
+        float sq = 0.f;
+        for (int c = lane; c < Cout; c += 64) {
+            const float d = Y[r * Cout + c] - mu;
+            sq = fmaf(d, d, sq);
+        }
+        const float var = wave_sum(sq) / (float)Cout;
+        if (lane == 0) mean[r] = mu, rstd[r] = rsqrtf(var + 1e-5f);
+    }
+    __syncthreads();
+    float *out = out_all + ((size_t)b * S + s) * Cout;
+    for (int c = t; c < Cout; c += 256) {
+        const float gm = gamma[c], bt = beta[c];
+        float m = 0.f;  // ReLU output is >= 0, so 0 is the identity of the max
+        for (int r = 0; r < K; ++r) m = fmaxf(m, fmaf((Y[r * Cout + c] - mean[r]) * rstd[r], gm, bt));
+        out[c] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// out = act(x W^T + bias + residual): 64x64 tile, 4x4 per thread, K-step 16 through LDS.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == DPM_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == DPM_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ X, int ldx,
+                                                     const float *__restrict__ W, int ldw,
+                                                     const float *__restrict__ bias,
+                                                     const float *__restrict__ res, int ldr,
+                                                     float *__restrict__ out, int ldo, int R, int Cin, int Cout,
+                                                     int act) {
+    __shared__ float Xs[16][68];
+    __shared__ float Ws[16][68];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    const int lr = t >> 2, lk = (t & 3) * 4;  // loader: row lr (0..63), k offset lk (0,4,8,12)
+    for (int k0 = 0; k0 < Cin; k0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + lk + q;
+            const int xr = row0 + lr, wr = col0 + lr;
+            Xs[lk + q][lr] = (xr < R && k < Cin) ? X[(size_t)xr * ldx + k] : 0.f;
+            Ws[lk + q][lr] = (wr < Cout && k < Cin) ? W[(size_t)wr * ldw + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 a = *reinterpret_cast<const float4 *>(&Xs[k][ty * 4]);
+            const float4 bq = *reinterpret_cast<const float4 *>(&Ws[k][tx * 4]);
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + ty * 4 + i;
+        if (r >= R) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = col0 + tx * 4 + j;
+            if (c >= Cout) continue;
+            float v = acc[i][j];
+            if (bias) v += bias[c];
+            if (res) v += res[(size_t)r * ldr + c];
+            out[(size_t)r * ldo + c] = apply_act(v, act);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// out = act(LN(x + pre) * gamma + beta + post); one wave per row
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ X, int ldx,
+                                                        const float *__restrict__ pre,
+                                                        const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta,
+                                                        const float *__restrict__ post,
+                                                        float *__restrict__ out, int ldo, int R, int C, int act) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float *x = X + (size_t)r * ldx;
+    const float *pr = pre ? pre + (size_t)r * C : nullptr;
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += x[c] + (pr ? pr[c] : 0.f);
+    const float mu = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = x[c] + (pr ? pr[c] : 0.f) - mu;
+        sq = fmaf(d, d, sq);
+    }
+    const float rs = rsqrtf(wave_sum(sq) / (float)C + 1e-5f);
+    const float *po = post ? post + (size_t)r * C : nullptr;
+    float *o = out + (size_t)r * ldo;
+    for (int c = lane; c < C; c += 64) {
+        float v = fmaf((x[c] + (pr ? pr[c] : 0.f) - mu) * rs, gamma[c], beta[c]);
+        if (po) v += po[c];
+        o[c] = apply_act(v, act);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 3-NN inverse-distance interpolation + concat [skip | interpolated]; one workgroup per fine point
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void three_interp_cat_kernel(
+    const float *__restrict__ xyz1_all, const float *__restrict__ xyz2_all, const int32_t *__restrict__ len2,
+    const float *__restrict__ fea1_all, const float *__restrict__ fea2_all, int N, int S, int D1, int D2,
+    float *__restrict__ out_all) {
+    const int b = blockIdx.y, n = blockIdx.x, t = threadIdx.x;
+    const float *p = xyz1_all + ((size_t)b * N + n) * 3;
+    const float *q = xyz2_all + (size_t)b * S * 3;
+    const float *f1 = fea1_all + ((size_t)b * N + n) * D1;
+    const float *f2 = fea2_all + (size_t)b * S * D2;
+    float *out = out_all + ((size_t)b * N + n) * (D1 + D2);
+    for (int c = t; c < D1; c += 128) out[c] = f1[c];
+    if (S == 1) {
+        for (int c = t; c < D2; c += 128) out[D1 + c] = f2[c];
+        return;
+    }
+    // every thread redundantly finds the 3 nearest valid coarse points (S <= a few hundred).
+    // expanded form -2ab + |a|^2 + |b|^2 like the reference (pointnext.py:205, utils.py:288-295)
+    const int ls = min(max(len2[b], 0), S);
+    const float px = p[0], py = p[1], pz = p[2];
+    const float pp = fmaf(pz, pz, fmaf(py, py, px * px));
+    float d0 = __builtin_inff(), d1 = d0, d2 = d0;
+    int i0 = 0, i1 = 0, i2 = 0;
+    for (int j = 0; j < ls; ++j) {
+        const float x = q[3 * j], y = q[3 * j + 1], z = q[3 * j + 2];
+        float d = -2.f * fmaf(pz, z, fmaf(py, y, px * x));
+        d += pp;
+        d += fmaf(z, z, fmaf(y, y, x * x));
+        if (d < d2) {
+            if (d < d1) {
+                d2 = d1, i2 = i1;
+                if (d < d0) d1 = d0, i1 = i0, d0 = d, i0 = j;
+                else d1 = d, i1 = j;
+            } else d2 = d, i2 = j;
+        }
+    }
+    float w0 = 1.f / fmaxf(d0, 1e-8f), w1 = 1.f / fmaxf(d1, 1e-8f), w2 = 1.f / fmaxf(d2, 1e-8f);
+    if (ls < 3) w2 = 0.f;
+    if (ls < 2) w1 = 0.f;
+    const float ws = w0 + w1 + w2;
+    w0 /= ws, w1 /= ws, w2 /= ws;
+    for (int c = t; c < D2; c += 128)
+        out[D1 + c] = f2[(size_t)i0 * D2 + c] * w0 + f2[(size_t)i1 * D2 + c] * w1 + f2[(size_t)i2 * D2 + c] * w2;
+}
+
+}  // namespace
+
+extern "C" int dpm_prepare_points(const float *points_cf, const uint8_t *padding, int B, int C, int N, float *xyz,
+                                  int32_t *lengths, dpm_stream_t stream) {
+    DPM_CHECK_ARG(points_cf && padding && xyz && lengths);
+    DPM_CHECK_ARG(B >= 1 && C >= 3 && N >= 1);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(lengths, 0, sizeof(int32_t) * (size_t)B, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(prepare_points_kernel, dim3(dpm_cdiv(N, 256), B), dim3(256), 0, st, points_cf, padding, C, N,
+                       xyz, lengths);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_to_channel_first(const float *x, int B, int R, int C, float *out, dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && out && B >= 1 && R >= 1 && C >= 1);
+    hipLaunchKernelGGL(to_channel_first_kernel, dim3(dpm_cdiv(C, 32), dpm_cdiv(R, 32), B), dim3(256), 0,
+                       (hipStream_t)stream, x, R, C, out);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_group_mlp_max(const float *xyz, const float *fea, const float *centers, const int32_t *idx,
+                                 const float *Wt, const float *bias, const float *gamma, const float *beta, int B,
+                                 int N, int S, int K, int Cin, int Cout, double radius, float *out,
+                                 dpm_stream_t stream) {
+    DPM_CHECK_ARG(xyz && fea && centers && idx && Wt && bias && gamma && beta && out);
+    DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && K <= 64 && Cin >= 1 && Cout >= 1 && radius > 0.0);
+    const size_t lds = sizeof(float) * ((size_t)K * (Cin + 3) + (size_t)K * Cout + 2 * K) + sizeof(int) * K;
+    if (lds > 160 * 1024) return DPM_EUNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)group_mlp_max_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(group_mlp_max_kernel, dim3(S, B), dim3(256), lds, (hipStream_t)stream, xyz, fea, centers, idx,
+                       Wt, bias, gamma, beta, N, S, K, Cin, Cout, (float)(1.0 / radius), out);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_linear(const float *x, int ldx, const float *W, int ldw, const float *bias, const float *residual,
+                          int ldr, float *out, int ldo, int R, int Cin, int Cout, int act, dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && W && out && R >= 1 && Cin >= 1 && Cout >= 1);
+    DPM_CHECK_ARG(ldx >= Cin && ldw >= Cin && ldo >= Cout && (!residual || ldr >= Cout));
+    DPM_CHECK_ARG(act >= DPM_ACT_NONE && act <= DPM_ACT_SIGMOID);
+    hipLaunchKernelGGL(linear_kernel, dim3(dpm_cdiv(Cout, 64), dpm_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, W, ldw, bias, residual, ldr, out, ldo, R, Cin, Cout, act);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_layernorm(const float *x, int ldx, const float *pre, const float *gamma, const float *beta,
+                             const float *post, float *out, int ldo, int R, int C, int act, dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && gamma && beta && out && R >= 1 && C >= 1 && ldx >= C && ldo >= C);
+    DPM_CHECK_ARG(act >= DPM_ACT_NONE && act <= DPM_ACT_SIGMOID);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(dpm_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, pre, gamma,
+                       beta, post, out, ldo, R, C, act);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_three_interp_cat(const float *xyz1, const float *xyz2, const int32_t *lengths2, const float *fea1,
+                                    const float *fea2, int B, int N, int S, int D1, int D2, float *out,
+                                    dpm_stream_t stream) {
+    DPM_CHECK_ARG(xyz1 && xyz2 && lengths2 && fea1 && fea2 && out);
+    DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && D1 >= 0 && D2 >= 1);
+    hipLaunchKernelGGL(three_interp_cat_kernel, dim3(N, B), dim3(128), 0, (hipStream_t)stream, xyz1, xyz2, lengths2,
+                       fea1, fea2, N, S, D1, D2, out);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_version(void) { return 1000; }
+
+extern "C" const char *dpm_error_string(int status) {
+    if (status == DPM_OK) return "ok";
+    if (status == DPM_EINVAL) return "invalid argument";
+    if (status == DPM_EUNSUPPORTED) return "unsupported shape";
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "unknown error";
+}

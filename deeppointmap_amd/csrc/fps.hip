@@ -1,0 +1,426 @@
+// Farthest point sampling for gfx950.  Replaces Sampler.fps / pytorch3d.sample_farthest_points
+// (reference network/encoder/utils.py:210-285).
+//
+// Bit-exact contract (checked against the reference's own outputs in tests): the squared
+// distance is (dx*dx + dy*dy) + dz*dz in fp32 with NO fused multiply-add, closest = min(d,
+// closest), and the next pick is the FIRST index attaining the maximum.  This translation unit
+// is compiled with -ffp-contract=off and additionally pins the pragma below.
+//
+// One workgroup per frame (the K-1 rounds of a frame are strictly serial); two algorithms:
+//
+//  * REGISTER (N <= 16384): every thread keeps PPT points (x,y,z,closest) in registers for the
+//    whole run; a round = PPT distance updates + one wave reduction + one LDS exchange.
+//
+//  * BUCKET (N up to 65536): points are counting-sorted by a 64x64 xy grid cell in Z-order and
+//    cut into buckets of 64 consecutive points (one bucket = one wave-wide load).  Thread t owns
+//    bucket t: its bounding box, its current max(closest) and the original index attaining it,
+//    all in registers.  A round tests every bucket's box against the newly selected point with
+//    the SAME fp32 expression as the point distance; because every fp32 operation involved is
+//    monotonic, box distance <= distance to any point in the box, so a bucket whose box
+//    distance >= its current max cannot change and is skipped -- the surviving ("active")
+//    buckets are the only global-memory traffic of the round.  Results are identical to brute
+//    force, bit for bit, including the first-index tie rule (buckets track the smallest
+//    original index among their maxima).  `closest` lives in the w component of the sorted
+//    float4 array in the caller's workspace.
+#include "dpm_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct Best {
+    float v;
+    int i;
+};
+
+__device__ __forceinline__ Best better(Best a, Best b) {
+    // larger value wins; on equal value the smaller index wins (torch.argmax = first maximum)
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+__device__ __forceinline__ Best wave_best(Best x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.v = __shfl_xor(x.v, off, 64);
+        o.i = __shfl_xor(x.i, off, 64);
+        x = better(x, o);
+    }
+    return x;
+}
+
+__device__ __forceinline__ float sqdist(float sx, float sy, float sz, float x, float y, float z) {
+    const float dx = sx - x, dy = sy - y, dz = sz - z;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// ------------------------------------------------------------------------------------------
+// REGISTER algorithm.  REG=false keeps `closest` in the workspace and re-reads xyz (fallback /
+// cross-check path for large N).
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, int PPT, bool REG>
+__global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xyz_all,
+                                                    const int32_t *__restrict__ lengths, int N, int K,
+                                                    int32_t *__restrict__ idx_all,
+                                                    float *__restrict__ new_xyz_all,
+                                                    int32_t *__restrict__ new_len, float *__restrict__ cd_ws) {
+    constexpr int NW = BLOCK / 64;
+    __shared__ float s_v[2][NW];
+    __shared__ int s_i[2][NW];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *xyz = xyz_all + (size_t)b * N * 3;
+    int32_t *idx = idx_all + (size_t)b * K;
+    float *new_xyz = new_xyz_all + (size_t)b * K * 3;
+    float *cdg = REG ? nullptr : cd_ws + (size_t)b * N;
+    const int len = min(max(lengths[b], 0), N);
+    const int kn = min(len, K);
+
+    float px[REG ? PPT : 1], py[REG ? PPT : 1], pz[REG ? PPT : 1], cd[REG ? PPT : 1];
+    if (REG) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int i = t + j * BLOCK;
+            const bool ok = i < len;
+            cd[j] = __builtin_inff();
+            px[j] = ok ? xyz[3 * i] : 0.f;
+            py[j] = ok ? xyz[3 * i + 1] : 0.f;
+            pz[j] = ok ? xyz[3 * i + 2] : 0.f;
+        }
+    } else {
+        for (int i = t; i < len; i += BLOCK) cdg[i] = __builtin_inff();
+    }
+    // slot 0 is index 0 even for an empty frame (utils.py:249-250)
+    int cur = 0;
+    if (t == 0) {
+        idx[0] = 0;
+        new_xyz[0] = xyz[0];
+        new_xyz[1] = xyz[1];
+        new_xyz[2] = xyz[2];
+        new_len[b] = max(kn, 1);
+    }
+    for (int r = 1; r < kn; ++r) {
+        const float sx = xyz[3 * cur], sy = xyz[3 * cur + 1], sz = xyz[3 * cur + 2];
+        Best best{-1.f, 0x7fffffff};
+        if (REG) {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int i = t + j * BLOCK;
+                if (i < len) {
+                    const float c = fminf(sqdist(sx, sy, sz, px[j], py[j], pz[j]), cd[j]);
+                    cd[j] = c;
+                    if (c > best.v) best = Best{c, i};  // ascending i: strict > keeps the first maximum
+                }
+            }
+        } else {
+            for (int i = t; i < len; i += BLOCK) {
+                const float c = fminf(sqdist(sx, sy, sz, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]), cdg[i]);
+                cdg[i] = c;
+                if (c > best.v) best = Best{c, i};
+            }
+        }
+        best = wave_best(best);
+        const int p = r & 1;
+        if ((t & 63) == 0) {
+            s_v[p][t >> 6] = best.v;
+            s_i[p][t >> 6] = best.i;
+        }
+        __syncthreads();
+        Best g{s_v[p][0], s_i[p][0]};
+#pragma unroll
+        for (int w = 1; w < NW; ++w) g = better(g, Best{s_v[p][w], s_i[p][w]});
+        cur = g.i;
+        if (t == 0) {
+            idx[r] = cur;
+            new_xyz[3 * r] = xyz[3 * cur];
+            new_xyz[3 * r + 1] = xyz[3 * cur + 1];
+            new_xyz[3 * r + 2] = xyz[3 * cur + 2];
+        }
+    }
+    // padding: -1 / zeros where the frame has fewer than K valid points
+    for (int r = max(kn, 1) + t; r < K; r += BLOCK) {
+        idx[r] = -1;
+        new_xyz[3 * r] = 0.f;
+        new_xyz[3 * r + 1] = 0.f;
+        new_xyz[3 * r + 2] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BUCKET algorithm, part 1: counting sort by Z-ordered grid cell -> sorted float4 + original ids
+// ------------------------------------------------------------------------------------------
+constexpr int FB = 1024;        // threads per frame workgroup
+constexpr int CELLS = 4096;     // 64 x 64 grid cells
+constexpr int MAXBUCKETS = FB;  // one bucket per thread -> N <= 65536
+
+__device__ __forceinline__ unsigned morton2_6(unsigned x, unsigned y) {
+    // interleave the low 6 bits of x and y (x in even positions)
+    unsigned r = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r |= ((x >> k) & 1u) << (2 * k) | ((y >> k) & 1u) << (2 * k + 1);
+    return r;
+}
+
+__global__ __launch_bounds__(FB) void fps_bucket_sort_kernel(const float *__restrict__ xyz_all,
+                                                             const int32_t *__restrict__ lengths, int N,
+                                                             float4 *__restrict__ pts_all,
+                                                             int32_t *__restrict__ orig_all) {
+    __shared__ int s_hist[CELLS];
+    __shared__ float s_red[4][FB / 64];
+    __shared__ int s_wsum[FB / 64];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float *xyz = xyz_all + (size_t)b * N * 3;
+    float4 *pts = pts_all + (size_t)b * N;
+    int32_t *orig = orig_all + (size_t)b * N;
+    const int len = min(max(lengths[b], 0), N);
+
+    // xy bounding box of the valid points
+    float lox = __builtin_inff(), loy = __builtin_inff(), hix = -__builtin_inff(), hiy = -__builtin_inff();
+    for (int i = t; i < len; i += FB) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1];
+        lox = fminf(lox, x), hix = fmaxf(hix, x), loy = fminf(loy, y), hiy = fmaxf(hiy, y);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lox = fminf(lox, __shfl_xor(lox, off, 64));
+        loy = fminf(loy, __shfl_xor(loy, off, 64));
+        hix = fmaxf(hix, __shfl_xor(hix, off, 64));
+        hiy = fmaxf(hiy, __shfl_xor(hiy, off, 64));
+    }
+    if (lane == 0) s_red[0][w] = lox, s_red[1][w] = loy, s_red[2][w] = hix, s_red[3][w] = hiy;
+    for (int c = t; c < CELLS; c += FB) s_hist[c] = 0;
+    __syncthreads();
+    for (int k = 0; k < FB / 64; ++k) {
+        lox = fminf(lox, s_red[0][k]), loy = fminf(loy, s_red[1][k]);
+        hix = fmaxf(hix, s_red[2][k]), hiy = fmaxf(hiy, s_red[3][k]);
+    }
+    const float sxc = (hix > lox) ? 64.f / (hix - lox) : 0.f;
+    const float syc = (hiy > loy) ? 64.f / (hiy - loy) : 0.f;
+    auto cell_of = [&](float x, float y) -> int {
+        const int cx = min(max((int)((x - lox) * sxc), 0), 63);
+        const int cy = min(max((int)((y - loy) * syc), 0), 63);
+        return (int)morton2_6((unsigned)cx, (unsigned)cy);
+    };
+    for (int i = t; i < len; i += FB) atomicAdd(&s_hist[cell_of(xyz[3 * i], xyz[3 * i + 1])], 1);
+    __syncthreads();
+    // exclusive scan of the 4096 counters: 4 per thread -> wave scan -> cross-wave offsets
+    int c0 = s_hist[4 * t], c1 = s_hist[4 * t + 1], c2 = s_hist[4 * t + 2], c3 = s_hist[4 * t + 3];
+    const int tsum = c0 + c1 + c2 + c3;
+    int inc = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wsum[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; ++k) base += s_wsum[k];
+    const int excl = base + inc - tsum;
+    s_hist[4 * t] = excl;
+    s_hist[4 * t + 1] = excl + c0;
+    s_hist[4 * t + 2] = excl + c0 + c1;
+    s_hist[4 * t + 3] = excl + c0 + c1 + c2;
+    __syncthreads();
+    for (int i = t; i < len; i += FB) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const int pos = atomicAdd(&s_hist[cell_of(x, y)], 1);
+        pts[pos] = make_float4(x, y, z, __builtin_inff());
+        orig[pos] = i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BUCKET algorithm, part 2: the sampling rounds
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict__ xyz_all,
+                                                        const int32_t *__restrict__ lengths, int N, int K,
+                                                        float4 *__restrict__ pts_all,
+                                                        const int32_t *__restrict__ orig_all,
+                                                        int32_t *__restrict__ idx_all,
+                                                        float *__restrict__ new_xyz_all,
+                                                        int32_t *__restrict__ new_len) {
+    constexpr int NW = FB / 64;
+    __shared__ float s_box[MAXBUCKETS][6];
+    __shared__ float s_bmax[MAXBUCKETS];
+    __shared__ int s_bidx[MAXBUCKETS];
+    __shared__ float s_bxyz[MAXBUCKETS][3];
+    __shared__ int s_list[MAXBUCKETS];
+    __shared__ int s_nact[2];
+    __shared__ float s_rv[NW];
+    __shared__ int s_ri[NW], s_rb[NW];
+
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float *xyz = xyz_all + (size_t)b * N * 3;
+    float4 *pts = pts_all + (size_t)b * N;
+    const int32_t *orig = orig_all + (size_t)b * N;
+    int32_t *idx = idx_all + (size_t)b * K;
+    float *new_xyz = new_xyz_all + (size_t)b * K * 3;
+    const int len = min(max(lengths[b], 0), N);
+    const int kn = min(len, K);
+    const int nb = (len + 63) >> 6;
+
+    // bucket bounding boxes: wave w builds buckets w, w+NW, ...
+    for (int bk = w; bk < nb; bk += NW) {
+        const int q = bk * 64 + lane;
+        float x0 = __builtin_inff(), y0 = x0, z0 = x0, x1 = -x0, y1 = -x0, z1 = -x0;
+        if (q < len) {
+            const float4 p = pts[q];
+            x0 = x1 = p.x, y0 = y1 = p.y, z0 = z1 = p.z;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, off, 64)), x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
+            y0 = fminf(y0, __shfl_xor(y0, off, 64)), y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+            z0 = fminf(z0, __shfl_xor(z0, off, 64)), z1 = fmaxf(z1, __shfl_xor(z1, off, 64));
+        }
+        if (lane == 0) {
+            s_box[bk][0] = x0, s_box[bk][1] = y0, s_box[bk][2] = z0;
+            s_box[bk][3] = x1, s_box[bk][4] = y1, s_box[bk][5] = z1;
+        }
+    }
+    if (t == 0) {
+        s_nact[0] = 0, s_nact[1] = 0;
+        idx[0] = 0;  // slot 0 is index 0 even for an empty frame (utils.py:249-250)
+        new_xyz[0] = xyz[0], new_xyz[1] = xyz[1], new_xyz[2] = xyz[2];
+        new_len[b] = max(kn, 1);
+    }
+    __syncthreads();
+    const bool mine = t < nb;
+    const float bx0 = mine ? s_box[t][0] : 0.f, by0 = mine ? s_box[t][1] : 0.f, bz0 = mine ? s_box[t][2] : 0.f;
+    const float bx1 = mine ? s_box[t][3] : 0.f, by1 = mine ? s_box[t][4] : 0.f, bz1 = mine ? s_box[t][5] : 0.f;
+    float bmax = __builtin_inff();  // every closest distance starts at +inf
+    int bidx = 0x7fffffff;
+    float sx = xyz[0], sy = xyz[1], sz = xyz[2];
+
+    for (int r = 1; r < kn; ++r) {
+        const int par = r & 1;
+        // ---- step 1: which buckets can change?  (box distance with the point-distance expression)
+        bool act = false;
+        if (mine) {
+            // nearest point of the box to s, per axis; (s - clamp) reproduces (s - x) monotonically
+            const float cx = fminf(fmaxf(sx, bx0), bx1), cy = fminf(fmaxf(sy, by0), by1),
+                        cz = fminf(fmaxf(sz, bz0), bz1);
+            act = sqdist(sx, sy, sz, cx, cy, cz) < bmax;
+        }
+        const unsigned long long m = __ballot(act);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_nact[par], __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (act) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+        __syncthreads();  // B1: list + count complete
+        const int nact = s_nact[par];
+        // ---- step 2: update the active buckets, one wave per bucket
+        for (int a = w; a < nact; a += NW) {
+            const int bk = s_list[a];
+            const int q = bk * 64 + lane;
+            Best best{-1.f, 0x7fffffff};
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (q < len) {
+                const float4 p = pts[q];
+                x = p.x, y = p.y, z = p.z;
+                const float d = sqdist(sx, sy, sz, x, y, z);
+                if (d < p.w) pts[q].w = d;
+                best = Best{fminf(d, p.w), orig[q]};
+            }
+            // reduce (value, original index) and remember which lane holds the winner
+            Best g = best;
+            int gl = lane;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                Best o;
+                o.v = __shfl_xor(g.v, off, 64);
+                o.i = __shfl_xor(g.i, off, 64);
+                const int ol = __shfl_xor(gl, off, 64);
+                if (o.v > g.v || (o.v == g.v && o.i < g.i)) g = o, gl = ol;
+            }
+            const float wx = __shfl(x, gl, 64), wy = __shfl(y, gl, 64), wz = __shfl(z, gl, 64);
+            if (lane == 0) {
+                s_bmax[bk] = g.v, s_bidx[bk] = g.i;
+                s_bxyz[bk][0] = wx, s_bxyz[bk][1] = wy, s_bxyz[bk][2] = wz;
+            }
+        }
+        __syncthreads();  // B2: bucket results visible
+        if (t == 0) s_nact[par] = 0;  // next use of this counter is two rounds away
+        if (act) bmax = s_bmax[t], bidx = s_bidx[t];
+        // ---- step 3: global argmax over the buckets
+        Best g{mine ? bmax : -1.f, mine ? bidx : 0x7fffffff};
+        int gb = t;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            Best o;
+            o.v = __shfl_xor(g.v, off, 64);
+            o.i = __shfl_xor(g.i, off, 64);
+            const int ob = __shfl_xor(gb, off, 64);
+            if (o.v > g.v || (o.v == g.v && o.i < g.i)) g = o, gb = ob;
+        }
+        if (lane == 0) s_rv[w] = g.v, s_ri[w] = g.i, s_rb[w] = gb;
+        __syncthreads();  // B3
+        g = Best{s_rv[0], s_ri[0]};
+        gb = s_rb[0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) {
+            const Best o{s_rv[k], s_ri[k]};
+            if (o.v > g.v || (o.v == g.v && o.i < g.i)) g = o, gb = s_rb[k];
+        }
+        sx = s_bxyz[gb][0], sy = s_bxyz[gb][1], sz = s_bxyz[gb][2];
+        if (t == 0) {
+            idx[r] = g.i;
+            new_xyz[3 * r] = sx, new_xyz[3 * r + 1] = sy, new_xyz[3 * r + 2] = sz;
+        }
+        // s_rv/s_ri/s_rb are rewritten only after B1 and B2 of the next round: no extra barrier
+    }
+    for (int r = max(kn, 1) + t; r < K; r += FB) {
+        idx[r] = -1;
+        new_xyz[3 * r] = 0.f, new_xyz[3 * r + 1] = 0.f, new_xyz[3 * r + 2] = 0.f;
+    }
+}
+
+template <int BLOCK, int PPT, bool REG>
+int launch(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx, float *new_xyz,
+           int32_t *new_len, float *ws, hipStream_t st) {
+    hipLaunchKernelGGL((fps_kernel<BLOCK, PPT, REG>), dim3(B), dim3(BLOCK), 0, st, xyz, lengths, N, K, idx,
+                       new_xyz, new_len, ws);
+    return dpm_launch_status();
+}
+
+}  // namespace
+
+extern "C" size_t dpm_fps_workspace_bytes(int B, int N, int K) {
+    (void)K;
+    // float4 sorted points (closest in .w) + int32 original ids, per frame
+    return (size_t)B * (size_t)N * (sizeof(float4) + sizeof(int32_t)) + 256;
+}
+
+extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
+                          float *new_xyz, int32_t *new_lengths, void *workspace, int algo,
+                          dpm_stream_t stream) {
+    DPM_CHECK_ARG(xyz && lengths && idx && new_xyz && new_lengths);
+    DPM_CHECK_ARG(B >= 1 && N >= 1 && K >= 1);
+    DPM_CHECK_ARG(algo >= 0 && algo <= 2);
+    hipStream_t st = (hipStream_t)stream;
+    if (algo == 0) algo = (N > 16384) ? 2 : 1;
+    if (algo == 2) {
+        if (N > 64 * MAXBUCKETS) return DPM_EUNSUPPORTED;
+        DPM_CHECK_ARG(workspace != nullptr);
+        uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+        float4 *pts = (float4 *)p;
+        int32_t *orig = (int32_t *)(pts + (size_t)B * N);
+        hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, pts, orig);
+        hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, orig, idx,
+                           new_xyz, new_lengths);
+        return dpm_launch_status();
+    }
+    float *ws = (float *)workspace;
+    if (N <= 64) return launch<64, 1, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
+    if (N <= 256) return launch<256, 1, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
+    if (N <= 1024) return launch<1024, 1, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
+    if (N <= 4096) return launch<1024, 4, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
+    if (N <= 16384) return launch<1024, 16, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
+    DPM_CHECK_ARG(workspace != nullptr);
+    return launch<1024, 1, false>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
+}
+
+extern "C" int dpm_fps(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
+                       float *new_xyz, int32_t *new_lengths, void *workspace, dpm_stream_t stream) {
+    return dpm_fps_ex(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, workspace, 0, stream);
+}

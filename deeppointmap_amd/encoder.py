@@ -1,0 +1,115 @@
+"""`Encoder` -- drop-in for the reference's network/encoder/encoder.py::Encoder.
+
+Same constructor (`Encoder(args)`), same state-dict keys/shapes (params.encoder_shapes), same
+call contract: `encoder(points (B,C>=3,N) f32, points_padding (B,N) bool) ->
+[coor (B,3,S), fea (B,out_channel,S), padding (B,S)]` (encoder.py:51-69).  Inputs may arrive on
+the CPU (ScanPack keeps CPU tensors, system/modules/pose_graph.py:43-45); they are staged to the
+module's GPU.  All arithmetic runs in libdpm_hip.so; there is no torch fallback.
+
+Internally everything is point-major fp32 with a per-frame valid length (valid points lead,
+exactly what the reference's FPS assumes, utils.py:255).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .params import ParamTree, encoder_shapes
+
+
+class Encoder(ParamTree):
+    def __init__(self, args):
+        super().__init__(encoder_shapes(args))
+        self.args = args
+        self.encoder_cfg = args.encoder
+        self.in_channel = self.encoder_cfg.in_channel
+        self.out_channel = self.encoder_cfg.out_channel
+        self.downsample_layers = len(self.encoder_cfg.npoint)
+        self.upsample_layers = self.encoder_cfg.upsample_layers
+        for s in self.encoder_cfg.sample:
+            if s["type"] not in ("fps", "fps-t3d"):
+                raise NotImplementedError(f"sampler {s['type']!r}: only farthest point sampling is implemented "
+                                          "(all shipped configs use fps-t3d)")
+        self._wt_cache: Dict[str, tuple] = {}
+        self.eval()
+
+    # -- helpers -------------------------------------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self.p("point_mlp0.weight").device
+
+    def _wt(self, key: str) -> torch.Tensor:
+        """(Cout, Cin+3, 1, 1) conv weight -> cached (Cin+3, Cout) transpose the grouped-MLP kernel reads."""
+        w = self.p(key)
+        tag = (w.data_ptr(), w._version, w.device)
+        hit = self._wt_cache.get(key)
+        if hit is None or hit[0] != tag:
+            hit = (tag, w.detach().reshape(w.shape[0], w.shape[1]).t().contiguous())
+            self._wt_cache[key] = hit
+        return hit[1]
+
+    def _mlp_ln(self, x: torch.Tensor, conv: str, ln: str, act: int, post: Optional[torch.Tensor] = None):
+        y = ops.linear(x, self.p(conv + ".weight"), self.p(conv + ".bias"))
+        return ops.layernorm(y, self.p(ln + ".weight"), self.p(ln + ".bias"), act=act, post=post)
+
+    def _group(self, prefix: str, radius: float, xyz, fea, centers, idx):
+        return ops.group_mlp_max(xyz, fea, centers, idx, self._wt(prefix + ".0.weight"), self.p(prefix + ".0.bias"),
+                                 self.p(prefix + ".1.ln.weight"), self.p(prefix + ".1.ln.bias"), radius)
+
+    # -- forward -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, points: torch.Tensor, points_padding: torch.Tensor, trace: Optional[dict] = None) -> List[torch.Tensor]:
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("deeppointmap_amd.Encoder runs on the GPU only: call .to('cuda') first "
+                               "(there is no CPU fallback)")
+        enc = self.encoder_cfg
+        with torch.cuda.device(dev):
+            pts = points.to(device=dev, dtype=torch.float32).contiguous()
+            pad = points_padding.to(device=dev).contiguous()
+            xyz, lengths = ops.prepare_points(pts, pad)
+            if self.in_channel == 3:
+                fea = ops.linear(xyz, self.p("point_mlp0.weight"), self.p("point_mlp0.bias"))
+            else:  # extra input channels: point-major copy of the first in_channel rows
+                fea = ops.linear(pts[:, :self.in_channel].transpose(1, 2).contiguous(),
+                                 self.p("point_mlp0.weight"), self.p("point_mlp0.bias"))
+            levels = [(xyz, fea, lengths)]
+            for i, npoint in enumerate(enc.npoint):
+                xyz, fea, lengths = levels[-1]
+                radii, ks = enc.radius_list[i], enc.nsample_list[i]
+                pre = f"downsampler.{i}"
+                fidx, new_xyz, new_len = ops.fps(xyz, lengths, npoint)
+                gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0])
+                new_fea = self._group(pre + ".sa.mlp", radii[0], xyz, fea, new_xyz, gidx)
+                if trace is not None:
+                    trace[pre + ".fps.idx"], trace[pre + ".fps.new"] = fidx, new_xyz
+                    trace[pre + ".sa.idx"], trace[pre + ".sa.out"] = gidx, new_fea
+                for j in range(1, len(radii)):
+                    q = f"{pre}.irm.{j - 1}"
+                    lidx = ops.knn_hybrid(new_xyz, new_len, new_xyz, ks[j], radii[j])
+                    t = self._group(q + ".la.mlp", radii[j], new_xyz, new_fea, new_xyz, lidx)
+                    u = self._mlp_ln(t, q + ".pw_conv.0", q + ".pw_conv.1.ln", ops.ACT_RELU)
+                    new_fea = self._mlp_ln(u, q + ".pw_conv.3", q + ".pw_conv.4.ln", ops.ACT_RELU, post=new_fea)
+                    if trace is not None:
+                        trace[q + ".la.idx"], trace[q + ".la.out"], trace[q + ".out"] = lidx, t, new_fea
+                levels.append((new_xyz, new_fea, new_len))
+            L = self.downsample_layers
+            for i in range(self.upsample_layers):
+                xyz1, fea1, len1 = levels[L - i - 1]
+                xyz2, fea2, len2 = levels[-1]
+                q = f"upsampler.{i}"
+                x = ops.three_interp_cat(xyz1, xyz2, len2, fea1, fea2)
+                x = self._mlp_ln(x, q + ".mlp.0", q + ".mlp.1.ln", ops.ACT_RELU)
+                x = self._mlp_ln(x, q + ".mlp.3", q + ".mlp.4.ln", ops.ACT_RELU)
+                if trace is not None:
+                    trace[q + ".out"] = x
+                levels.append((xyz1, x, len1))
+            xyz, fea, lengths = levels[-1]
+            S = xyz.shape[1]
+            coor = ops.to_channel_first(xyz)
+            feat = ops.to_channel_first(fea)
+            padding = torch.arange(S, device=dev).unsqueeze(0) >= lengths.unsqueeze(1)
+        return [coor, feat, padding]

@@ -1,0 +1,159 @@
+"""Thin torch-tensor wrappers over the C ABI (include/dpm_hip.h).
+
+torch provides device memory and the stream; every computation happens inside libdpm_hip.so.
+Tensors must live on a ROCm device ("cuda" in torch terms); layouts are point-major fp32,
+indices int32.  Nothing here falls back to torch math.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _lib.DpmError(f"{name}: expected a tensor on the GPU, got {t.device} (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def prepare_points(points_cf: torch.Tensor, padding: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(B,C,N) f32 + (B,N) bool -> xyz (B,N,3), lengths (B,) int32."""
+    _chk(points_cf, torch.float32, "points")
+    pad = _chk(padding.to(torch.uint8) if padding.dtype == torch.bool else padding, torch.uint8, "padding")
+    B, C, N = points_cf.shape
+    xyz = torch.empty(B, N, 3, device=points_cf.device, dtype=torch.float32)
+    lengths = torch.empty(B, device=points_cf.device, dtype=torch.int32)
+    lib = _lib.load()
+    _lib.check(lib.dpm_prepare_points(_ptr(points_cf), _ptr(pad), B, C, N, _ptr(xyz), _ptr(lengths),
+                                      _stream(xyz)), "dpm_prepare_points")
+    return xyz, lengths
+
+
+def to_channel_first(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    B, R, C = x.shape
+    out = torch.empty(B, C, R, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().dpm_to_channel_first(_ptr(x), B, R, C, _ptr(out), _stream(x)), "dpm_to_channel_first")
+    return out
+
+
+def fps(xyz: torch.Tensor, lengths: torch.Tensor, K: int, algo: int = 0):
+    """xyz (B,N,3), lengths (B,) -> idx (B,K) int32 (-1 = padding), new_xyz (B,K,3), new_lengths (B,)."""
+    _chk(xyz, torch.float32, "xyz")
+    _chk(lengths, torch.int32, "lengths")
+    B, N, _ = xyz.shape
+    lib = _lib.load()
+    idx = torch.empty(B, K, device=xyz.device, dtype=torch.int32)
+    new_xyz = torch.empty(B, K, 3, device=xyz.device, dtype=torch.float32)
+    new_len = torch.empty(B, device=xyz.device, dtype=torch.int32)
+    ws = torch.empty(lib.dpm_fps_workspace_bytes(B, N, K), device=xyz.device, dtype=torch.uint8)
+    _lib.check(lib.dpm_fps_ex(_ptr(xyz), _ptr(lengths), B, N, K, _ptr(idx), _ptr(new_xyz), _ptr(new_len),
+                              _ptr(ws), algo, _stream(xyz)), "dpm_fps")
+    return idx, new_xyz, new_len
+
+
+def knn_hybrid(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tensor, K: int,
+               radius: float) -> torch.Tensor:
+    """points (B,N,3), centers (B,S,3) -> idx (B,S,K) int32."""
+    _chk(points, torch.float32, "points")
+    _chk(centers, torch.float32, "centers")
+    _chk(lengths, torch.int32, "lengths")
+    B, N, _ = points.shape
+    S = centers.shape[1]
+    idx = torch.empty(B, S, K, device=points.device, dtype=torch.int32)
+    _lib.check(_lib.load().dpm_knn_hybrid(_ptr(points), _ptr(lengths), _ptr(centers), B, N, S, K, float(radius),
+                                          _ptr(idx), _stream(points)), "dpm_knn_hybrid")
+    return idx
+
+
+def group_mlp_max(xyz, fea, centers, idx, Wt, bias, gamma, beta, radius: float) -> torch.Tensor:
+    """xyz (B,N,3), fea (B,N,Cin), centers (B,S,3), idx (B,S,K), Wt (Cin+3,Cout) -> (B,S,Cout)."""
+    for n, t in (("xyz", xyz), ("fea", fea), ("centers", centers), ("Wt", Wt), ("bias", bias),
+                 ("gamma", gamma), ("beta", beta)):
+        _chk(t, torch.float32, n)
+    _chk(idx, torch.int32, "idx")
+    B, N, Cin = fea.shape
+    S, K = idx.shape[1], idx.shape[2]
+    Cout = Wt.shape[1]
+    if Wt.shape[0] != Cin + 3:
+        raise ValueError(f"Wt must be (Cin+3, Cout) = ({Cin + 3}, {Cout}), got {tuple(Wt.shape)}")
+    out = torch.empty(B, S, Cout, device=fea.device, dtype=torch.float32)
+    _lib.check(_lib.load().dpm_group_mlp_max(_ptr(xyz), _ptr(fea), _ptr(centers), _ptr(idx), _ptr(Wt), _ptr(bias),
+                                             _ptr(gamma), _ptr(beta), B, N, S, K, Cin, Cout, float(radius),
+                                             _ptr(out), _stream(fea)), "dpm_group_mlp_max")
+    return out
+
+
+def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (..., Cin) (last dim contiguous rows), W (Cout, Cin[,1[,1]]) -> (..., Cout).
+
+    `out` may be a column slice of a wider row-major buffer (its row stride is honoured)."""
+    _chk(W, torch.float32, "W")
+    Cout, Cin = W.shape[0], W.shape[1]
+    if x.dtype != torch.float32 or not x.is_cuda or x.stride(-1) != 1:
+        raise ValueError("x must be an fp32 GPU tensor with unit stride in the last dimension")
+    x2 = x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x
+    if x2.dim() != 2:
+        raise ValueError("non-contiguous x must be 2-D")
+    R = x2.shape[0]
+    if out is None:
+        out = torch.empty(*x.shape[:-1], Cout, device=x.device, dtype=torch.float32)
+    o2 = out.reshape(-1, Cout) if out.is_contiguous() else out
+    if o2.dim() != 2 or o2.stride(1) != 1:
+        raise ValueError("out must be 2-D with unit column stride")
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, Cout)
+        _chk(r2, torch.float32, "residual")
+    _lib.check(_lib.load().dpm_linear(_ptr(x2), x2.stride(0), _ptr(W), Cin, _ptr(bias), _ptr(r2),
+                                      Cout if r2 is not None else 0, _ptr(o2), o2.stride(0), R, Cin, Cout, act,
+                                      _stream(x)), "dpm_linear")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int = ACT_NONE,
+              pre: Optional[torch.Tensor] = None, post: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(LN(x + pre) * gamma + beta + post) over the last dimension."""
+    _chk(x, torch.float32, "x")
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    out = torch.empty_like(x)
+    for n, t in (("pre", pre), ("post", post)):
+        if t is not None:
+            _chk(t, torch.float32, n)
+            if t.numel() != x.numel():
+                raise ValueError(f"{n} must have the shape of x")
+    _lib.check(_lib.load().dpm_layernorm(_ptr(x2), C, _ptr(pre), _ptr(gamma), _ptr(beta), _ptr(post), _ptr(out), C,
+                                         x2.shape[0], C, act, _stream(x)), "dpm_layernorm")
+    return out
+
+
+def three_interp_cat(xyz1, xyz2, lengths2, fea1, fea2) -> torch.Tensor:
+    """fine xyz1 (B,N,3)/fea1 (B,N,D1), coarse xyz2 (B,S,3)/fea2 (B,S,D2) -> (B,N,D1+D2)."""
+    for n, t in (("xyz1", xyz1), ("xyz2", xyz2), ("fea1", fea1), ("fea2", fea2)):
+        _chk(t, torch.float32, n)
+    _chk(lengths2, torch.int32, "lengths2")
+    B, N, D1 = fea1.shape
+    S, D2 = fea2.shape[1], fea2.shape[2]
+    out = torch.empty(B, N, D1 + D2, device=fea1.device, dtype=torch.float32)
+    _lib.check(_lib.load().dpm_three_interp_cat(_ptr(xyz1), _ptr(xyz2), _ptr(lengths2), _ptr(fea1), _ptr(fea2),
+                                                B, N, S, D1, D2, _ptr(out), _stream(fea1)), "dpm_three_interp_cat")
+    return out

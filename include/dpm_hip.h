@@ -1,0 +1,106 @@
+/* dpm_hip.h -- C ABI of libdpm_hip.so: the MI355X (gfx950) kernels behind DeepPointMap's
+ * encode -> match -> register hot path.
+ *
+ * The reference has no FFI layer of its own: its lower boundary is the string-keyed operator
+ * tables `Sampler(method)` / `Querier(method)` (network/encoder/utils.py:21-28,129-133), the
+ * third-party pytorch3d ops they dispatch to (utils.py:12,94,102,115,278-283;
+ * system/modules/utils.py:10,80) and plain torch modules.  Each entry point below names the
+ * reference interface it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller, the
+ *    library never allocates, frees or retains it; scratch is passed in as `workspace`.
+ *  - all tensors are fp32, dense, "point-major": xyz (B,N,3), features (B,N,C); index
+ *    tensors are int32; `lengths[b]` = number of valid (leading) points of frame b.
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant and
+ *    free of global mutable state, so one Decoder may be driven from several host threads
+ *    (reference system/core.py:54-57,93-103).
+ *  - return value: 0 = ok, <0 = invalid argument / unsupported shape, >0 = hipError_t.
+ */
+#ifndef DPM_HIP_H
+#define DPM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *dpm_stream_t;
+
+#define DPM_OK 0
+#define DPM_EINVAL (-1)
+#define DPM_EUNSUPPORTED (-2)
+
+#define DPM_ACT_NONE 0
+#define DPM_ACT_RELU 1
+#define DPM_ACT_SIGMOID 2
+
+/* library / ABI version (major*1000+minor) and a printable name for a status code */
+int dpm_version(void);
+const char *dpm_error_string(int status);
+
+/* Encoder.forward input staging (network/encoder/encoder.py:52): channel-first (B,C,N) points +
+ * bool padding (B,N; nonzero = padded) -> xyz (B,N,3), lengths (B,) = count of valid points.
+ * Valid points must be the leading ones, as the reference's FPS assumes (utils.py:255). */
+int dpm_prepare_points(const float *points_cf, const uint8_t *padding, int B, int C, int N,
+                       float *xyz, int32_t *lengths, dpm_stream_t stream);
+
+/* (B,R,C) point-major -> (B,C,R) channel-first (the layout Encoder.forward returns). */
+int dpm_to_channel_first(const float *x, int B, int R, int C, float *out, dpm_stream_t stream);
+
+/* Sampler.fps / Sampler.fps_t3d == pytorch3d.ops.sample_farthest_points
+ * (network/encoder/utils.py:210-285): start index 0, dist = (dx*dx+dy*dy)+dz*dz evaluated in
+ * fp32 without contraction, next pick = first argmax.  idx (B,K) is -1 where lengths[b] < K;
+ * new_xyz (B,K,3) is zero there (masked_gather, utils.py:298-343); new_lengths[b] = number of
+ * idx >= 0.  workspace: dpm_fps_workspace_bytes(B,N,K) bytes. */
+size_t dpm_fps_workspace_bytes(int B, int N, int K);
+int dpm_fps(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
+            float *new_xyz, int32_t *new_lengths, void *workspace, dpm_stream_t stream);
+/* same, with the algorithm forced: 0 = auto, 1 = register/brute force, 2 = bucket-pruned
+ * (both give identical bits; tests run both). */
+int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
+               float *new_xyz, int32_t *new_lengths, void *workspace, int algo, dpm_stream_t stream);
+
+/* Querier.hybrid_query / hybrid_query_t3d == pytorch3d.ops.knn_points + radius mask
+ * (network/encoder/utils.py:76-89,113-123): for each centre the K nearest valid points, slots
+ * whose squared distance exceeds radius^2 replaced by the nearest index.  Slot 0 is the nearest
+ * point.  idx (B,S,K). */
+int dpm_knn_hybrid(const float *points, const int32_t *lengths, const float *centers, int B, int N,
+                   int S, int K, double radius, int32_t *idx, dpm_stream_t stream);
+
+/* SetAbstraction / LocalAggregation body (network/encoder/pointnext.py:52-61,97-107):
+ * out[b,s,:] = max_k relu(LN(W [fea[idx[b,s,k]], (xyz[idx]-center)/radius] + bias)).
+ * Wt (Cin+3, Cout) row-major = the TRANSPOSE of the Conv2d weight (Cout,Cin+3,1,1): first Cin
+ * rows features, last 3 relative xyz.  LN: eps 1e-5, biased variance, affine (gamma, beta). */
+int dpm_group_mlp_max(const float *xyz, const float *fea, const float *centers, const int32_t *idx,
+                      const float *Wt, const float *bias, const float *gamma, const float *beta,
+                      int B, int N, int S, int K, int Cin, int Cout, double radius, float *out,
+                      dpm_stream_t stream);
+
+/* 1x1 Conv1d / nn.Linear (build_mlp, network/encoder/utils.py:358-389; decoder heads):
+ * out[r, :Cout] = act(x[r,:Cin] W^T + bias + residual[r]); W (Cout,Cin) row-major with leading
+ * dimension ldw; x/out/residual have leading dimensions ldx/ldo/ldr (rows R). bias, residual
+ * may be NULL. */
+int dpm_linear(const float *x, int ldx, const float *W, int ldw, const float *bias,
+               const float *residual, int ldr, float *out, int ldo, int R, int Cin, int Cout, int act,
+               dpm_stream_t stream);
+
+/* LayerNorm1d / nn.LayerNorm over the channel axis (network/encoder/utils.py:392-402,
+ * descriptor_attention.py:20-22): out = act(LN(x + pre)*gamma + beta + post); pre/post NULL-able,
+ * all (R,C) with leading dimension = C except x (ldx) and out (ldo). */
+int dpm_layernorm(const float *x, int ldx, const float *pre, const float *gamma, const float *beta,
+                  const float *post, float *out, int ldo, int R, int C, int act, dpm_stream_t stream);
+
+/* FeaturePropagation interpolation (network/encoder/pointnext.py:199-216): for each fine point
+ * the 3 nearest valid coarse points (expanded-form distance), w_j = (1/max(d_j,1e-8))/sum;
+ * out[b,n,:] = cat[fea1[b,n,:D1], sum_j w_j fea2[b,idx_j,:D2]].  S==1 broadcasts fea2. */
+int dpm_three_interp_cat(const float *xyz1, const float *xyz2, const int32_t *lengths2,
+                         const float *fea1, const float *fea2, int B, int N, int S, int D1, int D2,
+                         float *out, dpm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPM_HIP_H */

@@ -1,0 +1,64 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly what include/dpm_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "dpm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dpm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from deeppointmap_amd import _lib
+    from deeppointmap_amd.csrc import build
+    build.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/dpm_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "python binding table and header disagree"
+
+
+def test_version_and_error_strings_need_no_gpu():
+    from deeppointmap_amd import _lib
+    lib = _lib.load()
+    assert lib.dpm_version() >= 1000
+    assert lib.dpm_error_string(0) == b"ok"
+    assert b"invalid" in lib.dpm_error_string(-1)
+    assert b"unsupported" in lib.dpm_error_string(-2)
+    with pytest.raises(ValueError):
+        _lib.check(-1, "x")
+    with pytest.raises(_lib.DpmError):
+        _lib.check(1, "x")
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from deeppointmap_amd import _lib, ops
+    with pytest.raises(_lib.DpmError):
+        ops.fps(torch.zeros(1, 8, 3), torch.full((1,), 8, dtype=torch.int32), 4)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from deeppointmap_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.DpmError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_state_dict_layout(cfg_full):
+    from deeppointmap_amd.params import decoder_shapes, encoder_shapes
+    e, d = encoder_shapes(cfg_full), decoder_shapes(cfg_full)
+    assert len(e) == 110 and len(d) == 82  # tensor counts of the reference modules
+    num = lambda s: sum(int(__import__("numpy").prod(v)) for v in s.values())
+    assert num(e) == 3824224 and num(d) == 2776260
+    assert e["downsampler.0.sa.mlp.0.weight"] == (32, 19, 1, 1)
+    assert d["descriptor_attention.2.cross_attn.in_proj_weight"] == (768, 256)

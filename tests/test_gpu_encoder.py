@@ -1,0 +1,71 @@
+"""GPU: Encoder.forward (HIP path) against reference fixtures and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, idx_rows_equal_as_sets, load_golden
+from oracle import dpm_oracle as O
+from deeppointmap_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_encoder(cfg):
+    from deeppointmap_amd.encoder import Encoder
+    from deeppointmap_amd.weights import init_procedural
+    return init_procedural(Encoder(cfg)).to(DEV)
+
+
+@pytest.mark.parametrize("fixture", ["encoder_reduced.npz", "encoder_reduced_padded.npz"])
+def test_encoder_reduced_per_stage_vs_reference(fixture, cfg_reduced):
+    g = load_golden(fixture)
+    enc = make_encoder(cfg_reduced)
+    pts = T(g["points"])
+    if "length" in g:
+        pad = torch.arange(pts.shape[2]).unsqueeze(0) >= int(g["length"])
+    else:
+        pad = torch.zeros(pts.shape[0], pts.shape[2], dtype=torch.bool)
+    tr = {}
+    coor, fea, mask = enc(pts, pad, trace=tr)  # CPU inputs: the module stages them
+    assert coor.is_cuda and fea.is_cuda
+    assert np.array_equal(coor.cpu().numpy(), g["coor"]), "keypoint coordinates must be bit-identical"
+    assert np.array_equal(mask.cpu().numpy(), g["mask"])
+    for k, v in g.items():
+        if k.endswith(".fps.new"):
+            assert np.array_equal(tr[k].cpu().numpy(), v), k
+        elif k.endswith(".idx") and not k.endswith("fps.idx"):
+            got = tr[k].cpu().numpy().reshape(v.shape)
+            assert idx_rows_equal_as_sets(got.reshape(-1, v.shape[-1]), v.reshape(-1, v.shape[-1])).mean() > 0.995, k
+        elif k.endswith(".out"):
+            np.testing.assert_allclose(tr[k].cpu().numpy(), v, rtol=0, atol=3e-4, err_msg=k)
+    np.testing.assert_allclose(fea.cpu().numpy(), g["fea"], rtol=0, atol=3e-4)
+
+
+@pytest.mark.parametrize("tag", ["synthetic0", "synthetic1", "kitti0", "kitti1"])
+def test_encoder_full_descriptors_vs_reference(tag, cfg_full):
+    g = load_golden("encoder_full.npz")
+    enc = make_encoder(cfg_full)
+    if tag.startswith("synthetic"):
+        p = synthetic.frame(int(tag[-1])).unsqueeze(0)
+    else:
+        p = T(g[tag + ".points"]).unsqueeze(0)
+    coor, fea, mask = enc(p.to(DEV), torch.zeros(1, p.shape[2], dtype=torch.bool, device=DEV))
+    assert tuple(coor.shape) == (1, 3, 256) and tuple(fea.shape) == (1, 128, 256) and not bool(mask.any())
+    assert np.array_equal(coor[0].cpu().numpy(), g[tag + ".coor"])
+    np.testing.assert_allclose(fea[0].cpu().numpy(), g[tag + ".fea"], rtol=0, atol=3e-4)
+
+
+def test_encoder_batch_equals_single_frames(cfg_full):
+    enc = make_encoder(cfg_full)
+    pts, pad = synthetic.frames(3, 16384)
+    coor, fea, _ = enc(pts, pad)
+    for b in range(3):
+        c1, f1, _ = enc(pts[b:b + 1], pad[b:b + 1])
+        assert torch.equal(c1[0], coor[b]) and torch.equal(f1[0], fea[b])
+
+
+def test_encoder_rejects_cpu_module(cfg_reduced):
+    from deeppointmap_amd.encoder import Encoder
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Encoder(cfg_reduced)(torch.zeros(1, 3, 64), torch.zeros(1, 64, dtype=torch.bool))

@@ -1,0 +1,192 @@
+"""GPU: every C-ABI entry point of the encoder against the oracle / reference fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, idx_rows_equal_as_sets, load_golden
+from oracle import dpm_oracle as O
+from deeppointmap_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from deeppointmap_amd import ops as _ops
+    return _ops
+
+
+def _lengths(vals):
+    return torch.tensor(vals, dtype=torch.int32, device=DEV)
+
+
+def knn_rows_ok(idx_gpu, points, centers, radius, tol=2e-6):
+    """Per row: same index set as the exact fp64 answer, except for members whose distance is
+    within `tol` of the radius^2 cut or of the K-th distance (documented borderline margin)."""
+    idx_gpu = np.asarray(idx_gpu)
+    P, C = np.asarray(points, np.float64), np.asarray(centers, np.float64)
+    S, K = idx_gpu.shape
+    bad = 0
+    for s in range(S):
+        d = ((P - C[s]) ** 2).sum(1)
+        order = np.argsort(d, kind="stable")[:K]
+        want = set(int(i) if d[i] <= radius ** 2 else int(order[0]) for i in order)
+        got = set(int(i) for i in idx_gpu[s])
+        if got == want:
+            continue
+        dk = d[order[-1]]
+        for i in got ^ want:
+            if not (abs(d[i] - radius ** 2) <= tol or abs(d[i] - dk) <= tol):
+                bad += 1
+                break
+    return bad
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("algo", [1, 2])
+def test_fps_bit_exact_vs_reference_fixtures(ops, algo):
+    g = load_golden("fps.npz")
+    names = sorted({k.rsplit(".", 1)[0] for k in g if k.endswith(".points")})
+    for n in names:
+        pts, length, K = T(g[n + ".points"]), int(g[n + ".length"]), g[n + ".new"].shape[0]
+        idx, new, nl = ops.fps(pts.unsqueeze(0).to(DEV), _lengths([length]), K, algo=algo)
+        assert np.array_equal(new[0].cpu().numpy(), g[n + ".new"]), (n, algo)
+        assert np.array_equal((idx[0] < 0).cpu().numpy(), g[n + ".mask"]), (n, algo)
+        assert int(nl[0]) == min(length, K)
+
+
+@pytest.mark.parametrize("algo", [0, 1, 2])
+def test_fps_full_size_synthetic_bit_exact(ops, algo):
+    g = load_golden("fps.npz")
+    pts = synthetic.frame(0).t().contiguous()
+    idx, new, _ = ops.fps(pts.unsqueeze(0).to(DEV), _lengths([65536]), 4096, algo=algo)
+    assert np.array_equal(new[0].cpu().numpy(), g["synthetic0_k4096.new"])
+    want = O.fps_indices_fast(pts, 65536, 4096)
+    assert torch.equal(idx[0].cpu().long(), want)
+
+
+def test_fps_batched_ragged_and_ties(ops):
+    gen = torch.Generator().manual_seed(4)
+    B, N, K = 5, 20000, 700
+    pts = torch.rand(B, N, 3, generator=gen)
+    pts[1] = torch.round(pts[1] * 8) / 8  # heavy ties: first-index rule must hold
+    lens = [20000, 20000, 17001, 300, 1]
+    for algo in (1, 2):
+        idx, new, nl = ops.fps(pts.to(DEV), _lengths(lens), K, algo=algo)
+        for b in range(B):
+            want = O.fps_indices_fast(pts[b], lens[b], K)
+            assert torch.equal(idx[b].cpu().long(), want), (algo, b)
+            assert torch.equal(new[b].cpu(), O.gather_masked(pts[b], want))
+        assert nl.cpu().tolist() == [min(l, K) for l in lens]
+
+
+def test_fps_all_levels_sizes(ops):
+    gen = torch.Generator().manual_seed(6)
+    for N, K in [(4096, 1024), (1024, 256), (256, 64), (64, 16), (16, 16), (3, 8)]:
+        pts = torch.rand(2, N, 3, generator=gen)
+        idx, _, _ = ops.fps(pts.to(DEV), _lengths([N, max(N - 2, 1)]), K)
+        for b, l in enumerate([N, max(N - 2, 1)]):
+            assert torch.equal(idx[b].cpu().long(), O.fps_indices_fast(pts[b], l, K)), (N, K, b)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_knn_vs_reference_fixtures(ops):
+    g = load_golden("knn.npz")
+    names = sorted({k.rsplit(".", 1)[0] for k in g if k.endswith(".idx")})
+    for n in names:
+        pts, ctr, length = T(g[n + ".points"]), T(g[n + ".centers"]), int(g[n + ".length"])
+        r, K = float(g[n + ".radius"]), g[n + ".idx"].shape[1]
+        idx = ops.knn_hybrid(pts.unsqueeze(0).to(DEV), _lengths([length]), ctr.unsqueeze(0).to(DEV), K, r)[0].cpu().numpy()
+        same = idx_rows_equal_as_sets(idx, g[n + ".idx"])
+        assert same.mean() > 0.995, (n, same.mean())
+        assert knn_rows_ok(idx, pts[:length].numpy(), ctr.numpy(), r) == 0, n
+        # slot 0 is the nearest point (the centre itself here: centres are a subset of points)
+        d0 = (pts[idx[:, 0]] - ctr).pow(2).sum(1)
+        assert float(d0.max()) == 0.0
+
+
+def test_knn_dense_cluster_overflows_candidate_list(ops):
+    # > CAP points inside the radius forces the in-kernel compaction path
+    gen = torch.Generator().manual_seed(8)
+    pts = torch.cat([torch.randn(3000, 3, generator=gen) * 0.01, torch.rand(1000, 3, generator=gen)]).unsqueeze(0)
+    ctr = pts[:, :37].contiguous()
+    idx = ops.knn_hybrid(pts.to(DEV), _lengths([4000]), ctr.to(DEV), 32, 0.2)[0].cpu().numpy()
+    assert knn_rows_ok(idx, pts[0].numpy(), ctr[0].numpy(), 0.2) == 0
+
+
+def test_knn_sparse_rows_pad_with_nearest(ops):
+    pts = torch.tensor([[[0.0, 0, 0], [0.01, 0, 0], [5, 5, 5], [9, 9, 9]]])
+    ctr = torch.tensor([[[0.0, 0, 0], [5.2, 5, 5], [100, 100, 100]]])
+    idx = ops.knn_hybrid(pts.to(DEV), _lengths([4]), ctr.to(DEV), 4, 0.5)[0].cpu().tolist()
+    assert sorted(idx[0]) == [0, 0, 0, 1] and idx[0][0] == 0
+    assert idx[1] == [2, 2, 2, 2]
+    assert idx[2] == [3, 3, 3, 3]  # nothing within the radius: every slot is the nearest point
+
+
+# ------------------------------------------------------------------------------------------------
+def test_linear_layernorm_interp_vs_torch(ops):
+    gen = torch.Generator().manual_seed(2)
+    for R, Cin, Cout in [(1000, 3, 16), (257, 515, 512), (64, 768, 256), (130, 128, 3), (5, 512, 1)]:
+        x, W, b = torch.randn(R, Cin, generator=gen), torch.randn(Cout, Cin, generator=gen) / Cin ** 0.5, torch.randn(Cout, generator=gen)
+        res = torch.randn(R, Cout, generator=gen)
+        y = ops.linear(x.to(DEV), W.to(DEV), b.to(DEV), act=ops.ACT_RELU, residual=res.to(DEV)).cpu()
+        want = torch.relu(x.double() @ W.double().t() + b.double() + res.double()).float()
+        torch.testing.assert_close(y, want, rtol=1e-5, atol=2e-5)
+    y = ops.linear(x.to(DEV), W.to(DEV), None, act=ops.ACT_SIGMOID).cpu()
+    torch.testing.assert_close(y, torch.sigmoid(x @ W.t()), rtol=1e-5, atol=1e-6)
+    # strided output (column slice of a wider buffer)
+    buf = torch.zeros(7, 40, device=DEV)
+    x, W = torch.randn(7, 9, generator=gen), torch.randn(12, 9, generator=gen)
+    ops.linear(x.to(DEV), W.to(DEV), None, out=buf[:, 20:32])
+    torch.testing.assert_close(buf[:, 20:32].cpu(), x @ W.t(), rtol=1e-5, atol=1e-5)
+    assert float(buf[:, :20].abs().sum()) == 0 and float(buf[:, 32:].abs().sum()) == 0
+    for R, C in [(300, 32), (17, 2048), (256, 256)]:
+        x, pre, post = (torch.randn(R, C, generator=gen) * 3 for _ in range(3))
+        gm, bt = torch.randn(C, generator=gen), torch.randn(C, generator=gen)
+        y = ops.layernorm(x.to(DEV), gm.to(DEV), bt.to(DEV), act=ops.ACT_RELU, pre=pre.to(DEV), post=post.to(DEV)).cpu()
+        want = torch.relu(torch.nn.functional.layer_norm(x + pre, (C,), gm, bt, 1e-5) + post)
+        torch.testing.assert_close(y, want, rtol=1e-5, atol=2e-5)
+
+
+def test_three_interp_vs_oracle(ops):
+    gen = torch.Generator().manual_seed(12)
+    B, N, S, D1, D2 = 2, 64, 16, 24, 40
+    xyz1 = torch.rand(B, N, 3, generator=gen)
+    xyz2 = xyz1[:, :S].contiguous()  # coarse points coincide with fine ones (d = 0 -> clamp 1e-8)
+    f1, f2 = torch.randn(B, N, D1, generator=gen), torch.randn(B, S, D2, generator=gen)
+    out = ops.three_interp_cat(xyz1.to(DEV), xyz2.to(DEV), _lengths([S, S]), f1.to(DEV), f2.to(DEV)).cpu()
+    d, i = torch.topk(O.expanded_sqdist(xyz1, xyz2), 3, dim=-1, largest=False)
+    w = 1.0 / d.clamp(min=1e-8)
+    w = w / w.sum(2, keepdim=True)
+    bi = torch.arange(B).view(B, 1, 1)
+    want = torch.cat([f1, (f2[bi, i] * w.unsqueeze(-1)).sum(2)], dim=-1)
+    torch.testing.assert_close(out, want, rtol=1e-4, atol=1e-4)
+
+
+def test_group_mlp_max_vs_oracle(ops):
+    gen = torch.Generator().manual_seed(21)
+    for (N, S, K, Cin, Cout) in [(500, 40, 32, 16, 32), (128, 16, 16, 256, 512), (300, 9, 32, 128, 256)]:
+        B = 2
+        xyz, fea = torch.rand(B, N, 3, generator=gen), torch.randn(B, N, Cin, generator=gen)
+        ctr = xyz[:, :S].contiguous()
+        idx = torch.randint(0, N, (B, S, K), generator=gen)
+        sd = {"m.0.weight": torch.randn(Cout, Cin + 3, 1, 1, generator=gen) / (Cin + 3) ** 0.5,
+              "m.0.bias": torch.randn(Cout, generator=gen) * 0.1,
+              "m.1.ln.weight": 1 + 0.1 * torch.randn(Cout, generator=gen), "m.1.ln.bias": 0.1 * torch.randn(Cout, generator=gen)}
+        want = O.grouped_mlp_max(sd, "m", 0.3, xyz, fea, ctr, idx)
+        Wt = sd["m.0.weight"].reshape(Cout, Cin + 3).t().contiguous()
+        got = ops.group_mlp_max(xyz.to(DEV), fea.to(DEV), ctr.to(DEV), idx.int().to(DEV), Wt.to(DEV), sd["m.0.bias"].to(DEV),
+                                sd["m.1.ln.weight"].to(DEV), sd["m.1.ln.bias"].to(DEV), 0.3).cpu()
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+
+
+def test_prepare_and_channel_first(ops):
+    gen = torch.Generator().manual_seed(5)
+    pts = torch.randn(3, 4, 1000, generator=gen)
+    pad = torch.arange(1000).unsqueeze(0) >= torch.tensor([[1000], [640], [1]])
+    xyz, lens = ops.prepare_points(pts.to(DEV), pad.to(DEV))
+    assert torch.equal(xyz.cpu(), pts[:, :3].transpose(1, 2).contiguous())
+    assert lens.cpu().tolist() == [1000, 640, 1]
+    x = torch.randn(2, 77, 131, generator=gen)
+    assert torch.equal(ops.to_channel_first(x.to(DEV)).cpu(), x.transpose(1, 2).contiguous())
