@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Build libdpm_hip.so (gfx950) in-tree with hipcc.  `python deeppointmap_amd/csrc/build.py`.
 
-hipcc cross-compiles without a GPU.  fps.hip is compiled with -ffp-contract=off (bit-exact
-distance arithmetic); everything else uses explicit fmaf where fusion is wanted.
+hipcc cross-compiles without a GPU.  Everything is compiled with -ffp-contract=off: the distance
+arithmetic of FPS / kNN / interpolation must round exactly like the reference's; kernels use
+explicit fmaf() wherever fusion is wanted.
 """
 import os
 import subprocess
@@ -12,9 +13,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "libdpm_hip.so")
 ARCH = "gfx950"
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-ffp-contract=off"]
 SOURCES = {
-    "fps.hip": ["-ffp-contract=off"],
+    "fps.hip": [],
     "knn.hip": [],
     "encoder_ops.hip": [],
 }

@@ -1,6 +1,7 @@
 // Dense / gather kernels of the encoder (and the small linear algebra the decoder shares):
 // input staging, grouped MLP + LayerNorm + ReLU + max (SetAbstraction / LocalAggregation),
 // linear, LayerNorm, 3-NN feature propagation.  fp32 throughout, like the reference.
+// Compiled with -ffp-contract=off: every fused multiply-add is an explicit fmaf().
 #include "dpm_common.h"
 
 namespace {
@@ -214,14 +215,14 @@ __global__ __launch_bounds__(128) void three_interp_cat_kernel(
     // expanded form -2ab + |a|^2 + |b|^2 like the reference (pointnext.py:205, utils.py:288-295)
     const int ls = min(max(len2[b], 0), S);
     const float px = p[0], py = p[1], pz = p[2];
-    const float pp = fmaf(pz, pz, fmaf(py, py, px * px));
+    const float pp = (px * px + py * py) + pz * pz;  // torch.sum(p**2,-1): sequential, unfused
     float d0 = __builtin_inff(), d1 = d0, d2 = d0;
     int i0 = 0, i1 = 0, i2 = 0;
     for (int j = 0; j < ls; ++j) {
         const float x = q[3 * j], y = q[3 * j + 1], z = q[3 * j + 2];
         float d = -2.f * fmaf(pz, z, fmaf(py, y, px * x));
         d += pp;
-        d += fmaf(z, z, fmaf(y, y, x * x));
+        d += (x * x + y * y) + z * z;
         if (d < d2) {
             if (d < d1) {
                 d2 = d1, i2 = i1;
@@ -274,7 +275,7 @@ extern "C" int dpm_group_mlp_max(const float *xyz, const float *fea, const float
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(group_mlp_max_kernel, dim3(S, B), dim3(256), lds, (hipStream_t)stream, xyz, fea, centers, idx,
-                       Wt, bias, gamma, beta, N, S, K, Cin, Cout, (float)(1.0 / radius), out);
+                       Wt, bias, gamma, beta, N, S, K, Cin, Cout, 1.0f / (float)radius, out);
     return dpm_launch_status();
 }
 

@@ -6,11 +6,23 @@
 // squared distance exceeds r^2 with slot 0 (the nearest).  That equals "the K nearest among the
 // points within r, padded with the nearest point", which is what is computed here: a scan keeps
 // only candidates with d <= min(r^2, current K-th best), so the per-centre candidate list stays
-// tiny and no (S,N) distance matrix is ever materialised.  Distances use the direct form
-// (dx^2+dy^2+dz^2) like pytorch3d's kernel; the reference's CPU fallback uses the expanded form,
-// which differs by a few 1e-7 -- tests compare index SETS with that borderline margin.
+// tiny and no (S,N) distance matrix is ever materialised.  Distances reproduce the reference's
+// CPU path bit for bit: coordinate_distance (utils.py:288-295) evaluates the EXPANDED form
+//   d = ((-2 * dot) + |a|^2) + |b|^2,  dot = fma(az,bz, fma(ay,by, ax*bx)),  |v|^2 = (x*x+y*y)+z*z
+// (the K=3 sgemm is an fma chain in k order; verified equal on 3.3e7 pairs in the build container),
+// so radius cuts and K-th-neighbour cuts fall exactly where the reference's fall.  This file is
+// compiled with -ffp-contract=off; every fused operation below is an explicit fmaf.
 // Padded points (index >= lengths[b]) are ignored: the reference moves them to 3*max|coord|,
 // which is never nearer than any valid point, so they can only ever be masked out.
+//
+// Exact ties: when the K-th and (K+1)-th nearest have bit-equal distances, which of them the
+// reference keeps is decided by libstdc++'s std::partial_sort (heap-select), which torch.topk's
+// CPU kernel uses whenever K*64 <= N.  Such rows are rare (about 3 of 4096 at the first stage,
+// where the expanded form quantises distances to ~1e-7) but one flipped neighbour moves the final
+// pose by ~1e-4 m, so rows flagged with a boundary tie are re-run through a sequential emulation
+// of heap-select (make_heap over the first K points, then pop/replace in index order) and give
+// exactly the reference's set.  For K*64 > N the reference uses std::nth_element; ties there
+// keep the smaller index (none occur on the shipped shapes).
 //
 // v1 structure: one wave handles CPW centres and streams all points of the frame (64 per step,
 // coalesced); a wave-aggregated append (ballot + popcount) puts survivors into a per-centre LDS
@@ -24,6 +36,7 @@ constexpr int CPW = 4;    // centres per wave
 constexpr int WPB = 4;    // waves per block
 constexpr int CAP = 512;  // candidate slots per centre
 constexpr int KMAX = 64;
+constexpr int TMPN = 128;  // scratch entries per wave (>= KMAX + 1 and >= 64)
 
 __device__ __forceinline__ void wave_mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -59,6 +72,71 @@ __device__ __forceinline__ void select_smallest(volatile float *cd, volatile int
     }
 }
 
+// libstdc++ __adjust_heap + __push_heap on (value, index) pairs ordered by value only
+__device__ void heap_adjust(volatile float *hv, volatile int *hi, int hole, int len, float val, int vi) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (hv[child] < hv[child - 1]) child--;
+        hv[hole] = hv[child], hi[hole] = hi[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        hv[hole] = hv[child - 1], hi[hole] = hi[child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && hv[parent] < val) {
+        hv[hole] = hv[parent], hi[hole] = hi[parent];
+        hole = parent, parent = (hole - 1) / 2;
+    }
+    hv[hole] = val, hi[hole] = vi;
+}
+
+// Sequential emulation of std::partial_sort's heap-select over the whole row (see header).
+// hv/hi: K-entry heap in LDS; tv: 64-entry staging.  On return hv/hi hold the K survivors.
+__device__ void heap_select_exact(const float *__restrict__ pts, int len, int K, float cx, float cy, float cz,
+                                  float caa, volatile float *hv, volatile int *hi, volatile float *tv) {
+    const int lane = lane_id();
+    auto dist = [&](int i) -> float {
+        if (i >= len) return __builtin_inff();
+        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        const float bb = (x * x + y * y) + z * z;
+        return ((-2.f * fmaf(cz, z, fmaf(cy, y, cx * x))) + caa) + bb;
+    };
+    if (lane < K) hv[lane] = dist(lane), hi[lane] = lane;
+    wave_mem_sync();
+    if (lane == 0 && K >= 2) {  // std::__make_heap
+        for (int parent = (K - 2) / 2;; --parent) {
+            heap_adjust(hv, hi, parent, K, hv[parent], hi[parent]);
+            if (parent == 0) break;
+        }
+    }
+    wave_mem_sync();
+    for (int base = K; base < len; base += 64) {
+        const int i = base + lane;
+        const float d = dist(i);
+        const float top = hv[0];
+        const unsigned long long m = __ballot(d < top);
+        if (m) {
+            tv[lane] = d;
+            wave_mem_sync();
+            if (lane == 0) {
+                unsigned long long mm = m;
+                while (mm) {
+                    const int l = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const float dl = tv[l];
+                    if (dl < hv[0]) heap_adjust(hv, hi, 0, K, dl, base + l);  // std::__pop_heap(first, middle, i)
+                }
+            }
+            wave_mem_sync();
+        }
+    }
+}
+
 __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__restrict__ points_all,
                                                               const int32_t *__restrict__ lengths,
                                                               const float *__restrict__ centers_all, int N,
@@ -66,8 +144,8 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
                                                               int32_t *__restrict__ idx_all) {
     __shared__ float s_d[WPB][CPW][CAP];
     __shared__ int s_i[WPB][CPW][CAP];
-    __shared__ float s_td[WPB][KMAX];
-    __shared__ int s_ti[WPB][KMAX];
+    __shared__ float s_td[WPB][TMPN];
+    __shared__ int s_ti[WPB][TMPN];
     const int b = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s0 = (blockIdx.x * WPB + w) * CPW;
     if (s0 >= S) return;  // whole wave exits together; no block-wide barrier is used below
@@ -75,13 +153,16 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
     const float *ctr = centers_all + (size_t)b * S * 3;
     const int len = min(max(lengths[b], 0), N);
 
-    float cx[CPW], cy[CPW], cz[CPW], thr[CPW], gd[CPW];
+    float cx[CPW], cy[CPW], cz[CPW], caa[CPW], thr[CPW], gd[CPW];
     int gi[CPW], cnt[CPW];
+    bool tie[CPW];
+    const bool heap_regime = (long long)K * 64 <= (long long)N;  // torch.topk: partial_sort vs nth_element
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
         const int s = min(s0 + j, S - 1);
         cx[j] = ctr[3 * s], cy[j] = ctr[3 * s + 1], cz[j] = ctr[3 * s + 2];
-        thr[j] = r2, gd[j] = __builtin_inff(), gi[j] = 0x7fffffff, cnt[j] = 0;
+        caa[j] = (cx[j] * cx[j] + cy[j] * cy[j]) + cz[j] * cz[j];
+        thr[j] = r2, gd[j] = __builtin_inff(), gi[j] = 0x7fffffff, cnt[j] = 0, tie[j] = false;
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int base = 0; base < len; base += 64) {
@@ -89,10 +170,11 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
         const bool ok = i < len;
         float x = 0.f, y = 0.f, z = 0.f;
         if (ok) x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        const float bb = (x * x + y * y) + z * z;
 #pragma unroll
         for (int j = 0; j < CPW; ++j) {
-            const float dx = x - cx[j], dy = y - cy[j], dz = z - cz[j];
-            const float d = ok ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : __builtin_inff();
+            const float dot = fmaf(cz[j], z, fmaf(cy[j], y, cx[j] * x));
+            const float d = ok ? ((-2.f * dot) + caa[j]) + bb : __builtin_inff();
             if (d < gd[j]) gd[j] = d, gi[j] = i;
             const bool in = d <= thr[j];
             const unsigned long long m = __ballot(in);
@@ -106,7 +188,10 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
                 if (cnt[j] > CAP - 64) {  // compact: keep the K smallest, tighten the admission bound
                     wave_mem_sync();
                     const int k = min(K, cnt[j]);
-                    select_smallest(s_d[w][j], s_i[w][j], cnt[j], k, s_td[w], s_ti[w]);
+                    const int k1 = min(K + 1, cnt[j]);  // one extra: is there a tie across the K-th slot?
+                    select_smallest(s_d[w][j], s_i[w][j], cnt[j], k1, s_td[w], s_ti[w]);
+                    if (k1 > K && s_td[w][K] == s_td[w][K - 1]) tie[j] = true;
+                    wave_mem_sync();
                     if (lane < k) s_d[w][j][lane] = s_td[w][lane], s_i[w][j][lane] = s_ti[w][lane];
                     wave_mem_sync();
                     cnt[j] = k;
@@ -130,10 +215,38 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
         }
         if (ni == 0x7fffffff) ni = 0;  // empty frame
         const int k = min(K, cnt[j]);
-        select_smallest(s_d[w][j], s_i[w][j], cnt[j], k, s_td[w], s_ti[w]);
-        const int first = (k > 0) ? s_ti[w][0] : ni;
+        const int k1 = min(K + 1, cnt[j]);
+        select_smallest(s_d[w][j], s_i[w][j], cnt[j], k1, s_td[w], s_ti[w]);
+        if (k1 > K && s_td[w][K] == s_td[w][K - 1]) tie[j] = true;
         int32_t *out = idx_all + ((size_t)b * S + (s0 + j)) * K;
-        if (lane < K) out[lane] = (lane < k) ? s_ti[w][lane] : first;
+        if (tie[j] && heap_regime && len >= K) {
+            // boundary tie: reproduce the reference's choice exactly (rare, sequential)
+            wave_mem_sync();
+            volatile float *hv = s_d[w][j];
+            volatile int *hi = s_i[w][j];
+            heap_select_exact(pts, len, K, cx[j], cy[j], cz[j], caa[j], hv, hi, s_td[w]);
+            float mv = (lane < K) ? hv[lane] : __builtin_inff();
+            int mi = (lane < K) ? hi[lane] : 0x7fffffff;
+            const float myv = mv;
+            const int myi = mi;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(mv, off, 64);
+                const int oi = __shfl_xor(mi, off, 64);
+                if (ov < mv || (ov == mv && oi < mi)) mv = ov, mi = oi;
+            }
+            int outv = (myv > r2) ? mi : myi;  // radius mask -> nearest (utils.py:85-87)
+            // slot 0 must be the nearest point: swap it (in registers) with whoever holds it
+            const unsigned long long hm = __ballot(lane < K && myi == mi);
+            const int L = hm ? __builtin_ctzll(hm) : 0;
+            const int v0 = __shfl(outv, 0, 64);
+            if (lane == L) outv = v0;
+            if (lane == 0) outv = mi;
+            if (lane < K) out[lane] = outv;
+        } else {
+            const int first = (k > 0) ? s_ti[w][0] : ni;
+            if (lane < K) out[lane] = (lane < k) ? s_ti[w][lane] : first;
+        }
         wave_mem_sync();
     }
 }

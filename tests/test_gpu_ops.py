@@ -21,7 +21,7 @@ def _lengths(vals):
     return torch.tensor(vals, dtype=torch.int32, device=DEV)
 
 
-def knn_rows_ok(idx_gpu, points, centers, radius, tol=2e-6):
+def knn_rows_ok(idx_gpu, points, centers, radius, tol=4e-6):
     """Per row: same index set as the exact fp64 answer, except for members whose distance is
     within `tol` of the radius^2 cut or of the K-th distance (documented borderline margin)."""
     idx_gpu = np.asarray(idx_gpu)
@@ -98,12 +98,12 @@ def test_knn_vs_reference_fixtures(ops):
         pts, ctr, length = T(g[n + ".points"]), T(g[n + ".centers"]), int(g[n + ".length"])
         r, K = float(g[n + ".radius"]), g[n + ".idx"].shape[1]
         idx = ops.knn_hybrid(pts.unsqueeze(0).to(DEV), _lengths([length]), ctr.unsqueeze(0).to(DEV), K, r)[0].cpu().numpy()
+        # the kernel reproduces the reference's expanded-form arithmetic bit for bit, so the index
+        # SETS are the reference's (only exact distance ties at the K-th slot may pick differently)
         same = idx_rows_equal_as_sets(idx, g[n + ".idx"])
-        assert same.mean() > 0.995, (n, same.mean())
+        assert same.mean() >= 0.999, (n, same.mean())
         assert knn_rows_ok(idx, pts[:length].numpy(), ctr.numpy(), r) == 0, n
-        # slot 0 is the nearest point (the centre itself here: centres are a subset of points)
-        d0 = (pts[idx[:, 0]] - ctr).pow(2).sum(1)
-        assert float(d0.max()) == 0.0
+        assert (idx[:, 0] == g[n + ".idx"][:, 0]).mean() >= 0.999  # slot 0 = the reference's nearest
 
 
 def test_knn_dense_cluster_overflows_candidate_list(ops):
@@ -113,6 +113,25 @@ def test_knn_dense_cluster_overflows_candidate_list(ops):
     ctr = pts[:, :37].contiguous()
     idx = ops.knn_hybrid(pts.to(DEV), _lengths([4000]), ctr.to(DEV), 32, 0.2)[0].cpu().numpy()
     assert knn_rows_ok(idx, pts[0].numpy(), ctr[0].numpy(), 0.2) == 0
+
+
+def test_knn_boundary_ties_follow_reference_topk(ops):
+    # lattice points: many bit-equal distances straddle the K-th slot.  The reference's choice there is
+    # libstdc++ heap-select (torch.topk CPU, K*64 <= N); the kernel re-runs such rows through an exact
+    # emulation, so the index sets must be identical, not merely equivalent.
+    gen = torch.Generator().manual_seed(31)
+    for N, K, r in [(4096, 32, 0.3), (8192, 32, 0.25), (2048, 16, 0.4)]:
+        pts = (torch.randint(0, 24, (1, N, 3), generator=gen).float() / 24.0)
+        ctr = pts[:, torch.randperm(N, generator=gen)[:200]].contiguous()
+        pad = torch.zeros(1, N, dtype=torch.bool)
+        want, dk = O.hybrid_query(r, K, pts, ctr, pad, return_dist=True)
+        got = ops.knn_hybrid(pts.to(DEV), _lengths([N]), ctr.to(DEV), K, r)[0].cpu().numpy()
+        # make sure the case really contains boundary ties inside the radius
+        full = O.expanded_sqdist(ctr, pts)[0]
+        srt = torch.sort(full, dim=1)[0]
+        n_tie_rows = int(((srt[:, K - 1] == srt[:, K]) & (srt[:, K] <= r * r)).sum())
+        assert n_tie_rows > 20, n_tie_rows
+        assert idx_rows_equal_as_sets(got, want[0].numpy()).all(), (N, K)
 
 
 def test_knn_sparse_rows_pad_with_nearest(ops):
