@@ -8,12 +8,12 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdpm_hip.so")
 
-P, I, D = c_void_p, c_int, c_double
+P, I, D, LL = c_void_p, c_int, c_double, c_longlong
 
 # name -> (restype, argtypes); mirrors include/dpm_hip.h one to one (tests check the symbol list)
 SIGNATURES = {
@@ -29,6 +29,17 @@ SIGNATURES = {
     "dpm_linear": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
     "dpm_layernorm": (I, [P, I, P, P, P, P, P, I, I, I, I, P]),
     "dpm_three_interp_cat": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),
+    "dpm_posemb": (I, [P, I, P, I, I, I, P, P]),
+    "dpm_attention": (I, [P, I, LL, P, I, LL, P, I, LL, P, I, LL, I, I, I, I, I, P]),
+    "dpm_l2_normalize": (I, [P, I, I, P, P]),
+    "dpm_pairing_workspace_bytes": (c_size_t, [I, I]),
+    "dpm_dual_softmax_topk": (I, [P, I, I, D, I, P, P, P, P]),
+    "dpm_gather_pairs": (I, [P, P, P, I, I, I, P, P, P, P]),
+    "dpm_mean_rows": (I, [P, I, I, I, P, I, P]),
+    "dpm_kabsch_workspace_bytes": (c_size_t, [I]),
+    "dpm_corr_kabsch": (I, [P, P, I, P, I, P, P, P, I, D, I, D, P, P, P]),
+    "dpm_infomat_workspace_bytes": (c_size_t, [I, I]),
+    "dpm_information_matrix": (I, [P, I, P, I, P, D, P, P, P]),
 }
 
 

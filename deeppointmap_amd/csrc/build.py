@@ -19,6 +19,8 @@ SOURCES = {
     "fps.hip": [],
     "knn.hip": [],
     "encoder_ops.hip": [],
+    "decoder_ops.hip": [],
+    "infomat.hip": [],
 }
 
 

@@ -1,0 +1,649 @@
+// Decoder kernels: sine position embedding, multi-head attention core, L2 row normalisation,
+// dual-softmax pairing + top-k, pair gather, correspondence sets + iterative weighted Kabsch
+// (fp64 3x3 SVD on device), row mean.  fp32 like the reference unless stated.
+// Compiled with -ffp-contract=off: every fused multiply-add is an explicit fmaf().
+#include "dpm_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// a11 PositionEmbeddingCoordsSine (descriptor_attention.py:66-83).  dim_t (F floats) is the
+// reference's own table temperature**(2*(i//2)/F), computed once on the host with the same
+// torch expression, so p*pi/dim_t is bit-identical; channel axis*F+i = sin (even i) / cos (odd i).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void posemb_kernel(const float *__restrict__ xyz, int ld,
+                                                     const float *__restrict__ dim_t, int F, int E, int R,
+                                                     float scale, float *__restrict__ out) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)R * E) return;
+    const int r = (int)(e / E), c = (int)(e - (long long)r * E);
+    float v = 0.f;
+    if (c < 3 * F) {
+        const int a = c / F, i = c - a * F;
+        const float ang = (xyz[(size_t)r * ld + a] * scale) / dim_t[i];
+        v = (i & 1) ? cosf(ang) : sinf(ang);
+    }
+    out[e] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// a12 attention core: out[b,m,h*32:(h+1)*32] = softmax(q k^T / sqrt(32)) v, head dim 32.
+// One workgroup = 16 queries x 16 key-lanes of one (batch, head); every thread runs an
+// independent online softmax over its keys, merged across the 16 key-lanes at the end.
+// ------------------------------------------------------------------------------------------
+constexpr int HD = 32;
+__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
+                                                        const float *__restrict__ Kp, int ldk, long long sk,
+                                                        const float *__restrict__ V, int ldv, long long sv,
+                                                        float *__restrict__ O, int ldo, long long so, int M,
+                                                        int N, float scale) {
+    __shared__ float Ks[64][HD + 1];
+    __shared__ float Vs[64][HD + 1];
+    const int b = blockIdx.z, h = blockIdx.y, t = threadIdx.x;
+    const int qi = t >> 4, kl = t & 15;
+    const int m = blockIdx.x * 16 + qi;
+    const float *q = Q + (size_t)b * sq + (size_t)min(m, M - 1) * ldq + h * HD;
+    float qr[HD], acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) qr[d] = q[d] * scale, acc[d] = 0.f;
+    float mx = -__builtin_inff(), l = 0.f;
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        __syncthreads();
+        for (int e = t; e < 64 * HD; e += 256) {
+            const int kr = e >> 5, d = e & 31;
+            const bool ok = n0 + kr < N;
+            Ks[kr][d] = ok ? Kp[(size_t)b * sk + (size_t)(n0 + kr) * ldk + h * HD + d] : 0.f;
+            Vs[kr][d] = ok ? V[(size_t)b * sv + (size_t)(n0 + kr) * ldv + h * HD + d] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kr = kl + 16 * j;
+            if (n0 + kr >= N) continue;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) s = fmaf(qr[d], Ks[kr][d], s);
+            const float nm = fmaxf(mx, s);
+            const float corr = __expf(mx - nm), p = __expf(s - nm);
+            l = fmaf(l, corr, p);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(acc[d], corr, p * Vs[kr][d]);
+            mx = nm;
+        }
+    }
+    // merge the 16 key-lanes of this query (lanes qi*16 .. qi*16+15 are contiguous in the wave)
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        const float om = __shfl_xor(mx, off, 64), ol = __shfl_xor(l, off, 64);
+        const float nm = fmaxf(mx, om);
+        const float ca = (mx == -__builtin_inff()) ? 0.f : __expf(mx - nm);
+        const float cb = (om == -__builtin_inff()) ? 0.f : __expf(om - nm);
+        l = l * ca + ol * cb;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = acc[d] * ca + __shfl_xor(acc[d], off, 64) * cb;
+        mx = nm;
+    }
+    if (m < M) {
+        float *o = O + (size_t)b * so + (size_t)m * ldo + h * HD;
+        const float inv = 1.f / l;
+        // 16 lanes hold the same result: lane kl writes columns kl and kl+16 (static register indexing)
+#pragma unroll
+        for (int d = 0; d < HD; ++d)
+            if (d == kl || d == kl + 16) o[d] = acc[d] * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// F.normalize(x, p=2, dim=-1): x / max(||x||, 1e-12); one wave per row
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_kernel(const float *__restrict__ X, int R, int C,
+                                                     float *__restrict__ out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float *x = X + (size_t)r * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(x[c], x[c], s);
+    const float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    for (int c = lane; c < C; c += 64) out[(size_t)r * C + c] = x[c] / nrm;
+}
+
+// ------------------------------------------------------------------------------------------
+// a13 dual softmax (decoder.py:186-188): x = S * (1/tau); P = softmax_row(x) * softmax_col(x)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ S, int M, int N, float itau,
+                                                        float *__restrict__ rmax, float *__restrict__ rsum) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= M) return;
+    const float *s = S + (size_t)r * N;
+    float mx = -__builtin_inff();
+    for (int c = lane; c < N; c += 64) mx = fmaxf(mx, s[c] * itau);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < N; c += 64) sum += expf(s[c] * itau - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) rmax[r] = mx, rsum[r] = sum;
+}
+
+__global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict__ S, int M, int N, float itau,
+                                                        float *__restrict__ cmax, float *__restrict__ csum) {
+    // 64 columns per block, 4 row-groups; coalesced along columns
+    __shared__ float sm[4][64], ss[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float mx = -__builtin_inff(), sum = 0.f;
+    if (c < N) {
+        for (int r = g; r < M; r += 4) mx = fmaxf(mx, S[(size_t)r * N + c] * itau);
+    }
+    sm[g][threadIdx.x & 63] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sm[0][threadIdx.x & 63], sm[1][threadIdx.x & 63]),
+               fmaxf(sm[2][threadIdx.x & 63], sm[3][threadIdx.x & 63]));
+    if (c < N) {
+        for (int r = g; r < M; r += 4) sum += expf(S[(size_t)r * N + c] * itau - mx);
+    }
+    ss[g][threadIdx.x & 63] = sum;
+    __syncthreads();
+    if (g == 0 && c < N) {
+        cmax[c] = mx;
+        csum[c] = (ss[0][threadIdx.x] + ss[1][threadIdx.x]) + (ss[2][threadIdx.x] + ss[3][threadIdx.x]);
+    }
+}
+
+__global__ __launch_bounds__(256) void dual_softmax_kernel(float *__restrict__ S, int M, int N, float itau,
+                                                           const float *__restrict__ rmax,
+                                                           const float *__restrict__ rsum,
+                                                           const float *__restrict__ cmax,
+                                                           const float *__restrict__ csum) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)M * N) return;
+    const int r = (int)(e / N), c = (int)(e - (long long)r * N);
+    const float x = S[e] * itau;
+    S[e] = (expf(x - rmax[r]) / rsum[r]) * (expf(x - cmax[c]) / csum[c]);
+}
+
+// ------------------------------------------------------------------------------------------
+// top-k (largest) of n non-negative floats, sorted descending (ties: smaller index first).
+// v1: ONE workgroup: 4-pass MSB radix select for the k-th value, ordered compaction, bitonic sort.
+// ------------------------------------------------------------------------------------------
+constexpr int TK_THREADS = 1024;
+constexpr int TK_MAXK = 4096;
+
+__global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float *__restrict__ P, long long n, int k,
+                                                          float *__restrict__ out_v, int32_t *__restrict__ out_i) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_mask, s_krem;
+    __shared__ int s_wcnt[2][TK_THREADS / 64];
+    __shared__ int s_base[2];
+    __shared__ float sv[TK_MAXK];
+    __shared__ int si[TK_MAXK];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) s_prefix = 0u, s_mask = 0u, s_krem = (unsigned)k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (t < 256) hist[t] = 0u;
+        __syncthreads();
+        const unsigned prefix = s_prefix, mask = s_mask;
+        for (long long e = t; e < n; e += TK_THREADS) {
+            const unsigned u = __float_as_uint(P[e]);
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (t == 0) {
+            unsigned rem = s_krem, bsel = 0;
+            for (int bin = 255; bin >= 0; --bin) {
+                const unsigned c = hist[bin];
+                if (c >= rem) {
+                    bsel = (unsigned)bin;
+                    break;
+                }
+                rem -= c;
+            }
+            s_krem = rem;
+            s_prefix = prefix | (bsel << shift);
+            s_mask = mask | (255u << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned thr = s_prefix;  // bit pattern of the k-th largest value
+    const int take_eq = (int)s_krem;  // how many elements equal to it are taken (in index order)
+    if (t == 0) s_base[0] = 0, s_base[1] = 0;
+    __syncthreads();
+    for (long long e0 = 0; e0 < n; e0 += TK_THREADS) {
+        const long long e = e0 + t;
+        unsigned u = 0;
+        float v = 0.f;
+        if (e < n) v = P[e], u = __float_as_uint(v);
+        const bool gt = e < n && u > thr, eq = e < n && u == thr;
+        const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+        if (lane == 0) s_wcnt[0][w] = __popcll(mg), s_wcnt[1][w] = __popcll(me);
+        __syncthreads();
+        int bg = s_base[0], be = s_base[1], tg = 0, te = 0;
+        for (int x = 0; x < TK_THREADS / 64; ++x) {
+            if (x < w) bg += s_wcnt[0][x], be += s_wcnt[1][x];
+            tg += s_wcnt[0][x], te += s_wcnt[1][x];
+        }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        // elements > thr occupy [0, k - take_eq); equal ones fill [k - take_eq, k)
+        if (gt) {
+            const int p = bg + __popcll(mg & lt);
+            sv[p] = v, si[p] = (int)e;
+        }
+        if (eq) {
+            const int p = be + __popcll(me & lt);
+            if (p < take_eq) sv[k - take_eq + p] = v, si[k - take_eq + p] = (int)e;
+        }
+        __syncthreads();
+        if (t == 0) s_base[0] += tg, s_base[1] += te;
+        __syncthreads();
+    }
+    // bitonic sort, descending by value, ascending index on ties; pad to a power of two
+    int np2 = 1;
+    while (np2 < k) np2 <<= 1;
+    for (int e = k + t; e < np2; e += TK_THREADS) sv[e] = -1.f, si[e] = 0x7fffffff;
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int e = t; e < np2 / 2; e += TK_THREADS) {
+                const int lo = 2 * e - (e & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const float a = sv[lo], b2 = sv[hi];
+                const int ia = si[lo], ib = si[hi];
+                const bool a_first = a > b2 || (a == b2 && ia < ib);  // a ranks before b
+                if (a_first != desc) sv[lo] = b2, sv[hi] = a, si[lo] = ib, si[hi] = ia;
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = t; e < k; e += TK_THREADS) out_v[e] = sv[e], out_i[e] = si[e];
+}
+
+// ------------------------------------------------------------------------------------------
+// a14 gather: flat top-k index -> (src row, dst row); X[0:k] = [x[si] | y[di]], X[k:2k] = [y[di] | x[si]]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_pairs_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const int32_t *__restrict__ flat, int k, int N, int E,
+                                                           float *__restrict__ X, int32_t *__restrict__ si_out,
+                                                           int32_t *__restrict__ di_out) {
+    const int p = blockIdx.x, t = threadIdx.x;
+    const int f = flat[p];
+    const int si = f / N, di = f - si * N;
+    if (t == 0) si_out[p] = si, di_out[p] = di;
+    for (int c = t; c < E; c += 256) {
+        const float a = x[(size_t)si * E + c], b2 = y[(size_t)di * E + c];
+        X[(size_t)p * 2 * E + c] = a;
+        X[(size_t)p * 2 * E + E + c] = b2;
+        X[(size_t)(k + p) * 2 * E + c] = b2;
+        X[(size_t)(k + p) * 2 * E + E + c] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// mean over the rows of each batch element: (B,R,C) -> out (B, ldo) at column offset
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float *__restrict__ X, int R, int C,
+                                                        float *__restrict__ out, int ldo) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float *x = X + (size_t)b * R * C;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += x[(size_t)r * C + c];
+    out[(size_t)b * ldo + c] = s / (float)R;
+}
+
+// ------------------------------------------------------------------------------------------
+// a14 + a15: correspondence sets and the iterative weighted Kabsch (decoder.py:202-265)
+// ------------------------------------------------------------------------------------------
+constexpr int KB = 256;  // threads
+
+template <typename T>
+__device__ T block_sum(T v, T *scratch /* KB/64 entries */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    T r = scratch[0];
+    for (int i = 1; i < KB / 64; ++i) r += scratch[i];
+    return r;
+}
+
+// one-sided Jacobi SVD of a 3x3 (fp64): A = U diag(s) V^T; returns R = V U^T
+__device__ void rot_from_cov(const double A[9], double Rm[9]) {
+    double G[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; ++i) G[i] = A[i];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int i = 0; i < 3; ++i) {
+                    al += G[3 * i + p] * G[3 * i + p];
+                    be += G[3 * i + q] * G[3 * i + q];
+                    ga += G[3 * i + p] * G[3 * i + q];
+                }
+                if (al == 0.0 || be == 0.0) continue;
+                const double lim = 1e-15 * sqrt(al * be);
+                if (fabs(ga) <= lim) continue;
+                off += fabs(ga);
+                const double zeta = (be - al) / (2.0 * ga);
+                const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+                for (int i = 0; i < 3; ++i) {
+                    const double gp = G[3 * i + p], gq = G[3 * i + q];
+                    G[3 * i + p] = c * gp - s * gq;
+                    G[3 * i + q] = s * gp + c * gq;
+                    const double vp = V[3 * i + p], vq = V[3 * i + q];
+                    V[3 * i + p] = c * vp - s * vq;
+                    V[3 * i + q] = s * vp + c * vq;
+                }
+            }
+        if (off == 0.0) break;
+    }
+    // columns of G are s_j * u_j.  R = V U^T = sum_j v_j u_j^T
+    double U[9];
+    double sig[3];
+    for (int j = 0; j < 3; ++j) {
+        sig[j] = sqrt(G[j] * G[j] + G[3 + j] * G[3 + j] + G[6 + j] * G[6 + j]);
+    }
+    int jmin = 0;
+    for (int j = 1; j < 3; ++j)
+        if (sig[j] < sig[jmin]) jmin = j;
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) U[3 * i + j] = sig[j] > 0 ? G[3 * i + j] / sig[j] : 0.0;
+    if (!(sig[jmin] > 1e-300)) {  // rank deficient: complete U with the cross product of the other two
+        const int a = (jmin + 1) % 3, b2 = (jmin + 2) % 3;
+        U[0 + jmin] = U[3 + a] * U[6 + b2] - U[6 + a] * U[3 + b2];
+        U[3 + jmin] = U[6 + a] * U[0 + b2] - U[0 + a] * U[6 + b2];
+        U[6 + jmin] = U[0 + a] * U[3 + b2] - U[3 + a] * U[0 + b2];
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double r = 0;
+            for (int l = 0; l < 3; ++l) r += V[3 * i + l] * U[3 * j + l];
+            Rm[3 * i + j] = r;
+        }
+}
+
+// result layout (floats): [0:9] R row-major, [9:12] T, [12] rmse, [13] n_corr, [14] n_inlier, [15] iterations,
+// [16 : 16+n_inlier] confidences of the inliers (in correspondence order)
+__global__ __launch_bounds__(KB) void corr_kabsch_kernel(
+    const float *__restrict__ off /* (2k,3) */, const float *__restrict__ sxyz, int lds_,
+    const float *__restrict__ dxyz, int ldd, const int32_t *__restrict__ si, const int32_t *__restrict__ di,
+    const float *__restrict__ conf, int k, float eps2, int num_iter, float std_ratio,
+    float *__restrict__ ws /* 7*2k floats + 2*2k ints */, float *__restrict__ result) {
+    __shared__ int s_cnt[KB / 64];
+    __shared__ int s_run;
+    __shared__ float s_f[KB / 64];
+    __shared__ double s_R[9], s_T[3];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int n2 = 2 * k;
+    float *src = ws, *dst = ws + 3 * (size_t)n2, *wt = ws + 6 * (size_t)n2;
+    int *inl = (int *)(ws + 7 * (size_t)n2), *rank = inl + n2;
+
+    // ---- correspondence sets: [src+off_s2d ; src] <-> [dst ; dst+off_d2s], keep |off|^2 <= eps^2,
+    //      stable compaction (decoder.py:208-223)
+    const bool direct = (off == nullptr);  // test / generic mode: (conf, sxyz, dxyz) ARE the n = k correspondences
+    if (t == 0) s_run = direct ? k : 0;
+    __syncthreads();
+    if (direct) {
+        for (int p = t; p < k; p += KB) {
+            for (int a = 0; a < 3; ++a) src[3 * p + a] = sxyz[(size_t)p * lds_ + a], dst[3 * p + a] = dxyz[(size_t)p * ldd + a];
+            wt[p] = conf[p];
+        }
+    }
+    for (int e0 = 0; !direct && e0 < n2; e0 += KB) {
+        const int e = e0 + t;
+        bool keep = false;
+        float a[3] = {0, 0, 0}, b2[3] = {0, 0, 0}, wv = 0.f;
+        int orig = 0;
+        if (e < n2) {
+            const int p = e < k ? e : e - k;
+            const float ox = off[3 * (size_t)e], oy = off[3 * (size_t)e + 1], oz = off[3 * (size_t)e + 2];
+            keep = ((ox * ox + oy * oy) + oz * oz) <= eps2;
+            const float *sp = sxyz + (size_t)si[p] * lds_, *dp = dxyz + (size_t)di[p] * ldd;
+            if (e < k) {
+                a[0] = sp[0] + ox, a[1] = sp[1] + oy, a[2] = sp[2] + oz;
+                b2[0] = dp[0], b2[1] = dp[1], b2[2] = dp[2];
+            } else {
+                a[0] = sp[0], a[1] = sp[1], a[2] = sp[2];
+                b2[0] = dp[0] + ox, b2[1] = dp[1] + oy, b2[2] = dp[2] + oz;
+            }
+            wv = conf[p];
+            orig = e;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_cnt[w] = __popcll(m);
+        __syncthreads();
+        int base = s_run, tot = 0;
+        for (int x = 0; x < KB / 64; ++x) {
+            if (x < w) base += s_cnt[x];
+            tot += s_cnt[x];
+        }
+        if (keep) {
+            const int p = base + __popcll(m & ((1ull << lane) - 1ull));
+            src[3 * p] = a[0], src[3 * p + 1] = a[1], src[3 * p + 2] = a[2];
+            dst[3 * p] = b2[0], dst[3 * p + 1] = b2[1], dst[3 * p + 2] = b2[2];
+            wt[p] = wv;
+            rank[p] = orig;
+        }
+        __syncthreads();
+        if (t == 0) s_run += tot;
+        __syncthreads();
+    }
+    const int n = s_run;
+    // ---- initial inliers: w > 0.5, plus the 64 largest weights (decoder.py:233-235).  The weights are
+    //      two copies of the descending top-k confidences, so "rank among the kept ones" is a merge:
+    //      an entry is in the top 64 iff fewer than 64 kept entries precede it in (conf desc, copy) order.
+    __syncthreads();
+    if (direct) {
+        // generic top-64: rank by (weight desc, index asc), O(n^2 / threads)
+        for (int p = t; p < n; p += KB) {
+            const float wp = wt[p];
+            int before = 0;
+            for (int q = 0; q < n; ++q) before += (wt[q] > wp) || (wt[q] == wp && q < p);
+            inl[p] = (wp > 0.5f) || (before < min(64, n));
+        }
+    } else {
+        auto lower = [&](int lo, int hi, int key) {  // first q in [lo,hi) with rank[q] >= key (rank is ascending)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (rank[mid] < key) lo = mid + 1;
+                else hi = mid;
+            }
+            return lo;
+        };
+        const int nA = lower(0, n, k);  // kept entries of the first copy
+        for (int p = t; p < n; p += KB) {
+            const int e = rank[p];
+            const bool isB = e >= k;
+            const int j = isB ? e - k : e;
+            const int a_lt = lower(0, nA, j), a_le = lower(0, nA, j + 1);
+            const int b_lt = lower(nA, n, k + j) - nA;
+            const int before = a_lt + b_lt + (isB ? (a_le - a_lt) : 0);
+            inl[p] = (wt[p] > 0.5f) || (before < min(64, n));
+        }
+    }
+    __syncthreads();
+    int iter = 0;
+    float rmse = 0.f;
+    int n_in = 0;
+    while (true) {
+        // weighted centroids (fp32, like the reference), covariance (fp32), SVD (fp64)
+        float sw = 0, cs[3] = {0, 0, 0}, cd[3] = {0, 0, 0};
+        for (int p = t; p < n; p += KB)
+            if (inl[p]) {
+                const float wv = wt[p];
+                sw += wv;
+                for (int a = 0; a < 3; ++a) cs[a] = fmaf(src[3 * p + a], wv, cs[a]), cd[a] = fmaf(dst[3 * p + a], wv, cd[a]);
+            }
+        sw = block_sum(sw, s_f);
+        for (int a = 0; a < 3; ++a) cs[a] = block_sum(cs[a], s_f) / sw, cd[a] = block_sum(cd[a], s_f) / sw;
+        float cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int p = t; p < n; p += KB)
+            if (inl[p]) {
+                const float wv = wt[p];
+                for (int a = 0; a < 3; ++a) {
+                    const float sa = (src[3 * p + a] - cs[a]) * wv;
+                    for (int c = 0; c < 3; ++c) cov[3 * a + c] = fmaf(sa, dst[3 * p + c] - cd[c], cov[3 * a + c]);
+                }
+            }
+        for (int i = 0; i < 9; ++i) cov[i] = block_sum(cov[i], s_f);
+        if (t == 0) {
+            double A[9], Rm[9];
+            for (int i = 0; i < 9; ++i) A[i] = (double)cov[i];
+            rot_from_cov(A, Rm);
+            for (int i = 0; i < 9; ++i) s_R[i] = Rm[i];
+            for (int a = 0; a < 3; ++a)
+                s_T[a] = (double)cd[a] - (Rm[3 * a] * (double)cs[0] + Rm[3 * a + 1] * (double)cs[1] + Rm[3 * a + 2] * (double)cs[2]);
+        }
+        __syncthreads();
+        float Rf[9], Tf[3];
+        for (int i = 0; i < 9; ++i) Rf[i] = (float)s_R[i];
+        for (int a = 0; a < 3; ++a) Tf[a] = (float)s_T[a];
+        // residuals for every correspondence; mean / unbiased std over the current inliers
+        float es = 0.f;
+        int cnt = 0;
+        for (int p = t; p < n; p += KB) {
+            float e2 = 0.f;
+            for (int a = 0; a < 3; ++a) {
+                const float r = fmaf(Rf[3 * a + 2], src[3 * p + 2], fmaf(Rf[3 * a + 1], src[3 * p + 1], Rf[3 * a] * src[3 * p])) + Tf[a] - dst[3 * p + a];
+                e2 = fmaf(r, r, e2);
+            }
+            const float er = sqrtf(e2);
+            rank[p] = __float_as_int(er);  // rank[] is free now: reuse as the residual buffer
+            if (inl[p]) es += er, ++cnt;
+        }
+        const float tot_e = block_sum(es, s_f);
+        const int tot_c = block_sum(cnt, s_cnt);
+        const float mean = tot_e / (float)tot_c;
+        float vs = 0.f;
+        for (int p = t; p < n; p += KB)
+            if (inl[p]) {
+                const float d = __int_as_float(rank[p]) - mean;
+                vs = fmaf(d, d, vs);
+            }
+        const float sd = sqrtf(block_sum(vs, s_f) / (float)(tot_c - 1));
+        const float lim = mean + std_ratio * sd;
+        int same = 1, newc = 0;
+        for (int p = t; p < n; p += KB) {
+            const int nw = __int_as_float(rank[p]) <= lim ? 1 : 0;
+            same &= (nw == inl[p]);
+            newc += nw;
+            inl[p] = nw;  // the new mask is adopted in every exit case (decoder.py:252-256)
+        }
+        const int diff = block_sum(1 - same, s_cnt);
+        n_in = block_sum(newc, s_cnt);
+        ++iter;
+        if (iter >= num_iter || diff == 0 || n_in < 30) break;
+    }
+    // rmse over the final inliers with the last R, T; inlier confidences in order
+    {
+        float Rf[9], Tf[3];
+        for (int i = 0; i < 9; ++i) Rf[i] = (float)s_R[i];
+        for (int a = 0; a < 3; ++a) Tf[a] = (float)s_T[a];
+        float e2s = 0.f;
+        for (int p = t; p < n; p += KB)
+            if (inl[p]) {
+                for (int a = 0; a < 3; ++a) {
+                    const float r = fmaf(Rf[3 * a + 2], src[3 * p + 2], fmaf(Rf[3 * a + 1], src[3 * p + 1], Rf[3 * a] * src[3 * p])) + Tf[a] - dst[3 * p + a];
+                    e2s = fmaf(r, r, e2s);
+                }
+            }
+        rmse = sqrtf(block_sum(e2s, s_f) / (float)n_in);
+        if (t == 0) {
+            for (int i = 0; i < 9; ++i) result[i] = Rf[i];
+            for (int a = 0; a < 3; ++a) result[9 + a] = Tf[a];
+            result[12] = rmse, result[13] = (float)n, result[14] = (float)n_in, result[15] = (float)iter;
+            s_run = 0;
+        }
+        __syncthreads();
+        for (int e0 = 0; e0 < n; e0 += KB) {
+            const int p = e0 + t;
+            const bool keep = p < n && inl[p];
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) s_cnt[w] = __popcll(m);
+            __syncthreads();
+            int base = s_run, tot = 0;
+            for (int x = 0; x < KB / 64; ++x) {
+                if (x < w) base += s_cnt[x];
+                tot += s_cnt[x];
+            }
+            if (keep) result[16 + base + __popcll(m & ((1ull << lane) - 1ull))] = wt[p];
+            __syncthreads();
+            if (t == 0) s_run += tot;
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dpm_posemb(const float *xyz, int ld, const float *dim_t, int F, int E, int R, float *out,
+                          dpm_stream_t stream) {
+    DPM_CHECK_ARG(xyz && dim_t && out && ld >= 3 && F >= 1 && E >= 3 * F && R >= 1);
+    hipLaunchKernelGGL(posemb_kernel, dim3(dpm_cdiv((long long)R * E, 256)), dim3(256), 0, (hipStream_t)stream, xyz, ld,
+                       dim_t, F, E, R, 3.14159265358979323846f, out);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_attention(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                             const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
+                             int N, int heads, int head_dim, dpm_stream_t stream) {
+    DPM_CHECK_ARG(Q && K && V && out && B >= 1 && M >= 1 && N >= 1 && heads >= 1);
+    if (head_dim != HD) return DPM_EUNSUPPORTED;
+    hipLaunchKernelGGL(attention_kernel, dim3(dpm_cdiv(M, 16), heads, B), dim3(256), 0, (hipStream_t)stream, Q, ldq, sq,
+                       K, ldk, sk, V, ldv, sv, out, ldo, so, M, N, (float)(1.0 / sqrt((double)head_dim)));
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && out && R >= 1 && C >= 1);
+    hipLaunchKernelGGL(l2norm_kernel, dim3(dpm_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, R, C, out);
+    return dpm_launch_status();
+}
+
+extern "C" size_t dpm_pairing_workspace_bytes(int M, int N) { return sizeof(float) * 2 * ((size_t)M + (size_t)N) + 256; }
+
+extern "C" int dpm_dual_softmax_topk(float *S, int M, int N, double tau, int k, float *out_val, int32_t *out_idx,
+                                     void *workspace, dpm_stream_t stream) {
+    DPM_CHECK_ARG(S && out_val && out_idx && workspace && M >= 1 && N >= 1 && tau > 0.0);
+    DPM_CHECK_ARG(k >= 1 && (long long)k <= (long long)M * N);
+    if (k > TK_MAXK || (long long)M * N > 0x7fffffffLL) return DPM_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    float *rmax = (float *)workspace, *rsum = rmax + M, *cmax = rsum + M, *csum = cmax + N;
+    const float itau = 1.0f / (float)tau;  // torch divides by the scalar as a multiplication by 1/tau
+    hipLaunchKernelGGL(row_stats_kernel, dim3(dpm_cdiv(M, 4)), dim3(256), 0, st, S, M, N, itau, rmax, rsum);
+    hipLaunchKernelGGL(col_stats_kernel, dim3(dpm_cdiv(N, 64)), dim3(256), 0, st, S, M, N, itau, cmax, csum);
+    hipLaunchKernelGGL(dual_softmax_kernel, dim3(dpm_cdiv((long long)M * N, 256)), dim3(256), 0, st, S, M, N, itau, rmax,
+                       rsum, cmax, csum);
+    hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(TK_THREADS), 0, st, S, (long long)M * N, k, out_val, out_idx);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_gather_pairs(const float *x, const float *y, const int32_t *flat_idx, int k, int N, int E,
+                                float *X, int32_t *src_idx, int32_t *dst_idx, dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && y && flat_idx && X && src_idx && dst_idx && k >= 1 && N >= 1 && E >= 1);
+    hipLaunchKernelGGL(gather_pairs_kernel, dim3(k), dim3(256), 0, (hipStream_t)stream, x, y, flat_idx, k, N, E, X,
+                       src_idx, dst_idx);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_mean_rows(const float *x, int B, int R, int C, float *out, int ldo, dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && out && B >= 1 && R >= 1 && C >= 1 && ldo >= C);
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(dpm_cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, x, R, C, out, ldo);
+    return dpm_launch_status();
+}
+
+extern "C" size_t dpm_kabsch_workspace_bytes(int k) { return (size_t)(2 * k) * (7 * sizeof(float) + 2 * sizeof(int32_t)) + 256; }
+
+extern "C" int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, const float *dst_xyz, int ld_dst,
+                               const int32_t *src_idx, const int32_t *dst_idx, const float *conf, int k, double eps_offset,
+                               int num_iter, double std_ratio, void *workspace, float *result, dpm_stream_t stream) {
+    DPM_CHECK_ARG(src_xyz && dst_xyz && conf && workspace && result);
+    DPM_CHECK_ARG(!offsets || (src_idx && dst_idx));
+    DPM_CHECK_ARG(k >= 1 && ld_src >= 3 && ld_dst >= 3 && num_iter >= 1);
+    hipLaunchKernelGGL(corr_kabsch_kernel, dim3(1), dim3(KB), 0, (hipStream_t)stream, offsets, src_xyz, ld_src, dst_xyz,
+                       ld_dst, src_idx, dst_idx, conf, k, (float)(eps_offset * eps_offset), num_iter, (float)std_ratio,
+                       (float *)workspace, result);
+    return dpm_launch_status();
+}

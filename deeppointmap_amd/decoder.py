@@ -1,0 +1,187 @@
+"""`Decoder` -- drop-in for the reference's network/decoder/decoder.py::Decoder (inference calls).
+
+Same constructor (`Decoder(args)`), state-dict keys/shapes (params.decoder_shapes) and call
+contracts:
+  * `registration_forward(src_desc (131,M), dst_desc (131,N), src_padding_mask=None,
+     dst_padding_mask=None, num_sample=0.5) -> (R (3,3), T (3,1), conf (K,), rmse: float)`
+     (decoder.py:91-127); 3-D inputs give the batched return shapes of the reference.
+  * `loop_detection_forward(src (C,131,M), dst (C,131,N)) -> (C,)` (decoder.py:129-143).
+  * `forward` is training-only in the reference (decoder.py:34-38) and raises here as it does there.
+Every inference call site of the reference passes no padding masks (odometry.py:108-110,
+mapping.py:153-155, loop_closure.py:170-174,239-242); masks are therefore rejected explicitly.
+
+All arithmetic runs in libdpm_hip.so; the module is re-entrant (no per-call state on self), so
+the three SLAM threads of the reference can share one instance (system/core.py:55-57).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple, Union
+
+import torch
+
+from . import ops
+from .params import ParamTree, decoder_shapes
+
+HEADS = 8
+
+
+class Decoder(ParamTree):
+    def __init__(self, args):
+        super().__init__(decoder_shapes(args))
+        self.args = args
+        self.decoder_cfg = args.decoder
+        self.in_channel = self.decoder_cfg.in_channel
+        self.model_channel = self.decoder_cfg.model_channel
+        self.attention_layers = self.decoder_cfg.attention_layers
+        self.tau = args.loss.tau
+        self._dim_t: Dict[str, torch.Tensor] = {}
+        self.eval()
+
+    # -- helpers -------------------------------------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self.p("projection.weight").device
+
+    def _dimt(self, dev: torch.device) -> torch.Tensor:
+        """temperature ** (2*(i//2)/F), evaluated with the reference's own torch expression
+        (descriptor_attention.py:71-72) on the host, once per device."""
+        key = str(dev)
+        if key not in self._dim_t:
+            F = self.model_channel // 3 // 2 * 2
+            i = torch.arange(F, dtype=torch.float32)
+            self._dim_t[key] = (10000 ** (2 * torch.div(i, 2, rounding_mode="trunc") / F)).to(dev)
+        return self._dim_t[key]
+
+    def _lin(self, key: str, x, act=ops.ACT_NONE, residual=None):
+        return ops.linear(x, self.p(key + ".weight"), self.p(key + ".bias"), act=act, residual=residual)
+
+    def _ln(self, key: str, x, post=None):
+        return ops.layernorm(x, self.p(key + ".weight"), self.p(key + ".bias"), post=post)
+
+    def _stage(self, desc: torch.Tensor, dev) -> Tuple[torch.Tensor, torch.Tensor, int, int]:
+        """(B,131,M) any device -> token-major rows (B*M,131) on the GPU."""
+        d = desc.to(device=dev, dtype=torch.float32).contiguous()
+        B, C, M = d.shape
+        if C != self.in_channel + 3:
+            raise ValueError(f"descriptor must have {self.in_channel + 3} rows, got {C}")
+        return ops.to_channel_first(d).view(B * M, C), B, M
+
+    def _self_attn(self, pre: str, xp, B, M):
+        E = self.model_channel
+        qkv = ops.linear(xp, self.p(pre + ".in_proj_weight"), self.p(pre + ".in_proj_bias"))
+        a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, M, M, HEADS)
+        return ops.linear(a, self.p(pre + ".out_proj.weight"), self.p(pre + ".out_proj.bias"), residual=xp)
+
+    def _cross_attn(self, pre: str, xq, xkv, B, M, N):
+        E = self.model_channel
+        w, b = self.p(pre + ".in_proj_weight"), self.p(pre + ".in_proj_bias")
+        q = ops.linear(xq, w[:E], b[:E])
+        kv = ops.linear(xkv, w[E:], b[E:])
+        a = ops.attention(q, kv[:, :E], kv[:, E:], B, M, N, HEADS)
+        return ops.linear(a, self.p(pre + ".out_proj.weight"), self.p(pre + ".out_proj.bias"), residual=xq)
+
+    def _descriptor_attention_forward(self, src_descriptor, dst_descriptor, src_padding_mask=None,
+                                      dst_padding_mask=None):
+        """-> (x (B*M,256), xyz_s (B*M,3) view, y (B*N,256), xyz_d view, B, M, N)   decoder.py:145-162."""
+        if src_padding_mask is not None or dst_padding_mask is not None:
+            raise NotImplementedError("padding masks are not used by any inference call site of the reference "
+                                      "and are not implemented")
+        dev = self.device
+        ts, B, M = self._stage(src_descriptor, dev)
+        td, B2, N = self._stage(dst_descriptor, dev)
+        if B != B2:
+            raise ValueError("src and dst batch sizes differ")
+        C, E = self.in_channel, self.model_channel
+        xyz_s, xyz_d = ts[:, C:C + 3], td[:, C:C + 3]
+        ps, pd = ops.posemb(xyz_s, self._dimt(dev), E), ops.posemb(xyz_d, self._dimt(dev), E)
+        # x + pos enters every layer: fold the addition into the producing kernel's epilogue
+        xp = ops.linear(ts[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=ps)
+        yp = ops.linear(td[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=pd)
+        for l in range(self.attention_layers):
+            pre = f"descriptor_attention.{l}"
+            last = l == self.attention_layers - 1
+            # self attention: LN1(x + attn(x)), then + pos for the cross block   (descriptor_attention.py:31-40)
+            x1 = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", xp, B, M), post=ps)
+            y1 = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", yp, B, N), post=pd)
+            # cross attention, both directions read the pre-update tensors      (descriptor_attention.py:41-44)
+            x2 = self._ln(pre + ".norm2", self._cross_attn(pre + ".cross_attn", x1, y1, B, M, N))
+            y2 = self._ln(pre + ".norm2", self._cross_attn(pre + ".cross_attn", y1, x1, B, N, M))
+            # MLP: LN3(mlp(x) + x); the next layer starts with + pos            (descriptor_attention.py:47-48)
+            xp = self._ln(pre + ".norm3", self._lin(pre + ".mlp.2", self._lin(pre + ".mlp.0", x2, ops.ACT_RELU),
+                                                    residual=x2), post=None if last else ps)
+            yp = self._ln(pre + ".norm3", self._lin(pre + ".mlp.2", self._lin(pre + ".mlp.0", y2, ops.ACT_RELU),
+                                                    residual=y2), post=None if last else pd)
+        return xp, xyz_s, yp, xyz_d, B, M, N
+
+    # -- public API ----------------------------------------------------------------------------
+    def forward(self, *a, **k):
+        assert self.training, "forward is not available during inference!"
+        raise NotImplementedError("the training forward (decoder.py:40-89) is outside the inference hot path")
+
+    @staticmethod
+    def _num_pairs(num_sample, M: int, N: int) -> int:
+        if isinstance(num_sample, int):
+            k = num_sample
+        elif isinstance(num_sample, float) and num_sample > 1:
+            k = int(num_sample)
+        elif isinstance(num_sample, float) and 0 < num_sample <= 1:
+            k = int(num_sample * (M + N))
+        else:
+            raise ValueError(f"Argument `num_sample` with value {num_sample} is not supported")
+        return k // 2
+
+    @torch.no_grad()
+    def registration_forward(self, src_descriptor: torch.Tensor, dst_descriptor: torch.Tensor,
+                             src_padding_mask=None, dst_padding_mask=None,
+                             num_sample: Union[int, float] = 0.5, trace: dict = None):
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("deeppointmap_amd.Decoder runs on the GPU only (there is no CPU fallback)")
+        batch = not (src_descriptor.ndim == 2 and dst_descriptor.ndim == 2)
+        if not batch:
+            src_descriptor, dst_descriptor = src_descriptor.unsqueeze(0), dst_descriptor.unsqueeze(0)
+        with torch.cuda.device(dev):
+            x, xyz_s, y, xyz_d, B, M, N = self._descriptor_attention_forward(src_descriptor, dst_descriptor,
+                                                                             src_padding_mask, dst_padding_mask)
+            assert B == 1, "batch size in inference must be 1"
+            k = self._num_pairs(num_sample, M, N)
+            # similarity head -> L2 normalise -> M x N similarity -> dual softmax -> top-k   (decoder.py:181-191)
+            a = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", x, ops.ACT_RELU)))
+            b = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", y, ops.ACT_RELU)))
+            S = ops.linear(a, b)
+            conf, flat = ops.dual_softmax_topk(S, self.tau, k)
+            # offset head on both pair directions                                           (decoder.py:204-207)
+            X, si, di = ops.gather_pairs(x, y, flat)
+            h = self._lin("offset_head.mlp.2", self._lin("offset_head.mlp.0", X, ops.ACT_RELU), ops.ACT_RELU)
+            h = self._lin("offset_head.mlp.4", h, ops.ACT_RELU, residual=self._lin("offset_head.downsample", X))
+            off = self._lin("offset_head.head", h)
+            res = ops.corr_kabsch(off, xyz_s, xyz_d, si, di, conf, self.args.loss.eps_offset)
+            head = res[:16].cpu()  # the one host sync of the call: rmse is a python float in the contract
+        n_in, rmse = int(head[14]), float(head[12])
+        R, T, cf = res[0:9].view(3, 3), res[9:12].view(3, 1), res[16:16 + n_in]
+        if trace is not None:
+            trace.update(x=x, y=y, conf=conf, flat=flat, src_index=si, dst_index=di, offsets=off,
+                         n_corr=int(head[13]), iterations=int(head[15]))
+        if not batch:
+            return R, T, cf, rmse
+        return R.unsqueeze(0), T.unsqueeze(0), cf.unsqueeze(0), [rmse]
+
+    @torch.no_grad()
+    def loop_detection_forward(self, src_descriptor: torch.Tensor, dst_descriptor: torch.Tensor,
+                               src_padding_mask=None, dst_padding_mask=None) -> torch.Tensor:
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("deeppointmap_amd.Decoder runs on the GPU only (there is no CPU fallback)")
+        if src_descriptor.ndim == 2 and dst_descriptor.ndim == 2:
+            src_descriptor, dst_descriptor = src_descriptor.unsqueeze(0), dst_descriptor.unsqueeze(0)
+        E = self.model_channel
+        with torch.cuda.device(dev):
+            x, _, y, _, B, M, N = self._descriptor_attention_forward(src_descriptor, dst_descriptor,
+                                                                     src_padding_mask, dst_padding_mask)
+            fx = self._lin("loop_head.mlp.2", self._lin("loop_head.mlp.0", x, ops.ACT_RELU))
+            fy = self._lin("loop_head.mlp.2", self._lin("loop_head.mlp.0", y, ops.ACT_RELU))
+            cat = torch.empty(B, 2 * E, device=dev, dtype=torch.float32)
+            ops.mean_rows(fx.view(B, M, E), cat[:, :E])
+            ops.mean_rows(fy.view(B, N, E), cat[:, E:])
+            h = self._lin("loop_head.projection.0", cat, ops.ACT_RELU)
+            return self._lin("loop_head.projection.2", h, ops.ACT_SIGMOID).flatten()

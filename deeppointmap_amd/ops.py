@@ -157,3 +157,105 @@ def three_interp_cat(xyz1, xyz2, lengths2, fea1, fea2) -> torch.Tensor:
     _lib.check(_lib.load().dpm_three_interp_cat(_ptr(xyz1), _ptr(xyz2), _ptr(lengths2), _ptr(fea1), _ptr(fea2),
                                                 B, N, S, D1, D2, _ptr(out), _stream(fea1)), "dpm_three_interp_cat")
     return out
+
+
+# ---------------------------------------------------------------------------------------- decoder
+def _rows2d(t: torch.Tensor, name: str) -> torch.Tensor:
+    """2-D fp32 GPU view with unit column stride (row stride free)."""
+    if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D fp32 GPU tensor with unit column stride")
+    return t
+
+
+def posemb(xyz_rows: torch.Tensor, dim_t: torch.Tensor, emb_dim: int) -> torch.Tensor:
+    """xyz_rows (R,3) view (row stride free) -> (R, emb_dim)."""
+    _rows2d(xyz_rows, "xyz")
+    _chk(dim_t, torch.float32, "dim_t")
+    R = xyz_rows.shape[0]
+    out = torch.empty(R, emb_dim, device=xyz_rows.device, dtype=torch.float32)
+    _lib.check(_lib.load().dpm_posemb(_ptr(xyz_rows), xyz_rows.stride(0), _ptr(dim_t), dim_t.numel(), emb_dim, R,
+                                      _ptr(out), _stream(out)), "dpm_posemb")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, M: int, N: int, heads: int = 8):
+    """q (B*M,E) / k,v (B*N,E) row views (column slices of wider buffers allowed) -> (B*M,E)."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _rows2d(t, n)
+    E = q.shape[1]
+    out = torch.empty(B * M, E, device=q.device, dtype=torch.float32)
+    _lib.check(_lib.load().dpm_attention(_ptr(q), q.stride(0), M * q.stride(0), _ptr(k), k.stride(0), N * k.stride(0),
+                                         _ptr(v), v.stride(0), N * v.stride(0), _ptr(out), E, M * E, B, M, N, heads,
+                                         E // heads, _stream(q)), "dpm_attention")
+    return out
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().dpm_l2_normalize(_ptr(x), x.numel() // x.shape[-1], x.shape[-1], _ptr(out), _stream(x)),
+               "dpm_l2_normalize")
+    return out
+
+
+def dual_softmax_topk(S: torch.Tensor, tau: float, k: int):
+    """S (M,N) similarity (overwritten with the dual-softmax matrix) -> (values (k,), flat idx (k,) int32)."""
+    _chk(S, torch.float32, "S")
+    M, N = S.shape
+    lib = _lib.load()
+    val = torch.empty(k, device=S.device, dtype=torch.float32)
+    idx = torch.empty(k, device=S.device, dtype=torch.int32)
+    ws = torch.empty(lib.dpm_pairing_workspace_bytes(M, N), device=S.device, dtype=torch.uint8)
+    _lib.check(lib.dpm_dual_softmax_topk(_ptr(S), M, N, float(tau), k, _ptr(val), _ptr(idx), _ptr(ws), _stream(S)),
+               "dpm_dual_softmax_topk")
+    return val, idx
+
+
+def gather_pairs(x: torch.Tensor, y: torch.Tensor, flat: torch.Tensor):
+    """x (M,E), y (N,E), flat (k,) -> X (2k,2E), src_idx (k,), dst_idx (k,)."""
+    _chk(x, torch.float32, "x"), _chk(y, torch.float32, "y"), _chk(flat, torch.int32, "flat")
+    k, E, N = flat.numel(), x.shape[1], y.shape[0]
+    X = torch.empty(2 * k, 2 * E, device=x.device, dtype=torch.float32)
+    si = torch.empty(k, device=x.device, dtype=torch.int32)
+    di = torch.empty(k, device=x.device, dtype=torch.int32)
+    _lib.check(_lib.load().dpm_gather_pairs(_ptr(x), _ptr(y), _ptr(flat), k, N, E, _ptr(X), _ptr(si), _ptr(di),
+                                            _stream(x)), "dpm_gather_pairs")
+    return X, si, di
+
+
+def mean_rows(x: torch.Tensor, out: torch.Tensor) -> None:
+    """x (B,R,C) -> out (B,C) view (row stride free)."""
+    _chk(x, torch.float32, "x")
+    _rows2d(out, "out")
+    B, R, C = x.shape
+    _lib.check(_lib.load().dpm_mean_rows(_ptr(x), B, R, C, _ptr(out), out.stride(0), _stream(x)), "dpm_mean_rows")
+
+
+def corr_kabsch(offsets, src_xyz, dst_xyz, src_idx, dst_idx, conf, eps_offset: float, num_iter: int = 3,
+                std_ratio: float = 3.0) -> torch.Tensor:
+    """-> result (16 + 2k,) fp32: R(9) T(3) rmse n_corr n_inlier iters, then inlier confidences."""
+    _chk(conf, torch.float32, "conf")
+    _rows2d(src_xyz, "src_xyz"), _rows2d(dst_xyz, "dst_xyz")
+    if offsets is not None:  # None: (conf, src_xyz, dst_xyz) are ready-made correspondences
+        _chk(offsets, torch.float32, "offsets")
+        _chk(src_idx, torch.int32, "src_idx"), _chk(dst_idx, torch.int32, "dst_idx")
+    k = conf.numel()
+    lib = _lib.load()
+    ws = torch.empty(lib.dpm_kabsch_workspace_bytes(k), device=conf.device, dtype=torch.uint8)
+    result = torch.zeros(16 + 2 * k, device=conf.device, dtype=torch.float32)
+    _lib.check(lib.dpm_corr_kabsch(_ptr(offsets), _ptr(src_xyz), src_xyz.stride(0), _ptr(dst_xyz), dst_xyz.stride(0),
+                                   _ptr(src_idx), _ptr(dst_idx), _ptr(conf), k, float(eps_offset), num_iter,
+                                   float(std_ratio), _ptr(ws), _ptr(result), _stream(conf)), "dpm_corr_kabsch")
+    return result
+
+
+def information_matrix(pcd1: torch.Tensor, pcd2: torch.Tensor, Rt: torch.Tensor, radius: float = 1.0) -> torch.Tensor:
+    """pcd1 (3,N1), pcd2 (3,N2) metres on the GPU, Rt (12,) [R row-major, T] -> (6,6) fp32 on the GPU."""
+    _chk(pcd1, torch.float32, "pcd1"), _chk(pcd2, torch.float32, "pcd2"), _chk(Rt, torch.float32, "Rt")
+    N1, N2 = pcd1.shape[1], pcd2.shape[1]
+    lib = _lib.load()
+    ws = torch.empty(lib.dpm_infomat_workspace_bytes(N1, N2), device=pcd1.device, dtype=torch.uint8)
+    out = torch.empty(6, 6, device=pcd1.device, dtype=torch.float32)
+    _lib.check(lib.dpm_information_matrix(_ptr(pcd1), N1, _ptr(pcd2), N2, _ptr(Rt), float(radius), _ptr(out),
+                                          _ptr(ws), _stream(pcd1)), "dpm_information_matrix")
+    return out

@@ -100,6 +100,64 @@ int dpm_three_interp_cat(const float *xyz1, const float *xyz2, const int32_t *le
                          const float *fea1, const float *fea2, int B, int N, int S, int D1, int D2,
                          float *out, dpm_stream_t stream);
 
+/* ---------------------------------------------------------------- decoder -------------- */
+
+/* PositionEmbeddingCoordsSine.forward (network/decoder/descriptor_attention.py:66-83):
+ * xyz rows (R, leading dim ld, metres) -> out (R,E); dim_t (F) is the reference's table
+ * temperature**(2*(i//2)/F); channels >= 3F are zero. */
+int dpm_posemb(const float *xyz, int ld, const float *dim_t, int F, int E, int R, float *out,
+               dpm_stream_t stream);
+
+/* Scaled-dot-product core of nn.MultiheadAttention (descriptor_attention.py:14-15,35-45):
+ * out[b,m,h*d:(h+1)*d] = softmax(Q_h K_h^T / sqrt(d)) V_h; no masks, dropout 0; head_dim 32.
+ * Q/K/V/out: row leading dims ld*, batch strides s* (in floats). */
+int dpm_attention(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                  const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
+                  int N, int heads, int head_dim, dpm_stream_t stream);
+
+/* F.normalize(x, p=2, dim=-1) (decoder.py:185): x / max(||x||, 1e-12), rows (R,C). */
+int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stream);
+
+/* Decoder._descriptor_pairing tail (decoder.py:186-191): S (M,N) similarity, overwritten with
+ * P = softmax_row(S/tau) * softmax_col(S/tau); then the k largest entries of the flattened P,
+ * sorted descending: out_val (k), out_idx (k) flat indices (row = idx / N, col = idx % N). */
+size_t dpm_pairing_workspace_bytes(int M, int N);
+int dpm_dual_softmax_topk(float *S, int M, int N, double tau, int k, float *out_val, int32_t *out_idx,
+                          void *workspace, dpm_stream_t stream);
+
+/* Decoder._get_corres_sets input assembly (decoder.py:204-205): for the k flat indices,
+ * X[0:k] = [x[src] | y[dst]], X[k:2k] = [y[dst] | x[src]] (rows of 2E), and the decoded
+ * src_idx/dst_idx (k). x (M,E), y (N,E). */
+int dpm_gather_pairs(const float *x, const float *y, const int32_t *flat_idx, int k, int N, int E,
+                     float *X, int32_t *src_idx, int32_t *dst_idx, dpm_stream_t stream);
+
+/* torch.mean over the points of each batch element (OverlapHead, heads.py:64-65):
+ * x (B,R,C) -> out[b, 0:C] with row stride ldo. */
+int dpm_mean_rows(const float *x, int B, int R, int C, float *out, int ldo, dpm_stream_t stream);
+
+/* Decoder._get_corres_sets + _solve_transformation_SVD (decoder.py:208-265): offsets (2k,3)
+ * [first k: src->dst, next k: dst->src], keypoint coordinates, pair indices and confidences ->
+ * result[0:9] R row-major, [9:12] T, [12] rmse, [13] #correspondences, [14] #inliers,
+ * [15] iterations, [16:16+#inliers] inlier confidences in correspondence order.
+ * result holds 16 + 2k floats. R = V U^T of the fp64 SVD, no reflection fix.
+ * offsets == NULL: src_xyz/dst_xyz/conf are taken as k ready-made correspondences (rows) and
+ * only _solve_transformation_SVD runs. */
+size_t dpm_kabsch_workspace_bytes(int k);
+int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, const float *dst_xyz,
+                    int ld_dst, const int32_t *src_idx, const int32_t *dst_idx, const float *conf, int k,
+                    double eps_offset, int num_iter, double std_ratio, void *workspace, float *result,
+                    dpm_stream_t stream);
+
+/* ---------------------------------------------------------------- registration edge ---- */
+
+/* calculate_information_matrix_from_pcd (system/modules/utils.py:60-113), pytorch3d branch:
+ * pcd1 (3,N1), pcd2 (3,N2) channel-first metres; Rt = 12 floats (R row-major, then T);
+ * out6x6 = sum over source points whose transformed nearest target lies within `radius` of the
+ * G^T G of that target point.  Exact nearest neighbours via a uniform grid. */
+size_t dpm_infomat_workspace_bytes(int N1, int N2);
+int dpm_information_matrix(const float *pcd1, int N1, const float *pcd2, int N2, const float *Rt,
+                           double radius, float *out6x6, void *workspace, dpm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,158 @@
+"""GPU: decoder / registration kernels and the Decoder module against reference fixtures and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, load_golden, rot_angle
+from oracle import dpm_oracle as O
+from deeppointmap_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from deeppointmap_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def dec(cfg_full):
+    from deeppointmap_amd.decoder import Decoder
+    from deeppointmap_amd.weights import init_procedural
+    return init_procedural(Decoder(cfg_full)).to(DEV)
+
+
+def test_position_embedding_vs_reference(dec, ops):
+    g = load_golden("decoder.npz")
+    xyz = T(g["posemb.xyz"]).to(DEV)
+    out = ops.posemb(xyz, dec._dimt(torch.device(DEV)), 256).cpu().numpy()
+    np.testing.assert_allclose(out, g["posemb.out"], rtol=0, atol=2e-6)
+    assert np.all(out[:, 252:] == 0)
+
+
+def test_attention_core_vs_torch(ops):
+    gen = torch.Generator().manual_seed(3)
+    for B, M, N in [(1, 256, 256), (2, 100, 333), (1, 1024, 256), (3, 17, 5)]:
+        q, k, v = (torch.randn(B * n, 256, generator=gen) for n in (M, N, N))
+        out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), B, M, N, 8).cpu()
+        qh = q.view(B, M, 8, 32).transpose(1, 2).double()
+        kh = k.view(B, N, 8, 32).transpose(1, 2).double()
+        vh = v.view(B, N, 8, 32).transpose(1, 2).double()
+        want = (torch.softmax(qh @ kh.transpose(-1, -2) / 32 ** 0.5, -1) @ vh).transpose(1, 2).reshape(B * M, 256).float()
+        torch.testing.assert_close(out, want, rtol=1e-4, atol=2e-5)
+    # strided operands: q/k/v as column slices of one (rows, 768) buffer (how the module calls it)
+    qkv = torch.randn(256, 768, generator=gen).to(DEV)
+    a = ops.attention(qkv[:, :256], qkv[:, 256:512], qkv[:, 512:], 1, 256, 256, 8)
+    b = ops.attention(qkv[:, :256].contiguous(), qkv[:, 256:512].contiguous(), qkv[:, 512:].contiguous(), 1, 256, 256, 8)
+    assert torch.equal(a, b)
+
+
+def test_dual_softmax_topk_vs_torch(ops):
+    gen = torch.Generator().manual_seed(7)
+    for M, N, k in [(256, 256, 128), (1024, 256, 640), (300, 77, 1), (64, 64, 4096)]:
+        a = torch.nn.functional.normalize(torch.randn(M, 64, generator=gen), dim=1)
+        b = torch.nn.functional.normalize(torch.randn(N, 64, generator=gen), dim=1)
+        S = a @ b.t()
+        P = torch.softmax(S / 0.1, 1) * torch.softmax(S / 0.1, 0)
+        wv, wi = torch.topk(P.reshape(-1), k)
+        Sd = S.clone().to(DEV)
+        val, idx = ops.dual_softmax_topk(Sd, 0.1, k)
+        torch.testing.assert_close(Sd.cpu(), P, rtol=2e-5, atol=1e-12)
+        torch.testing.assert_close(val.cpu(), wv, rtol=2e-5, atol=1e-12)
+        assert bool((val[:-1] >= val[1:]).all()), "top-k must come out sorted descending"
+        # the GPU's own matrix, re-selected exactly on the host, must give the same index set
+        gv, gi = torch.topk(Sd.cpu().reshape(-1), k)
+        assert set(idx.cpu().tolist()) == set(gi.tolist())
+
+
+def test_topk_ties_and_exact_values(ops):
+    # many equal values: result must still be a valid top-k (multiset of values equal), deterministic
+    P = (torch.randint(0, 6, (128, 128)).float() / 8).to(DEV)
+    k = 500
+    Q = P.clone()
+    v1, i1 = ops.dual_softmax_topk(Q, 1.0, k)
+    v2, i2 = ops.dual_softmax_topk(P.clone(), 1.0, k)
+    assert torch.equal(v1, v2) and torch.equal(i1, i2)  # deterministic under ties
+    wv = torch.topk(Q.cpu().reshape(-1), k)[0]
+    assert torch.equal(v1.cpu(), wv)  # same multiset of values as an exact host top-k of the same matrix
+    assert len(set(i1.cpu().tolist())) == k
+
+
+@pytest.mark.parametrize("name", ["svd_clean200", "svd_outliers300", "svd_few40", "svd_reflect120", "svd_lowconf100"])
+def test_kabsch_loop_vs_reference(name, ops):
+    g = load_golden("decoder.npz")
+    w, src, dst = T(g[name + ".w"]), T(g[name + ".src"]), T(g[name + ".dst"])
+    res = ops.corr_kabsch(None, src.t().contiguous().to(DEV), dst.t().contiguous().to(DEV), None, None,
+                          w.to(DEV), 2.0).cpu()
+    R, Tt, rmse, n, n_in = res[:9].view(3, 3), res[9:12].view(3, 1), float(res[12]), int(res[13]), int(res[14])
+    assert n == w.numel() and n_in == int(g[name + ".mask"].sum())
+    np.testing.assert_allclose(R.numpy(), g[name + ".R"], atol=2e-6)
+    np.testing.assert_allclose(Tt.numpy(), g[name + ".T"], atol=2e-5)
+    assert abs(rmse - float(g[name + ".rmse"])) < 2e-5
+    np.testing.assert_allclose(res[16:16 + n_in].numpy(), w.numpy()[g[name + ".mask"]], rtol=0, atol=0)
+    if name == "svd_reflect120":
+        assert np.linalg.det(R.double().numpy()) < 0  # R = V U^T is left uncorrected (decoder.py:243)
+
+
+@pytest.mark.parametrize("name", ["synthetic01", "kitti01", "map1024_vs_256"])
+def test_registration_forward_vs_reference(name, dec):
+    g = load_golden("decoder.npz")
+    s, d = T(g[name + ".src_desc"]), T(g[name + ".dst_desc"])
+    tr = {}
+    R, Tt, conf, rmse = dec.registration_forward(s, d, num_sample=0.5, trace=tr)  # CPU inputs, like ScanPack
+    assert R.is_cuda and tuple(R.shape) == (3, 3) and tuple(Tt.shape) == (3, 1) and isinstance(rmse, float)
+    np.testing.assert_allclose(tr["x"].cpu().numpy(), g[name + ".src_corr"][:-3].T, atol=3e-4, rtol=0)
+    np.testing.assert_allclose(tr["y"].cpu().numpy(), g[name + ".dst_corr"][:-3].T, atol=3e-4, rtol=0)
+    np.testing.assert_allclose(tr["conf"].cpu().numpy(), g[name + ".pair_conf"], rtol=3e-3, atol=0)
+    assert tr["n_corr"] == g[name + ".corr_w"].shape[0]
+    # the tolerance north_star states: 1e-4 m / 1e-4 rad
+    dT = float((Tt.cpu() - T(g[name + ".T"])).norm())
+    dR = rot_angle(R.cpu(), g[name + ".R"])
+    assert dT < 1e-4 and dR < 1e-4, (dT, dR)
+    assert conf.shape[0] == g[name + ".conf"].shape[0]
+    np.testing.assert_allclose(conf.cpu().numpy(), g[name + ".conf"], rtol=3e-3, atol=0)
+    assert abs(rmse - float(g[name + ".rmse"])) < 1e-3
+    # batched call shape contract (decoder.py:122-126)
+    Rb, Tb, cb, rb = dec.registration_forward(s.unsqueeze(0), d.unsqueeze(0), num_sample=0.5)
+    assert tuple(Rb.shape) == (1, 3, 3) and tuple(Tb.shape) == (1, 3, 1) and cb.dim() == 2 and isinstance(rb, list)
+    assert torch.equal(Rb[0], R)
+
+
+def test_registration_argument_errors(dec):
+    d = torch.zeros(131, 16)
+    with pytest.raises(ValueError):
+        dec.registration_forward(d, d, num_sample=0.0)
+    with pytest.raises(ValueError):
+        dec.registration_forward(d, d, num_sample="half")
+    with pytest.raises(AssertionError):
+        dec.forward(d, d)  # training-only in the reference (decoder.py:37)
+    with pytest.raises(NotImplementedError):
+        dec.registration_forward(d, d, src_padding_mask=torch.zeros(1, 16, dtype=torch.bool))
+
+
+def test_loop_detection_vs_reference(dec):
+    g = load_golden("decoder.npz")
+    p = dec.loop_detection_forward(T(g["loop.src"]), T(g["loop.dst"]))
+    assert tuple(p.shape) == (3,)
+    np.testing.assert_allclose(p.cpu().numpy(), g["loop.prob"], atol=2e-5, rtol=0)
+
+
+def test_information_matrix_vs_oracle():
+    from deeppointmap_amd.registration import calculate_information_matrix_from_pcd
+    for n in (4096, 65536):
+        a, b = synthetic.frame(0, n) * 60, synthetic.frame(1, n) * 60
+        SE3 = synthetic.relative_pose(0, 1).float()
+        SE3[:3, 3] += torch.tensor([0.03, -0.02, 0.01])
+        want = O.information_matrix(a, b, SE3)
+        got = calculate_information_matrix_from_pcd(a, b, SE3, device=DEV)
+        assert got.device.type == "cpu" and got.dtype == torch.float32 and tuple(got.shape) == (6, 6)
+        assert float(want[3, 3]) > 0.3 * n  # most points do find a neighbour within 1 m
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * float(want.abs().max()))
+    # hand case: nothing within the radius -> zero matrix; identity on a shifted copy -> counts
+    a = torch.tensor([[0.0, 10, 20], [0, 0, 0], [1, 2, 3]])
+    got = calculate_information_matrix_from_pcd(a, a + 50.0, torch.eye(4), device=DEV)
+    assert float(got.abs().sum()) == 0.0
+    got = calculate_information_matrix_from_pcd(a, a, torch.eye(4), device=DEV)
+    assert float(got[3, 3]) == 3.0 and float(got[0, 4]) == -6.0 and float(got[1, 5]) == -30.0
