@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes
 import os
+
+import torch  # noqa: F401  -- must precede the CDLL below: libdpm_hip.so has to bind to the HIP runtime torch ships
 from ctypes import c_char_p, c_double, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -37,7 +39,7 @@ SIGNATURES = {
     "dpm_gather_pairs": (I, [P, P, P, I, I, I, P, P, P, P]),
     "dpm_mean_rows": (I, [P, I, I, I, P, I, P]),
     "dpm_kabsch_workspace_bytes": (c_size_t, [I]),
-    "dpm_corr_kabsch": (I, [P, P, I, P, I, P, P, P, I, D, I, D, P, P, P]),
+    "dpm_corr_kabsch": (I, [P, P, I, P, I, P, P, P, I, D, I, D, P, P, P, P]),
     "dpm_infomat_workspace_bytes": (c_size_t, [I, I]),
     "dpm_information_matrix": (I, [P, I, P, I, P, D, P, P, P]),
 }

@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void mean_rows_kernel(const float *__restrict_
 // a14 + a15: correspondence sets and the iterative weighted Kabsch (decoder.py:202-265)
 // ------------------------------------------------------------------------------------------
 constexpr int KB = 256;  // threads
+constexpr int RES_HDR = 20;  // floats before the inlier-confidence list in `result`
 
 template <typename T>
 __device__ T block_sum(T v, T *scratch /* KB/64 entries */) {
@@ -365,12 +366,15 @@ __device__ void rot_from_cov(const double A[9], double Rm[9]) {
 }
 
 // result layout (floats): [0:9] R row-major, [9:12] T, [12] rmse, [13] n_corr, [14] n_inlier, [15] iterations,
-// [16 : 16+n_inlier] confidences of the inliers (in correspondence order)
+// [16] mean of the first 30 inlier confidences (simvec_to_num, system/modules/utils.py:18), [17:20] reserved,
+// [20 : 20+n_inlier] confidences of the inliers (in correspondence order).  `header` (optional) receives a
+// copy of the first 20 floats (lets the caller assemble an edge table without extra kernels).
 __global__ __launch_bounds__(KB) void corr_kabsch_kernel(
     const float *__restrict__ off /* (2k,3) */, const float *__restrict__ sxyz, int lds_,
     const float *__restrict__ dxyz, int ldd, const int32_t *__restrict__ si, const int32_t *__restrict__ di,
     const float *__restrict__ conf, int k, float eps2, int num_iter, float std_ratio,
-    float *__restrict__ ws /* 7*2k floats + 2*2k ints */, float *__restrict__ result) {
+    float *__restrict__ ws /* 7*2k floats + 2*2k ints */, float *__restrict__ result,
+    float *__restrict__ header) {
     __shared__ int s_cnt[KB / 64];
     __shared__ int s_run;
     __shared__ float s_f[KB / 64];
@@ -568,10 +572,19 @@ __global__ __launch_bounds__(KB) void corr_kabsch_kernel(
                 if (x < w) base += s_cnt[x];
                 tot += s_cnt[x];
             }
-            if (keep) result[16 + base + __popcll(m & ((1ull << lane) - 1ull))] = wt[p];
+            if (keep) result[RES_HDR + base + __popcll(m & ((1ull << lane) - 1ull))] = wt[p];
             __syncthreads();
             if (t == 0) s_run += tot;
             __syncthreads();
+        }
+        if (t == 0) {
+            const int m30 = min(30, n_in);
+            float cm = 0.f;
+            for (int q = 0; q < m30; ++q) cm += result[RES_HDR + q];
+            result[16] = m30 > 0 ? cm / (float)m30 : 0.f;
+            result[17] = result[18] = result[19] = 0.f;
+            if (header)
+                for (int q = 0; q < RES_HDR; ++q) header[q] = result[q];
         }
     }
 }
@@ -638,12 +651,13 @@ extern "C" size_t dpm_kabsch_workspace_bytes(int k) { return (size_t)(2 * k) * (
 
 extern "C" int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, const float *dst_xyz, int ld_dst,
                                const int32_t *src_idx, const int32_t *dst_idx, const float *conf, int k, double eps_offset,
-                               int num_iter, double std_ratio, void *workspace, float *result, dpm_stream_t stream) {
+                               int num_iter, double std_ratio, void *workspace, float *result, float *header,
+                               dpm_stream_t stream) {
     DPM_CHECK_ARG(src_xyz && dst_xyz && conf && workspace && result);
     DPM_CHECK_ARG(!offsets || (src_idx && dst_idx));
     DPM_CHECK_ARG(k >= 1 && ld_src >= 3 && ld_dst >= 3 && num_iter >= 1);
     hipLaunchKernelGGL(corr_kabsch_kernel, dim3(1), dim3(KB), 0, (hipStream_t)stream, offsets, src_xyz, ld_src, dst_xyz,
                        ld_dst, src_idx, dst_idx, conf, k, (float)(eps_offset * eps_offset), num_iter, (float)std_ratio,
-                       (float *)workspace, result);
+                       (float *)workspace, result, header);
     return dpm_launch_status();
 }

@@ -133,7 +133,7 @@ class Decoder(ParamTree):
     @torch.no_grad()
     def registration_forward(self, src_descriptor: torch.Tensor, dst_descriptor: torch.Tensor,
                              src_padding_mask=None, dst_padding_mask=None,
-                             num_sample: Union[int, float] = 0.5, trace: dict = None):
+                             num_sample: Union[int, float] = 0.5, trace: dict = None, header_out: torch.Tensor = None):
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("deeppointmap_amd.Decoder runs on the GPU only (there is no CPU fallback)")
@@ -155,10 +155,10 @@ class Decoder(ParamTree):
             h = self._lin("offset_head.mlp.2", self._lin("offset_head.mlp.0", X, ops.ACT_RELU), ops.ACT_RELU)
             h = self._lin("offset_head.mlp.4", h, ops.ACT_RELU, residual=self._lin("offset_head.downsample", X))
             off = self._lin("offset_head.head", h)
-            res = ops.corr_kabsch(off, xyz_s, xyz_d, si, di, conf, self.args.loss.eps_offset)
-            head = res[:16].cpu()  # the one host sync of the call: rmse is a python float in the contract
+            res = ops.corr_kabsch(off, xyz_s, xyz_d, si, di, conf, self.args.loss.eps_offset, header_out=header_out)
+            head = res[:ops.RES_HDR].cpu()  # the one host sync of the call: rmse is a python float in the contract
         n_in, rmse = int(head[14]), float(head[12])
-        R, T, cf = res[0:9].view(3, 3), res[9:12].view(3, 1), res[16:16 + n_in]
+        R, T, cf = res[0:9].view(3, 3), res[9:12].view(3, 1), res[ops.RES_HDR:ops.RES_HDR + n_in]
         if trace is not None:
             trace.update(x=x, y=y, conf=conf, flat=flat, src_index=si, dst_index=di, offsets=off,
                          n_corr=int(head[13]), iterations=int(head[15]))

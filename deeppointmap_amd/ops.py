@@ -231,9 +231,13 @@ def mean_rows(x: torch.Tensor, out: torch.Tensor) -> None:
     _lib.check(_lib.load().dpm_mean_rows(_ptr(x), B, R, C, _ptr(out), out.stride(0), _stream(x)), "dpm_mean_rows")
 
 
+RES_HDR = 20  # floats before the inlier-confidence list in a corr_kabsch result
+
+
 def corr_kabsch(offsets, src_xyz, dst_xyz, src_idx, dst_idx, conf, eps_offset: float, num_iter: int = 3,
-                std_ratio: float = 3.0) -> torch.Tensor:
-    """-> result (16 + 2k,) fp32: R(9) T(3) rmse n_corr n_inlier iters, then inlier confidences."""
+                std_ratio: float = 3.0, header_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> result (20 + 2k,) fp32: R(9) T(3) rmse n_corr n_inlier iters conf30 (3 reserved), then the inlier
+    confidences.  header_out: optional contiguous (>=20,) fp32 view that also receives result[:20]."""
     _chk(conf, torch.float32, "conf")
     _rows2d(src_xyz, "src_xyz"), _rows2d(dst_xyz, "dst_xyz")
     if offsets is not None:  # None: (conf, src_xyz, dst_xyz) are ready-made correspondences
@@ -242,20 +246,28 @@ def corr_kabsch(offsets, src_xyz, dst_xyz, src_idx, dst_idx, conf, eps_offset: f
     k = conf.numel()
     lib = _lib.load()
     ws = torch.empty(lib.dpm_kabsch_workspace_bytes(k), device=conf.device, dtype=torch.uint8)
-    result = torch.zeros(16 + 2 * k, device=conf.device, dtype=torch.float32)
+    result = torch.empty(RES_HDR + 2 * k, device=conf.device, dtype=torch.float32)
+    if header_out is not None:
+        _chk(header_out, torch.float32, "header_out")
     _lib.check(lib.dpm_corr_kabsch(_ptr(offsets), _ptr(src_xyz), src_xyz.stride(0), _ptr(dst_xyz), dst_xyz.stride(0),
                                    _ptr(src_idx), _ptr(dst_idx), _ptr(conf), k, float(eps_offset), num_iter,
-                                   float(std_ratio), _ptr(ws), _ptr(result), _stream(conf)), "dpm_corr_kabsch")
+                                   float(std_ratio), _ptr(ws), _ptr(result), _ptr(header_out), _stream(conf)),
+               "dpm_corr_kabsch")
     return result
 
 
-def information_matrix(pcd1: torch.Tensor, pcd2: torch.Tensor, Rt: torch.Tensor, radius: float = 1.0) -> torch.Tensor:
-    """pcd1 (3,N1), pcd2 (3,N2) metres on the GPU, Rt (12,) [R row-major, T] -> (6,6) fp32 on the GPU."""
+def information_matrix(pcd1: torch.Tensor, pcd2: torch.Tensor, Rt: torch.Tensor, radius: float = 1.0,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pcd1 (3,N1), pcd2 (3,N2) metres on the GPU, Rt (>=12,) [R row-major, T, ...] -> (6,6) fp32 on the GPU
+    (written into `out`, a contiguous 36-float view, when given)."""
     _chk(pcd1, torch.float32, "pcd1"), _chk(pcd2, torch.float32, "pcd2"), _chk(Rt, torch.float32, "Rt")
     N1, N2 = pcd1.shape[1], pcd2.shape[1]
     lib = _lib.load()
     ws = torch.empty(lib.dpm_infomat_workspace_bytes(N1, N2), device=pcd1.device, dtype=torch.uint8)
-    out = torch.empty(6, 6, device=pcd1.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(6, 6, device=pcd1.device, dtype=torch.float32)
+    else:
+        _chk(out, torch.float32, "out")
     _lib.check(lib.dpm_information_matrix(_ptr(pcd1), N1, _ptr(pcd2), N2, _ptr(Rt), float(radius), _ptr(out),
                                           _ptr(ws), _stream(pcd1)), "dpm_information_matrix")
     return out

@@ -1,0 +1,74 @@
+"""The hot path as one call: encode a batch of scans, register consecutive frames, build the
+information matrix of each edge -- what SlamSystem.step does per frame through
+ExtractionThread.process + OdometryThread.odometry (reference system/core.py:369-393,
+system/modules/odometry.py:36-54,103-127), minus the pose-graph bookkeeping.
+
+Used by bench.py, the smoke test and the parity tests; frame sharding across ranks lives in
+shard.py.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .decoder import Decoder
+from .encoder import Encoder
+from .registration import make_descriptors
+
+EDGE_FLOATS = 56  # per edge: 20-float registration header (R, T, rmse, n_corr, n_inlier, iters, conf30, ...) + 6x6 information
+
+
+@dataclass
+class Edge:
+    """One odometry edge (what PoseGraph_Edge receives, odometry.py:119-125)."""
+    src: int
+    dst: int
+    R: torch.Tensor           # (3,3) device
+    T: torch.Tensor           # (3,1) device, metres
+    conf: torch.Tensor        # (n_inlier,) device
+    rmse: float
+    information: Optional[torch.Tensor]  # (6,6) device
+
+
+class HotPath:
+    def __init__(self, encoder: Encoder, decoder: Decoder, coor_scale: float = 60.0, num_sample=0.5):
+        self.encoder, self.decoder = encoder, decoder
+        self.coor_scale, self.num_sample = float(coor_scale), num_sample
+
+    @torch.no_grad()
+    def extract(self, points: torch.Tensor, padding: torch.Tensor) -> torch.Tensor:
+        """(F,3,N) normalised scans -> unified descriptors (F,131,256): rows 0-127 feature, 128-130 xyz in metres."""
+        coor, fea, _ = self.encoder(points, padding)
+        return make_descriptors(coor, fea, self.coor_scale)
+
+    @torch.no_grad()
+    def register(self, desc: torch.Tensor, pcd_m: Optional[torch.Tensor], pairs, table: Optional[torch.Tensor] = None):
+        """desc (F,131,S); pcd_m (F,3,N) scans in metres (None: skip the information matrix);
+        pairs: list of (src_frame, dst_frame).  Returns (edges, table): table (E, EDGE_FLOATS) is filled on
+        the device by the kernels themselves (registration header | information matrix) -- it is what a
+        rank ships to rank 0."""
+        pairs = list(pairs)
+        if table is None:
+            table = torch.zeros(len(pairs), EDGE_FLOATS, device=desc.device, dtype=torch.float32)
+        edges = []
+        for e, (s, d) in enumerate(pairs):
+            row = table[e]
+            R, T, conf, rmse = self.decoder.registration_forward(desc[s], desc[d], num_sample=self.num_sample,
+                                                                 header_out=row[:ops.RES_HDR])
+            info = None
+            if pcd_m is not None:
+                info = ops.information_matrix(pcd_m[s], pcd_m[d], row[:12], 1.0, out=row[ops.RES_HDR:]).view(6, 6)
+            edges.append(Edge(s, d, R, T, conf, rmse, info))
+        return edges, table
+
+    @torch.no_grad()
+    def step(self, points: torch.Tensor, padding: torch.Tensor, pcd_m: Optional[torch.Tensor]):
+        """One batch: every frame is encoded and registered against its predecessor (frame 0 against
+        the last frame of the batch, so a batch of F frames carries exactly F edges)."""
+        desc = self.extract(points, padding)
+        F = desc.shape[0]
+        edges, table = self.register(desc, pcd_m, [((f - 1) % F, f) for f in range(F)])
+        return desc, edges, table

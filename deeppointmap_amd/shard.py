@@ -1,0 +1,47 @@
+"""Frame sharding across the GPUs of one node (one process per GPU, torch.distributed over RCCL).
+
+The encoder has no cross-frame state (LayerNorm only, reference configs/infer/*.yaml:49), so
+frames shard embarrassingly: rank r owns a contiguous block of frames (the reference's own
+multi-thread mode batches EXTRACTOR_BATCHSIZE consecutive frames the same way,
+system/core.py:141-143).  The only exchange step is the gather of per-frame results to rank 0,
+where the sequential pose-graph logic of system/core.py runs: descriptors (131 x 256 fp32 =
+134 144 B per frame) and the speculative consecutive-frame edges (R, T, rmse, confidence,
+6x6 information = 56 floats per edge, pipeline.EDGE_FLOATS).  That is ~1 MB per 8-frame round: latency-bound on xGMI,
+so whole shards are gathered with ONE collective per step rather than per frame.
+
+The reference has no inference-time collective; this module is new.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+
+def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [start, stop) of rank `rank`; the first n_frames % world ranks get one extra."""
+    base, extra = divmod(n_frames, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def gather_to_root(t: torch.Tensor, root: int = 0) -> Optional[torch.Tensor]:
+    """Equal-shaped per-rank tensor (F, ...) -> on `root`: (world*F, ...) in rank order; None elsewhere.
+    A no-op (returns t) when torch.distributed is not initialised or world == 1."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = t.contiguous()
+    if rank == root:
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.gather(t, gather_list=list(out.unbind(0)), dst=root)
+        return out.reshape((world * t.shape[0],) + tuple(t.shape[1:]))
+    dist.gather(t, gather_list=None, dst=root)
+    return None
+
+
+def gather_step_results(desc: torch.Tensor, edges_packed: torch.Tensor, root: int = 0):
+    """One step's exchange: descriptors (F,131,S) and packed edges (F,EDGE_FLOATS) -> rank 0."""
+    return gather_to_root(desc, root), gather_to_root(edges_packed, root)

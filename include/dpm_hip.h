@@ -138,15 +138,17 @@ int dpm_mean_rows(const float *x, int B, int R, int C, float *out, int ldo, dpm_
 /* Decoder._get_corres_sets + _solve_transformation_SVD (decoder.py:208-265): offsets (2k,3)
  * [first k: src->dst, next k: dst->src], keypoint coordinates, pair indices and confidences ->
  * result[0:9] R row-major, [9:12] T, [12] rmse, [13] #correspondences, [14] #inliers,
- * [15] iterations, [16:16+#inliers] inlier confidences in correspondence order.
- * result holds 16 + 2k floats. R = V U^T of the fp64 SVD, no reflection fix.
+ * [15] iterations, [16] mean of the first 30 inlier confidences (simvec_to_num,
+ * system/modules/utils.py:18), [17:20] reserved, [20:20+#inliers] inlier confidences in
+ * correspondence order.  result holds 20 + 2k floats; `header` (NULL-able) receives a copy of
+ * result[0:20].  R = V U^T of the fp64 SVD, no reflection fix.
  * offsets == NULL: src_xyz/dst_xyz/conf are taken as k ready-made correspondences (rows) and
  * only _solve_transformation_SVD runs. */
 size_t dpm_kabsch_workspace_bytes(int k);
 int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, const float *dst_xyz,
                     int ld_dst, const int32_t *src_idx, const int32_t *dst_idx, const float *conf, int k,
                     double eps_offset, int num_iter, double std_ratio, void *workspace, float *result,
-                    dpm_stream_t stream);
+                    float *header, dpm_stream_t stream);
 
 /* ---------------------------------------------------------------- registration edge ---- */
 
@@ -155,6 +157,7 @@ int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, cons
  * out6x6 = sum over source points whose transformed nearest target lies within `radius` of the
  * G^T G of that target point.  Exact nearest neighbours via a uniform grid. */
 size_t dpm_infomat_workspace_bytes(int N1, int N2);
+/* Rt may point into a dpm_corr_kabsch result (its first 12 floats are R row-major, T). */
 int dpm_information_matrix(const float *pcd1, int N1, const float *pcd2, int N2, const float *Rt,
                            double radius, float *out6x6, void *workspace, dpm_stream_t stream);
 

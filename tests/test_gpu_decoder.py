@@ -91,7 +91,8 @@ def test_kabsch_loop_vs_reference(name, ops):
     np.testing.assert_allclose(R.numpy(), g[name + ".R"], atol=2e-6)
     np.testing.assert_allclose(Tt.numpy(), g[name + ".T"], atol=2e-5)
     assert abs(rmse - float(g[name + ".rmse"])) < 2e-5
-    np.testing.assert_allclose(res[16:16 + n_in].numpy(), w.numpy()[g[name + ".mask"]], rtol=0, atol=0)
+    np.testing.assert_allclose(res[20:20 + n_in].numpy(), w.numpy()[g[name + ".mask"]], rtol=0, atol=0)
+    assert abs(float(res[16]) - float(w[T(g[name + ".mask"])][:30].mean())) < 1e-6
     if name == "svd_reflect120":
         assert np.linalg.det(R.double().numpy()) < 0  # R = V U^T is left uncorrected (decoder.py:243)
 

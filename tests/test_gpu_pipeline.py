@@ -1,0 +1,65 @@
+"""GPU: the whole hot path at BASELINE.json's full size -- encode two 65 536-point scans, register them,
+build the information matrix -- against the pose the REFERENCE computed on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, load_golden, rot_angle
+from oracle import dpm_oracle as O
+from deeppointmap_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hot(cfg_full):
+    from deeppointmap_amd.decoder import Decoder
+    from deeppointmap_amd.encoder import Encoder
+    from deeppointmap_amd.pipeline import HotPath
+    from deeppointmap_amd.weights import init_procedural
+    return HotPath(init_procedural(Encoder(cfg_full)).to(DEV), init_procedural(Decoder(cfg_full)).to(DEV))
+
+
+def test_full_size_pose_parity_vs_reference(hot):
+    g = load_golden("decoder.npz")
+    pts, pad = synthetic.frames(2, 65536)
+    pcd_m = (pts * 60).to(DEV)
+    desc, edges, table = hot.step(pts.to(DEV), pad.to(DEV), pcd_m)
+    # descriptors of both frames equal the reference's (the registration fixture stores them)
+    np.testing.assert_allclose(desc[0].cpu().numpy(), g["synthetic01.src_desc"], atol=3e-4 * 60, rtol=0)
+    np.testing.assert_allclose(desc[0, :128].cpu().numpy(), g["synthetic01.src_desc"][:128], atol=3e-4, rtol=0)
+    np.testing.assert_allclose(desc[1, :128].cpu().numpy(), g["synthetic01.dst_desc"][:128], atol=3e-4, rtol=0)
+    e = edges[1]  # frame 0 -> frame 1
+    dT = float((e.T.cpu() - T(g["synthetic01.T"])).norm())
+    dR = rot_angle(e.R.cpu(), g["synthetic01.R"])
+    assert dT < 1e-4 and dR < 1e-4, (dT, dR)   # north_star tolerance: 1e-4 m / 1e-4 rad
+    assert e.conf.shape[0] == g["synthetic01.conf"].shape[0]
+    assert abs(e.rmse - float(g["synthetic01.rmse"])) < 1e-3
+    # edge table row = [registration header | information matrix], written by the kernels themselves
+    row = table[1].cpu()
+    assert torch.equal(row[:9].view(3, 3), e.R.cpu()) and torch.equal(row[9:12].view(3, 1), e.T.cpu())
+    assert abs(float(row[12]) - e.rmse) < 1e-7 and int(row[14]) == e.conf.shape[0]
+    assert abs(float(row[16]) - float(e.conf[:30].mean())) < 1e-9
+    G = O.information_matrix(pts[0] * 60, pts[1] * 60, O.se3(e.R.cpu(), e.T.cpu()))
+    np.testing.assert_allclose(row[20:].view(6, 6).numpy(), G.numpy(), rtol=2e-4, atol=2e-4 * float(G.abs().max()))
+
+
+def test_size_independent_properties(hot):
+    # permuting the points of a scan permutes nothing downstream except FPS's start point (index 0):
+    # keep point 0 fixed, shuffle the rest -> identical keypoint SET and descriptors up to ordering
+    pts, pad = synthetic.frames(1, 65536)
+    perm = torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(65535, generator=torch.Generator().manual_seed(0))])
+    d0 = hot.extract(pts.to(DEV), pad.to(DEV))[0].cpu()
+    d1 = hot.extract(pts[:, :, perm].contiguous().to(DEV), pad.to(DEV))[0].cpu()
+    k0 = d0[128:].t().contiguous().numpy()
+    k1 = d1[128:].t().contiguous().numpy()
+    assert np.array_equal(k0, k1), "FPS picks depend on geometry only (ties aside), not on storage order"
+    # features: which of two EQUIDISTANT neighbours is grouped at the K-th slot follows the reference's
+    # heap-select and therefore the storage order, so a handful of rows may differ in one neighbour
+    diff = np.abs(d0[:128].numpy() - d1[:128].numpy())
+    assert diff.max() < 1e-2 and (diff > 3e-4).mean() < 0.15
+    # registering a scan against itself gives the identity
+    edges, _ = hot.register(torch.stack([d0, d0]).to(DEV), None, [(0, 1)])
+    assert float((edges[0].R.cpu() - torch.eye(3)).abs().max()) < 1e-4
+    assert float(edges[0].T.cpu().abs().max()) < 1e-3
