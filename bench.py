@@ -124,7 +124,8 @@ def main():
     enc_mod.ops.fps = timed_fps
 
     def step():
-        desc, edges, table = hot.step(pts, pad, pcd_m)
+        # edges stay on the device in `table` (header | information per frame); no host sync inside a step
+        desc, edges, table = hot.step(pts, pad, pcd_m, materialize=False)
         gather_step_results(desc, table)
         return desc, table
 

@@ -29,19 +29,21 @@ SIGNATURES = {
     "dpm_knn_hybrid": (I, [P, P, P, I, I, I, I, D, P, P]),
     "dpm_group_mlp_max": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, D, P, P]),
     "dpm_linear": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
+    "dpm_linear_batched": (I, [P, I, LL, P, I, LL, P, P, I, LL, P, I, LL, I, I, I, I, I, P]),
     "dpm_layernorm": (I, [P, I, P, P, P, P, P, I, I, I, I, P]),
     "dpm_three_interp_cat": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),
     "dpm_posemb": (I, [P, I, P, I, I, I, P, P]),
     "dpm_attention": (I, [P, I, LL, P, I, LL, P, I, LL, P, I, LL, I, I, I, I, I, P]),
     "dpm_l2_normalize": (I, [P, I, I, P, P]),
-    "dpm_pairing_workspace_bytes": (c_size_t, [I, I]),
-    "dpm_dual_softmax_topk": (I, [P, I, I, D, I, P, P, P, P]),
-    "dpm_gather_pairs": (I, [P, P, P, I, I, I, P, P, P, P]),
+    "dpm_pairing_workspace_bytes": (c_size_t, [I, I, I]),
+    "dpm_dual_softmax_topk": (I, [P, I, I, I, D, I, P, P, P, P]),
+    "dpm_gather_pairs": (I, [P, P, P, I, I, I, I, I, P, P, P, P]),
     "dpm_mean_rows": (I, [P, I, I, I, P, I, P]),
-    "dpm_kabsch_workspace_bytes": (c_size_t, [I]),
-    "dpm_corr_kabsch": (I, [P, P, I, P, I, P, P, P, I, D, I, D, P, P, P, P]),
-    "dpm_infomat_workspace_bytes": (c_size_t, [I, I]),
+    "dpm_kabsch_workspace_bytes": (c_size_t, [I, I]),
+    "dpm_corr_kabsch": (I, [P, P, I, LL, P, I, LL, P, P, P, I, I, D, I, D, P, P, P, I, P]),
+    "dpm_infomat_workspace_bytes": (c_size_t, [I, I, I]),
     "dpm_information_matrix": (I, [P, I, P, I, P, D, P, P, P]),
+    "dpm_information_matrix_batched": (I, [P, I, P, P, I, P, I, D, P, I, P, P]),
 }
 
 

@@ -19,6 +19,7 @@ SOURCES = {
     "fps.hip": [],
     "knn.hip": [],
     "encoder_ops.hip": [],
+    "gemm.hip": [],
     "decoder_ops.hip": [],
     "infomat.hip": [],
 }

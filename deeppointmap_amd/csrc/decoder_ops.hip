@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void posemb_kernel(const float *__restrict__ x
 // independent online softmax over its keys, merged across the 16 key-lanes at the end.
 // ------------------------------------------------------------------------------------------
 constexpr int HD = 32;
+constexpr int RES_HDR = 20;  // floats before the inlier-confidence list in a Kabsch `result`
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
                                                         const float *__restrict__ Kp, int ldk, long long sk,
                                                         const float *__restrict__ V, int ldv, long long sv,
@@ -126,8 +127,9 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
 
 __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict__ S, int M, int N, float itau,
                                                         float *__restrict__ cmax, float *__restrict__ csum) {
-    // 64 columns per block, 4 row-groups; coalesced along columns
+    // 64 columns per block, 4 row-groups; coalesced along columns; blockIdx.y = batch element
     __shared__ float sm[4][64], ss[4][64];
+    S += (size_t)blockIdx.y * M * N, cmax += (size_t)blockIdx.y * N, csum += (size_t)blockIdx.y * N;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     float mx = -__builtin_inff(), sum = 0.f;
     if (c < N) {
@@ -148,16 +150,19 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void dual_softmax_kernel(float *__restrict__ S, int M, int N, float itau,
+__global__ __launch_bounds__(256) void dual_softmax_kernel(float *__restrict__ S, long long total, int M, int N, float itau,
                                                            const float *__restrict__ rmax,
                                                            const float *__restrict__ rsum,
                                                            const float *__restrict__ cmax,
                                                            const float *__restrict__ csum) {
+    // M here is the number of rows of ONE batch element; r runs over all batch*M rows
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)M * N) return;
-    const int r = (int)(e / N), c = (int)(e - (long long)r * N);
+    if (e >= total) return;
+    const long long r = e / N;
+    const int c = (int)(e - r * N);
+    const size_t cb = (size_t)(r / M) * N + c;
     const float x = S[e] * itau;
-    S[e] = (expf(x - rmax[r]) / rsum[r]) * (expf(x - cmax[c]) / csum[c]);
+    S[e] = (expf(x - rmax[r]) / rsum[r]) * (expf(x - cmax[cb]) / csum[cb]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float *__restric
     __shared__ float sv[TK_MAXK];
     __shared__ int si[TK_MAXK];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    P += (size_t)blockIdx.x * n, out_v += (size_t)blockIdx.x * k, out_i += (size_t)blockIdx.x * k;  // batch element
     if (t == 0) s_prefix = 0u, s_mask = 0u, s_krem = (unsigned)k;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
@@ -261,10 +267,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float *__restric
 // a14 gather: flat top-k index -> (src row, dst row); X[0:k] = [x[si] | y[di]], X[k:2k] = [y[di] | x[si]]
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_pairs_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                                                           const int32_t *__restrict__ flat, int k, int N, int E,
+                                                           const int32_t *__restrict__ flat, int k, int M, int N, int E,
                                                            float *__restrict__ X, int32_t *__restrict__ si_out,
                                                            int32_t *__restrict__ di_out) {
-    const int p = blockIdx.x, t = threadIdx.x;
+    const int p = blockIdx.x, t = threadIdx.x, bz = blockIdx.y;
+    x += (size_t)bz * M * E, y += (size_t)bz * N * E, flat += (size_t)bz * k;
+    X += (size_t)bz * 2 * k * 2 * E, si_out += (size_t)bz * k, di_out += (size_t)bz * k;
     const int f = flat[p];
     const int si = f / N, di = f - si * N;
     if (t == 0) si_out[p] = si, di_out[p] = di;
@@ -294,7 +302,6 @@ __global__ __launch_bounds__(256) void mean_rows_kernel(const float *__restrict_
 // a14 + a15: correspondence sets and the iterative weighted Kabsch (decoder.py:202-265)
 // ------------------------------------------------------------------------------------------
 constexpr int KB = 256;  // threads
-constexpr int RES_HDR = 20;  // floats before the inlier-confidence list in `result`
 
 template <typename T>
 __device__ T block_sum(T v, T *scratch /* KB/64 entries */) {
@@ -370,11 +377,20 @@ __device__ void rot_from_cov(const double A[9], double Rm[9]) {
 // [20 : 20+n_inlier] confidences of the inliers (in correspondence order).  `header` (optional) receives a
 // copy of the first 20 floats (lets the caller assemble an edge table without extra kernels).
 __global__ __launch_bounds__(KB) void corr_kabsch_kernel(
-    const float *__restrict__ off /* (2k,3) */, const float *__restrict__ sxyz, int lds_,
-    const float *__restrict__ dxyz, int ldd, const int32_t *__restrict__ si, const int32_t *__restrict__ di,
-    const float *__restrict__ conf, int k, float eps2, int num_iter, float std_ratio,
-    float *__restrict__ ws /* 7*2k floats + 2*2k ints */, float *__restrict__ result,
-    float *__restrict__ header) {
+    const float *__restrict__ off /* (2k,3) */, const float *__restrict__ sxyz, int lds_, long long ssrc,
+    const float *__restrict__ dxyz, int ldd, long long sdst, const int32_t *__restrict__ si,
+    const int32_t *__restrict__ di, const float *__restrict__ conf, int k, float eps2, int num_iter, float std_ratio,
+    float *__restrict__ ws /* per batch element: 7*2k floats + 2*2k ints */, float *__restrict__ result,
+    float *__restrict__ header, int header_stride) {
+    {  // batch element = blockIdx.x
+        const size_t bz = blockIdx.x;
+        if (off) off += bz * 2 * k * 3;
+        sxyz += bz * ssrc, dxyz += bz * sdst, conf += bz * k;
+        if (si) si += bz * k, di += bz * k;
+        ws += bz * (size_t)(2 * k) * 9;
+        result += bz * (size_t)(RES_HDR + 2 * k);
+        if (header) header += bz * (size_t)header_stride;
+    }
     __shared__ int s_cnt[KB / 64];
     __shared__ int s_run;
     __shared__ float s_f[KB / 64];
@@ -615,29 +631,33 @@ extern "C" int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_st
     return dpm_launch_status();
 }
 
-extern "C" size_t dpm_pairing_workspace_bytes(int M, int N) { return sizeof(float) * 2 * ((size_t)M + (size_t)N) + 256; }
+extern "C" size_t dpm_pairing_workspace_bytes(int batch, int M, int N) {
+    return sizeof(float) * 2 * (size_t)batch * ((size_t)M + (size_t)N) + 256;
+}
 
-extern "C" int dpm_dual_softmax_topk(float *S, int M, int N, double tau, int k, float *out_val, int32_t *out_idx,
-                                     void *workspace, dpm_stream_t stream) {
-    DPM_CHECK_ARG(S && out_val && out_idx && workspace && M >= 1 && N >= 1 && tau > 0.0);
+extern "C" int dpm_dual_softmax_topk(float *S, int batch, int M, int N, double tau, int k, float *out_val,
+                                     int32_t *out_idx, void *workspace, dpm_stream_t stream) {
+    DPM_CHECK_ARG(S && out_val && out_idx && workspace && batch >= 1 && M >= 1 && N >= 1 && tau > 0.0);
     DPM_CHECK_ARG(k >= 1 && (long long)k <= (long long)M * N);
     if (k > TK_MAXK || (long long)M * N > 0x7fffffffLL) return DPM_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    float *rmax = (float *)workspace, *rsum = rmax + M, *cmax = rsum + M, *csum = cmax + N;
+    const size_t BM = (size_t)batch * M, BN = (size_t)batch * N;
+    float *rmax = (float *)workspace, *rsum = rmax + BM, *cmax = rsum + BM, *csum = cmax + BN;
     const float itau = 1.0f / (float)tau;  // torch divides by the scalar as a multiplication by 1/tau
-    hipLaunchKernelGGL(row_stats_kernel, dim3(dpm_cdiv(M, 4)), dim3(256), 0, st, S, M, N, itau, rmax, rsum);
-    hipLaunchKernelGGL(col_stats_kernel, dim3(dpm_cdiv(N, 64)), dim3(256), 0, st, S, M, N, itau, cmax, csum);
-    hipLaunchKernelGGL(dual_softmax_kernel, dim3(dpm_cdiv((long long)M * N, 256)), dim3(256), 0, st, S, M, N, itau, rmax,
+    const long long total = (long long)batch * M * N;
+    hipLaunchKernelGGL(row_stats_kernel, dim3(dpm_cdiv((long long)BM, 4)), dim3(256), 0, st, S, (int)BM, N, itau, rmax, rsum);
+    hipLaunchKernelGGL(col_stats_kernel, dim3(dpm_cdiv(N, 64), batch), dim3(256), 0, st, S, M, N, itau, cmax, csum);
+    hipLaunchKernelGGL(dual_softmax_kernel, dim3(dpm_cdiv(total, 256)), dim3(256), 0, st, S, total, M, N, itau, rmax,
                        rsum, cmax, csum);
-    hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(TK_THREADS), 0, st, S, (long long)M * N, k, out_val, out_idx);
+    hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(TK_THREADS), 0, st, S, (long long)M * N, k, out_val, out_idx);
     return dpm_launch_status();
 }
 
-extern "C" int dpm_gather_pairs(const float *x, const float *y, const int32_t *flat_idx, int k, int N, int E,
-                                float *X, int32_t *src_idx, int32_t *dst_idx, dpm_stream_t stream) {
-    DPM_CHECK_ARG(x && y && flat_idx && X && src_idx && dst_idx && k >= 1 && N >= 1 && E >= 1);
-    hipLaunchKernelGGL(gather_pairs_kernel, dim3(k), dim3(256), 0, (hipStream_t)stream, x, y, flat_idx, k, N, E, X,
-                       src_idx, dst_idx);
+extern "C" int dpm_gather_pairs(const float *x, const float *y, const int32_t *flat_idx, int batch, int k, int M, int N,
+                                int E, float *X, int32_t *src_idx, int32_t *dst_idx, dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && y && flat_idx && X && src_idx && dst_idx && batch >= 1 && k >= 1 && M >= 1 && N >= 1 && E >= 1);
+    hipLaunchKernelGGL(gather_pairs_kernel, dim3(k, batch), dim3(256), 0, (hipStream_t)stream, x, y, flat_idx, k, M, N, E,
+                       X, src_idx, dst_idx);
     return dpm_launch_status();
 }
 
@@ -647,17 +667,21 @@ extern "C" int dpm_mean_rows(const float *x, int B, int R, int C, float *out, in
     return dpm_launch_status();
 }
 
-extern "C" size_t dpm_kabsch_workspace_bytes(int k) { return (size_t)(2 * k) * (7 * sizeof(float) + 2 * sizeof(int32_t)) + 256; }
+extern "C" size_t dpm_kabsch_workspace_bytes(int batch, int k) {
+    return (size_t)batch * (size_t)(2 * k) * 9 * sizeof(float) + 256;
+}
 
-extern "C" int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, const float *dst_xyz, int ld_dst,
-                               const int32_t *src_idx, const int32_t *dst_idx, const float *conf, int k, double eps_offset,
+extern "C" int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, long long stride_src,
+                               const float *dst_xyz, int ld_dst, long long stride_dst, const int32_t *src_idx,
+                               const int32_t *dst_idx, const float *conf, int batch, int k, double eps_offset,
                                int num_iter, double std_ratio, void *workspace, float *result, float *header,
-                               dpm_stream_t stream) {
-    DPM_CHECK_ARG(src_xyz && dst_xyz && conf && workspace && result);
+                               int header_stride, dpm_stream_t stream) {
+    DPM_CHECK_ARG(src_xyz && dst_xyz && conf && workspace && result && batch >= 1);
     DPM_CHECK_ARG(!offsets || (src_idx && dst_idx));
-    DPM_CHECK_ARG(k >= 1 && ld_src >= 3 && ld_dst >= 3 && num_iter >= 1);
-    hipLaunchKernelGGL(corr_kabsch_kernel, dim3(1), dim3(KB), 0, (hipStream_t)stream, offsets, src_xyz, ld_src, dst_xyz,
-                       ld_dst, src_idx, dst_idx, conf, k, (float)(eps_offset * eps_offset), num_iter, (float)std_ratio,
-                       (float *)workspace, result, header);
+    DPM_CHECK_ARG(k >= 1 && ld_src >= 3 && ld_dst >= 3 && num_iter >= 1 && (!header || header_stride >= RES_HDR));
+    hipLaunchKernelGGL(corr_kabsch_kernel, dim3(batch), dim3(KB), 0, (hipStream_t)stream, offsets, src_xyz, ld_src,
+                       stride_src, dst_xyz, ld_dst, stride_dst, src_idx, dst_idx, conf, k,
+                       (float)(eps_offset * eps_offset), num_iter, (float)std_ratio, (float *)workspace, result, header,
+                       header_stride);
     return dpm_launch_status();
 }

@@ -105,61 +105,10 @@ __global__ __launch_bounds__(256) void group_mlp_max_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// out = act(x W^T + bias + residual): 64x64 tile, 4x4 per thread, K-step 16 through LDS.
-// ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == DPM_ACT_RELU) return fmaxf(v, 0.f);
     if (act == DPM_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
     return v;
-}
-
-__global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ X, int ldx,
-                                                     const float *__restrict__ W, int ldw,
-                                                     const float *__restrict__ bias,
-                                                     const float *__restrict__ res, int ldr,
-                                                     float *__restrict__ out, int ldo, int R, int Cin, int Cout,
-                                                     int act) {
-    __shared__ float Xs[16][68];
-    __shared__ float Ws[16][68];
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
-    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
-    float acc[4][4] = {};
-    const int lr = t >> 2, lk = (t & 3) * 4;  // loader: row lr (0..63), k offset lk (0,4,8,12)
-    for (int k0 = 0; k0 < Cin; k0 += 16) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + lk + q;
-            const int xr = row0 + lr, wr = col0 + lr;
-            Xs[lk + q][lr] = (xr < R && k < Cin) ? X[(size_t)xr * ldx + k] : 0.f;
-            Ws[lk + q][lr] = (wr < Cout && k < Cin) ? W[(size_t)wr * ldw + k] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float4 a = *reinterpret_cast<const float4 *>(&Xs[k][ty * 4]);
-            const float4 bq = *reinterpret_cast<const float4 *>(&Ws[k][tx * 4]);
-            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = row0 + ty * 4 + i;
-        if (r >= R) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = col0 + tx * 4 + j;
-            if (c >= Cout) continue;
-            float v = acc[i][j];
-            if (bias) v += bias[c];
-            if (res) v += res[(size_t)r * ldr + c];
-            out[(size_t)r * ldo + c] = apply_act(v, act);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -276,16 +225,6 @@ extern "C" int dpm_group_mlp_max(const float *xyz, const float *fea, const float
     }
     hipLaunchKernelGGL(group_mlp_max_kernel, dim3(S, B), dim3(256), lds, (hipStream_t)stream, xyz, fea, centers, idx,
                        Wt, bias, gamma, beta, N, S, K, Cin, Cout, 1.0f / (float)radius, out);
-    return dpm_launch_status();
-}
-
-extern "C" int dpm_linear(const float *x, int ldx, const float *W, int ldw, const float *bias, const float *residual,
-                          int ldr, float *out, int ldo, int R, int Cin, int Cout, int act, dpm_stream_t stream) {
-    DPM_CHECK_ARG(x && W && out && R >= 1 && Cin >= 1 && Cout >= 1);
-    DPM_CHECK_ARG(ldx >= Cin && ldw >= Cin && ldo >= Cout && (!residual || ldr >= Cout));
-    DPM_CHECK_ARG(act >= DPM_ACT_NONE && act <= DPM_ACT_SIGMOID);
-    hipLaunchKernelGGL(linear_kernel, dim3(dpm_cdiv(Cout, 64), dpm_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, x,
-                       ldx, W, ldw, bias, residual, ldr, out, ldo, R, Cin, Cout, act);
     return dpm_launch_status();
 }
 

@@ -15,16 +15,49 @@ namespace {
 
 constexpr int GMAX = 512;  // grid cells per axis (upper bound)
 
-struct GridHdr {       // lives at the start of the workspace
+// Batched operation: pair p reads its clouds from pcd1 + f1[p]*stride / pcd2 + f2[p]*stride (f1/f2 NULL: the
+// pair index itself), its pose from Rt + p*rt_stride, and owns workspace slice p.
+struct PairArgs {
+    const float *pcd1, *pcd2;
+    const int32_t *f1, *f2;
+    long long stride1, stride2;  // floats between consecutive frames
+    const float *Rt;
+    int rt_stride;
+    float *out;
+    int out_stride;
+    char *ws;
+    size_t ws_stride;
+    int N1, N2;
+};
+
+struct GridHdr {       // lives at the start of each workspace slice
     float lox, loy, inv_cs;
     int gx, gy, ncell;
     int pad[2];
     double sums[10];
 };
 
-__global__ __launch_bounds__(1024) void grid_setup_kernel(const float *__restrict__ p2, int N2, float radius,
-                                                          GridHdr *__restrict__ hdr, int *__restrict__ count) {
+__device__ __forceinline__ const float *pair_p1(const PairArgs &a, int p) {
+    return a.pcd1 + (size_t)(a.f1 ? a.f1[p] : p) * a.stride1;
+}
+__device__ __forceinline__ const float *pair_p2(const PairArgs &a, int p) {
+    return a.pcd2 + (size_t)(a.f2 ? a.f2[p] : p) * a.stride2;
+}
+__device__ __forceinline__ GridHdr *pair_hdr(const PairArgs &a, int p) { return (GridHdr *)(a.ws + (size_t)p * a.ws_stride); }
+__device__ __forceinline__ int *pair_count(const PairArgs &a, int p) { return (int *)(a.ws + (size_t)p * a.ws_stride + 256); }
+__device__ __forceinline__ int *pair_cursor(const PairArgs &a, int p) { return pair_count(a, p) + (GMAX * GMAX + 1); }
+__device__ __forceinline__ float4 *pair_sorted(const PairArgs &a, int p) {
+    return (float4 *)(a.ws + (size_t)p * a.ws_stride + 256 + 2 * sizeof(int) * (size_t)(GMAX * GMAX + 1) + 8);
+}
+
+__global__ __launch_bounds__(1024) void grid_setup_kernel(PairArgs A, float radius) {
+    const int pair = blockIdx.x;
+    const float *p2 = pair_p2(A, pair);
+    const int N2 = A.N2;
+    GridHdr *hdr = pair_hdr(A, pair);
+    int *count = pair_count(A, pair);
     __shared__ float red[4][16];
+    __shared__ int s_ncell;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     float lox = __builtin_inff(), loy = lox, hix = -lox, hiy = -lox;
     for (int i = t; i < N2; i += 1024) {
@@ -49,17 +82,23 @@ __global__ __launch_bounds__(1024) void grid_setup_kernel(const float *__restric
         hdr->gx = min(GMAX, (int)((hix - lox) / cs) + 1);
         hdr->gy = min(GMAX, (int)((hiy - loy) / cs) + 1);
         hdr->ncell = hdr->gx * hdr->gy;
+        s_ncell = hdr->ncell;
         for (int k = 0; k < 10; ++k) hdr->sums[k] = 0.0;
     }
-    for (int c = t; c <= GMAX * GMAX; c += 1024) count[c] = 0;
+    __syncthreads();
+    for (int c = t; c <= s_ncell; c += 1024) count[c] = 0;
 }
 
 __device__ __forceinline__ int cell_coord(float v, float lo, float inv_cs, int g) {
     return min(max((int)floorf((v - lo) * inv_cs), 0), g - 1);
 }
 
-__global__ __launch_bounds__(256) void grid_count_kernel(const float *__restrict__ p2, int N2,
-                                                         const GridHdr *__restrict__ hdr, int *__restrict__ count) {
+__global__ __launch_bounds__(256) void grid_count_kernel(PairArgs A) {
+    const int pair = blockIdx.y;
+    const float *p2 = pair_p2(A, pair);
+    const int N2 = A.N2;
+    const GridHdr *hdr = pair_hdr(A, pair);
+    int *count = pair_count(A, pair);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N2) return;
     const int cx = cell_coord(p2[i], hdr->lox, hdr->inv_cs, hdr->gx);
@@ -68,8 +107,9 @@ __global__ __launch_bounds__(256) void grid_count_kernel(const float *__restrict
 }
 
 // exclusive scan of count[0..ncell) in place -> cell start offsets; cursor = copy for the scatter
-__global__ __launch_bounds__(1024) void grid_scan_kernel(const GridHdr *__restrict__ hdr, int *__restrict__ count,
-                                                         int *__restrict__ cursor) {
+__global__ __launch_bounds__(1024) void grid_scan_kernel(PairArgs A) {
+    const GridHdr *hdr = pair_hdr(A, blockIdx.x);
+    int *count = pair_count(A, blockIdx.x), *cursor = pair_cursor(A, blockIdx.x);
     __shared__ int wsum[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int ncell = hdr->ncell;
@@ -96,9 +136,13 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(const GridHdr *__restri
     if (t == 1023) count[ncell] = run;  // == N2
 }
 
-__global__ __launch_bounds__(256) void grid_scatter_kernel(const float *__restrict__ p2, int N2,
-                                                           const GridHdr *__restrict__ hdr, int *__restrict__ cursor,
-                                                           float4 *__restrict__ sorted) {
+__global__ __launch_bounds__(256) void grid_scatter_kernel(PairArgs A) {
+    const int pair = blockIdx.y;
+    const float *p2 = pair_p2(A, pair);
+    const int N2 = A.N2;
+    const GridHdr *hdr = pair_hdr(A, pair);
+    int *cursor = pair_cursor(A, pair);
+    float4 *sorted = pair_sorted(A, pair);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N2) return;
     const float x = p2[i], y = p2[(size_t)N2 + i], z = p2[2 * (size_t)N2 + i];
@@ -108,10 +152,14 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float *__restri
     sorted[pos] = make_float4(x, y, z, __int_as_float(i));
 }
 
-__global__ __launch_bounds__(256) void nn1_moments_kernel(const float *__restrict__ p1, int N1,
-                                                          const float *__restrict__ Rt /* 12: R row-major, T */,
-                                                          GridHdr *__restrict__ hdr, const int *__restrict__ start,
-                                                          const float4 *__restrict__ sorted, float r2) {
+__global__ __launch_bounds__(256) void nn1_moments_kernel(PairArgs A, float r2) {
+    const int pair = blockIdx.y;
+    const float *p1 = pair_p1(A, pair);
+    const int N1 = A.N1;
+    const float *Rt = A.Rt + (size_t)pair * A.rt_stride;  // 12 floats: R row-major, T
+    GridHdr *hdr = pair_hdr(A, pair);
+    const int *start = pair_count(A, pair);
+    const float4 *sorted = pair_sorted(A, pair);
     __shared__ double sred[4][10];
     const int i = blockIdx.x * 256 + threadIdx.x;
     double m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -158,8 +206,10 @@ __global__ __launch_bounds__(256) void nn1_moments_kernel(const float *__restric
     }
 }
 
-__global__ void infomat_finalize_kernel(const GridHdr *__restrict__ hdr, float *__restrict__ out) {
+__global__ void infomat_finalize_kernel(PairArgs A) {
     if (threadIdx.x != 0) return;
+    const GridHdr *hdr = pair_hdr(A, blockIdx.x);
+    float *out = A.out + (size_t)blockIdx.x * A.out_stride;
     const double *s = hdr->sums;
     const double n = s[0], x = s[1], y = s[2], z = s[3], xx = s[4], yy = s[5], zz = s[6], xy = s[7], xz = s[8],
                  yz = s[9];
@@ -174,26 +224,48 @@ __global__ void infomat_finalize_kernel(const GridHdr *__restrict__ hdr, float *
 
 }  // namespace
 
-extern "C" size_t dpm_infomat_workspace_bytes(int N1, int N2) {
+static size_t ws_slice_bytes(int N2) {
+    size_t b = 256 + 2 * sizeof(int) * (size_t)(GMAX * GMAX + 1) + 8 + sizeof(float4) * (size_t)N2;
+    return (b + 255) & ~(size_t)255;
+}
+
+extern "C" size_t dpm_infomat_workspace_bytes(int n_pairs, int N1, int N2) {
     (void)N1;
-    return 1024 + 2 * sizeof(int) * (size_t)(GMAX * GMAX + 1) + sizeof(float4) * (size_t)N2;
+    return 256 + (size_t)n_pairs * ws_slice_bytes(N2);
+}
+
+static int launch_infomat(PairArgs A, int n_pairs, double radius, hipStream_t st) {
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(n_pairs), dim3(1024), 0, st, A, (float)radius);
+    hipLaunchKernelGGL(grid_count_kernel, dim3(dpm_cdiv(A.N2, 256), n_pairs), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(n_pairs), dim3(1024), 0, st, A);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(dpm_cdiv(A.N2, 256), n_pairs), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(nn1_moments_kernel, dim3(dpm_cdiv(A.N1, 256), n_pairs), dim3(256), 0, st, A,
+                       (float)(radius * radius));
+    hipLaunchKernelGGL(infomat_finalize_kernel, dim3(n_pairs), dim3(64), 0, st, A);
+    return dpm_launch_status();
 }
 
 extern "C" int dpm_information_matrix(const float *pcd1, int N1, const float *pcd2, int N2, const float *Rt,
                                       double radius, float *out6x6, void *workspace, dpm_stream_t stream) {
     DPM_CHECK_ARG(pcd1 && pcd2 && Rt && out6x6 && workspace && N1 >= 1 && N2 >= 1 && radius > 0.0);
-    hipStream_t st = (hipStream_t)stream;
-    uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
-    GridHdr *hdr = (GridHdr *)p;
-    int *count = (int *)(p + 256);
-    int *cursor = count + (GMAX * GMAX + 1);
-    float4 *sorted = (float4 *)(((uintptr_t)(cursor + (GMAX * GMAX + 1)) + 255) & ~(uintptr_t)255);
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1024), 0, st, pcd2, N2, (float)radius, hdr, count);
-    hipLaunchKernelGGL(grid_count_kernel, dim3(dpm_cdiv(N2, 256)), dim3(256), 0, st, pcd2, N2, hdr, count);
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, st, hdr, count, cursor);
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3(dpm_cdiv(N2, 256)), dim3(256), 0, st, pcd2, N2, hdr, cursor, sorted);
-    hipLaunchKernelGGL(nn1_moments_kernel, dim3(dpm_cdiv(N1, 256)), dim3(256), 0, st, pcd1, N1, Rt, hdr, count, sorted,
-                       (float)(radius * radius));
-    hipLaunchKernelGGL(infomat_finalize_kernel, dim3(1), dim3(64), 0, st, hdr, out6x6);
-    return dpm_launch_status();
+    PairArgs A{};
+    A.pcd1 = pcd1, A.pcd2 = pcd2, A.f1 = nullptr, A.f2 = nullptr, A.stride1 = 0, A.stride2 = 0;
+    A.Rt = Rt, A.rt_stride = 0, A.out = out6x6, A.out_stride = 0;
+    A.ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), A.ws_stride = ws_slice_bytes(N2);
+    A.N1 = N1, A.N2 = N2;
+    return launch_infomat(A, 1, radius, (hipStream_t)stream);
+}
+
+extern "C" int dpm_information_matrix_batched(const float *pcd, int N, const int32_t *src_frame,
+                                              const int32_t *dst_frame, int n_pairs, const float *Rt, int rt_stride,
+                                              double radius, float *out, int out_stride, void *workspace,
+                                              dpm_stream_t stream) {
+    DPM_CHECK_ARG(pcd && src_frame && dst_frame && Rt && out && workspace && N >= 1 && n_pairs >= 1 && radius > 0.0);
+    DPM_CHECK_ARG(rt_stride >= 12 && out_stride >= 36);
+    PairArgs A{};
+    A.pcd1 = pcd, A.pcd2 = pcd, A.f1 = src_frame, A.f2 = dst_frame, A.stride1 = 3LL * N, A.stride2 = 3LL * N;
+    A.Rt = Rt, A.rt_stride = rt_stride, A.out = out, A.out_stride = out_stride;
+    A.ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), A.ws_stride = ws_slice_bytes(N);
+    A.N1 = N, A.N2 = N;
+    return launch_infomat(A, n_pairs, radius, (hipStream_t)stream);
 }

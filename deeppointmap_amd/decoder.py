@@ -130,6 +130,40 @@ class Decoder(ParamTree):
             raise ValueError(f"Argument `num_sample` with value {num_sample} is not supported")
         return k // 2
 
+    def _register(self, src_descriptor, dst_descriptor, num_sample, header_out=None, trace: dict = None):
+        """Batched core: (B,131,M), (B,131,N) -> result (B, 20+2k) on the device, nothing synchronises.
+        Pairs are independent, so every kernel runs all B of them at once."""
+        x, xyz_s, y, xyz_d, B, M, N = self._descriptor_attention_forward(src_descriptor, dst_descriptor)
+        E = self.model_channel
+        k = self._num_pairs(num_sample, M, N)
+        # similarity head -> L2 normalise -> M x N similarity -> dual softmax -> top-k   (decoder.py:181-191)
+        a = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", x, ops.ACT_RELU)))
+        b = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", y, ops.ACT_RELU)))
+        S = ops.similarity_batched(a.view(B, M, E), b.view(B, N, E))
+        conf, flat = ops.dual_softmax_topk(S, self.tau, k)
+        # offset head on both pair directions                                           (decoder.py:204-207)
+        X, si, di = ops.gather_pairs(x.view(B, M, E), y.view(B, N, E), flat)
+        X = X.view(B * 2 * k, 2 * E)
+        h = self._lin("offset_head.mlp.2", self._lin("offset_head.mlp.0", X, ops.ACT_RELU), ops.ACT_RELU)
+        h = self._lin("offset_head.mlp.4", h, ops.ACT_RELU, residual=self._lin("offset_head.downsample", X))
+        off = self._lin("offset_head.head", h)
+        res = ops.corr_kabsch(off, xyz_s, xyz_d, si, di, conf, self.args.loss.eps_offset, header_out=header_out, batch=B)
+        if trace is not None:
+            trace.update(x=x, y=y, conf=conf, flat=flat, src_index=si, dst_index=di, offsets=off)
+        return res.view(B, -1)
+
+    @torch.no_grad()
+    def registration_forward_batch(self, src_descriptor: torch.Tensor, dst_descriptor: torch.Tensor,
+                                   num_sample: Union[int, float] = 0.5, header_out: torch.Tensor = None) -> torch.Tensor:
+        """B independent pairs in one pass (not in the reference API; used by the frame-sharded hot path).
+        -> result (B, 20+2k) on the device: per pair R(9) T(3) rmse n_corr n_inlier iters conf30 ..., then the
+        inlier confidences.  No host synchronisation."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("deeppointmap_amd.Decoder runs on the GPU only (there is no CPU fallback)")
+        with torch.cuda.device(dev):
+            return self._register(src_descriptor, dst_descriptor, num_sample, header_out)
+
     @torch.no_grad()
     def registration_forward(self, src_descriptor: torch.Tensor, dst_descriptor: torch.Tensor,
                              src_padding_mask=None, dst_padding_mask=None,
@@ -137,31 +171,20 @@ class Decoder(ParamTree):
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("deeppointmap_amd.Decoder runs on the GPU only (there is no CPU fallback)")
+        if src_padding_mask is not None or dst_padding_mask is not None:
+            raise NotImplementedError("padding masks are not used by any inference call site of the reference "
+                                      "and are not implemented")
         batch = not (src_descriptor.ndim == 2 and dst_descriptor.ndim == 2)
         if not batch:
             src_descriptor, dst_descriptor = src_descriptor.unsqueeze(0), dst_descriptor.unsqueeze(0)
+        assert src_descriptor.shape[0] == 1, "batch size in inference must be 1"
         with torch.cuda.device(dev):
-            x, xyz_s, y, xyz_d, B, M, N = self._descriptor_attention_forward(src_descriptor, dst_descriptor,
-                                                                             src_padding_mask, dst_padding_mask)
-            assert B == 1, "batch size in inference must be 1"
-            k = self._num_pairs(num_sample, M, N)
-            # similarity head -> L2 normalise -> M x N similarity -> dual softmax -> top-k   (decoder.py:181-191)
-            a = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", x, ops.ACT_RELU)))
-            b = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", y, ops.ACT_RELU)))
-            S = ops.linear(a, b)
-            conf, flat = ops.dual_softmax_topk(S, self.tau, k)
-            # offset head on both pair directions                                           (decoder.py:204-207)
-            X, si, di = ops.gather_pairs(x, y, flat)
-            h = self._lin("offset_head.mlp.2", self._lin("offset_head.mlp.0", X, ops.ACT_RELU), ops.ACT_RELU)
-            h = self._lin("offset_head.mlp.4", h, ops.ACT_RELU, residual=self._lin("offset_head.downsample", X))
-            off = self._lin("offset_head.head", h)
-            res = ops.corr_kabsch(off, xyz_s, xyz_d, si, di, conf, self.args.loss.eps_offset, header_out=header_out)
+            res = self._register(src_descriptor, dst_descriptor, num_sample, header_out, trace)[0]
             head = res[:ops.RES_HDR].cpu()  # the one host sync of the call: rmse is a python float in the contract
         n_in, rmse = int(head[14]), float(head[12])
         R, T, cf = res[0:9].view(3, 3), res[9:12].view(3, 1), res[ops.RES_HDR:ops.RES_HDR + n_in]
         if trace is not None:
-            trace.update(x=x, y=y, conf=conf, flat=flat, src_index=si, dst_index=di, offsets=off,
-                         n_corr=int(head[13]), iterations=int(head[15]))
+            trace.update(n_corr=int(head[13]), iterations=int(head[15]))
         if not batch:
             return R, T, cf, rmse
         return R.unsqueeze(0), T.unsqueeze(0), cf.unsqueeze(0), [rmse]

@@ -129,6 +129,17 @@ def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def similarity_batched(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a (B,M,C), b (B,N,C) contiguous -> S (B,M,N) with S[p] = a[p] @ b[p]^T (fp32 MFMA)."""
+    _chk(a, torch.float32, "a"), _chk(b, torch.float32, "b")
+    B, M, C = a.shape
+    N = b.shape[1]
+    out = torch.empty(B, M, N, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().dpm_linear_batched(_ptr(a), C, M * C, _ptr(b), C, N * C, None, None, 0, 0, _ptr(out), N,
+                                              M * N, B, M, C, N, ACT_NONE, _stream(a)), "dpm_linear_batched")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int = ACT_NONE,
               pre: Optional[torch.Tensor] = None, post: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = act(LN(x + pre) * gamma + beta + post) over the last dimension."""
@@ -199,28 +210,33 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
 
 
 def dual_softmax_topk(S: torch.Tensor, tau: float, k: int):
-    """S (M,N) similarity (overwritten with the dual-softmax matrix) -> (values (k,), flat idx (k,) int32)."""
+    """S (M,N) or (B,M,N) similarity (overwritten with the dual-softmax matrix) ->
+    (values (k,) / (B,k), flat idx int32 of the same shape), each row sorted descending."""
     _chk(S, torch.float32, "S")
-    M, N = S.shape
+    single = S.dim() == 2
+    B = 1 if single else S.shape[0]
+    M, N = S.shape[-2], S.shape[-1]
     lib = _lib.load()
-    val = torch.empty(k, device=S.device, dtype=torch.float32)
-    idx = torch.empty(k, device=S.device, dtype=torch.int32)
-    ws = torch.empty(lib.dpm_pairing_workspace_bytes(M, N), device=S.device, dtype=torch.uint8)
-    _lib.check(lib.dpm_dual_softmax_topk(_ptr(S), M, N, float(tau), k, _ptr(val), _ptr(idx), _ptr(ws), _stream(S)),
+    val = torch.empty(B, k, device=S.device, dtype=torch.float32)
+    idx = torch.empty(B, k, device=S.device, dtype=torch.int32)
+    ws = torch.empty(lib.dpm_pairing_workspace_bytes(B, M, N), device=S.device, dtype=torch.uint8)
+    _lib.check(lib.dpm_dual_softmax_topk(_ptr(S), B, M, N, float(tau), k, _ptr(val), _ptr(idx), _ptr(ws), _stream(S)),
                "dpm_dual_softmax_topk")
-    return val, idx
+    return (val[0], idx[0]) if single else (val, idx)
 
 
 def gather_pairs(x: torch.Tensor, y: torch.Tensor, flat: torch.Tensor):
-    """x (M,E), y (N,E), flat (k,) -> X (2k,2E), src_idx (k,), dst_idx (k,)."""
+    """x (B,M,E), y (B,N,E), flat (B,k) -> X (B,2k,2E), src_idx (B,k), dst_idx (B,k)   (2-D inputs: B = 1, 2-D outputs)."""
     _chk(x, torch.float32, "x"), _chk(y, torch.float32, "y"), _chk(flat, torch.int32, "flat")
-    k, E, N = flat.numel(), x.shape[1], y.shape[0]
-    X = torch.empty(2 * k, 2 * E, device=x.device, dtype=torch.float32)
-    si = torch.empty(k, device=x.device, dtype=torch.int32)
-    di = torch.empty(k, device=x.device, dtype=torch.int32)
-    _lib.check(_lib.load().dpm_gather_pairs(_ptr(x), _ptr(y), _ptr(flat), k, N, E, _ptr(X), _ptr(si), _ptr(di),
+    single = x.dim() == 2
+    B = 1 if single else x.shape[0]
+    M, E, N, k = x.shape[-2], x.shape[-1], y.shape[-2], flat.shape[-1]
+    X = torch.empty(B, 2 * k, 2 * E, device=x.device, dtype=torch.float32)
+    si = torch.empty(B, k, device=x.device, dtype=torch.int32)
+    di = torch.empty(B, k, device=x.device, dtype=torch.int32)
+    _lib.check(_lib.load().dpm_gather_pairs(_ptr(x), _ptr(y), _ptr(flat), B, k, M, N, E, _ptr(X), _ptr(si), _ptr(di),
                                             _stream(x)), "dpm_gather_pairs")
-    return X, si, di
+    return (X[0], si[0], di[0]) if single else (X, si, di)
 
 
 def mean_rows(x: torch.Tensor, out: torch.Tensor) -> None:
@@ -235,25 +251,33 @@ RES_HDR = 20  # floats before the inlier-confidence list in a corr_kabsch result
 
 
 def corr_kabsch(offsets, src_xyz, dst_xyz, src_idx, dst_idx, conf, eps_offset: float, num_iter: int = 3,
-                std_ratio: float = 3.0, header_out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """-> result (20 + 2k,) fp32: R(9) T(3) rmse n_corr n_inlier iters conf30 (3 reserved), then the inlier
-    confidences.  header_out: optional contiguous (>=20,) fp32 view that also receives result[:20]."""
+                std_ratio: float = 3.0, header_out: Optional[torch.Tensor] = None, batch: int = 1) -> torch.Tensor:
+    """-> result (batch, 20 + 2k) fp32 (1-D when batch == 1 and conf is 1-D): R(9) T(3) rmse n_corr n_inlier iters
+    conf30 (3 reserved), then the inlier confidences.  src_xyz / dst_xyz: (batch*M, 3) row views (row stride
+    free) holding the batch elements back to back.  offsets None: (conf, src_xyz, dst_xyz) are ready-made
+    correspondences.  header_out: optional (batch, >=20) fp32 view (unit column stride) that also receives
+    result[:, :20]."""
     _chk(conf, torch.float32, "conf")
     _rows2d(src_xyz, "src_xyz"), _rows2d(dst_xyz, "dst_xyz")
-    if offsets is not None:  # None: (conf, src_xyz, dst_xyz) are ready-made correspondences
+    k = conf.shape[-1]
+    if offsets is not None:
         _chk(offsets, torch.float32, "offsets")
         _chk(src_idx, torch.int32, "src_idx"), _chk(dst_idx, torch.int32, "dst_idx")
-    k = conf.numel()
     lib = _lib.load()
-    ws = torch.empty(lib.dpm_kabsch_workspace_bytes(k), device=conf.device, dtype=torch.uint8)
-    result = torch.empty(RES_HDR + 2 * k, device=conf.device, dtype=torch.float32)
+    ws = torch.empty(lib.dpm_kabsch_workspace_bytes(batch, k), device=conf.device, dtype=torch.uint8)
+    result = torch.empty(batch, RES_HDR + 2 * k, device=conf.device, dtype=torch.float32)
+    hs = 0
     if header_out is not None:
-        _chk(header_out, torch.float32, "header_out")
-    _lib.check(lib.dpm_corr_kabsch(_ptr(offsets), _ptr(src_xyz), src_xyz.stride(0), _ptr(dst_xyz), dst_xyz.stride(0),
-                                   _ptr(src_idx), _ptr(dst_idx), _ptr(conf), k, float(eps_offset), num_iter,
-                                   float(std_ratio), _ptr(ws), _ptr(result), _ptr(header_out), _stream(conf)),
-               "dpm_corr_kabsch")
-    return result
+        if header_out.dim() == 1:
+            header_out = header_out.unsqueeze(0)
+        _rows2d(header_out, "header_out")
+        hs = header_out.stride(0)
+    Ms, Md = src_xyz.shape[0] // batch, dst_xyz.shape[0] // batch
+    _lib.check(lib.dpm_corr_kabsch(_ptr(offsets), _ptr(src_xyz), src_xyz.stride(0), Ms * src_xyz.stride(0),
+                                   _ptr(dst_xyz), dst_xyz.stride(0), Md * dst_xyz.stride(0), _ptr(src_idx),
+                                   _ptr(dst_idx), _ptr(conf), batch, k, float(eps_offset), num_iter, float(std_ratio),
+                                   _ptr(ws), _ptr(result), _ptr(header_out), hs, _stream(conf)), "dpm_corr_kabsch")
+    return result[0] if (batch == 1 and conf.dim() == 1) else result
 
 
 def information_matrix(pcd1: torch.Tensor, pcd2: torch.Tensor, Rt: torch.Tensor, radius: float = 1.0,
@@ -263,7 +287,7 @@ def information_matrix(pcd1: torch.Tensor, pcd2: torch.Tensor, Rt: torch.Tensor,
     _chk(pcd1, torch.float32, "pcd1"), _chk(pcd2, torch.float32, "pcd2"), _chk(Rt, torch.float32, "Rt")
     N1, N2 = pcd1.shape[1], pcd2.shape[1]
     lib = _lib.load()
-    ws = torch.empty(lib.dpm_infomat_workspace_bytes(N1, N2), device=pcd1.device, dtype=torch.uint8)
+    ws = torch.empty(lib.dpm_infomat_workspace_bytes(1, N1, N2), device=pcd1.device, dtype=torch.uint8)
     if out is None:
         out = torch.empty(6, 6, device=pcd1.device, dtype=torch.float32)
     else:
@@ -271,3 +295,17 @@ def information_matrix(pcd1: torch.Tensor, pcd2: torch.Tensor, Rt: torch.Tensor,
     _lib.check(lib.dpm_information_matrix(_ptr(pcd1), N1, _ptr(pcd2), N2, _ptr(Rt), float(radius), _ptr(out),
                                           _ptr(ws), _stream(pcd1)), "dpm_information_matrix")
     return out
+
+
+def information_matrix_batched(pcd: torch.Tensor, src_frame: torch.Tensor, dst_frame: torch.Tensor, Rt_rows: torch.Tensor,
+                               out_rows: torch.Tensor, radius: float = 1.0) -> None:
+    """pcd (F,3,N) metres; pair p = (src_frame[p], dst_frame[p]) (int32 GPU tensors); Rt_rows (P, >=12) and
+    out_rows (P, >=36) are row views (unit column stride) -- typically columns of one edge table."""
+    _chk(pcd, torch.float32, "pcd"), _chk(src_frame, torch.int32, "src_frame"), _chk(dst_frame, torch.int32, "dst_frame")
+    _rows2d(Rt_rows, "Rt_rows"), _rows2d(out_rows, "out_rows")
+    P_, N = src_frame.numel(), pcd.shape[2]
+    lib = _lib.load()
+    ws = torch.empty(lib.dpm_infomat_workspace_bytes(P_, N, N), device=pcd.device, dtype=torch.uint8)
+    _lib.check(lib.dpm_information_matrix_batched(_ptr(pcd), N, _ptr(src_frame), _ptr(dst_frame), P_, _ptr(Rt_rows),
+                                                  Rt_rows.stride(0), float(radius), _ptr(out_rows), out_rows.stride(0),
+                                                  _ptr(ws), _stream(pcd)), "dpm_information_matrix_batched")

@@ -45,30 +45,38 @@ class HotPath:
         return make_descriptors(coor, fea, self.coor_scale)
 
     @torch.no_grad()
-    def register(self, desc: torch.Tensor, pcd_m: Optional[torch.Tensor], pairs, table: Optional[torch.Tensor] = None):
+    def register(self, desc: torch.Tensor, pcd_m: Optional[torch.Tensor], pairs, table: Optional[torch.Tensor] = None,
+                 materialize: bool = True):
         """desc (F,131,S); pcd_m (F,3,N) scans in metres (None: skip the information matrix);
-        pairs: list of (src_frame, dst_frame).  Returns (edges, table): table (E, EDGE_FLOATS) is filled on
-        the device by the kernels themselves (registration header | information matrix) -- it is what a
-        rank ships to rank 0."""
+        pairs: list of (src_frame, dst_frame).  All pairs are registered in ONE batched pass.
+        Returns (edges, table): table (E, EDGE_FLOATS) is filled on the device by the kernels themselves
+        (20-float registration header | 6x6 information) -- it is what a rank ships to rank 0.
+        materialize=False skips building Edge objects (no host synchronisation at all)."""
         pairs = list(pairs)
+        dev = desc.device
         if table is None:
-            table = torch.zeros(len(pairs), EDGE_FLOATS, device=desc.device, dtype=torch.float32)
+            table = torch.zeros(len(pairs), EDGE_FLOATS, device=dev, dtype=torch.float32)
+        sidx = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev)
+        didx = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev)
+        res = self.decoder.registration_forward_batch(desc.index_select(0, sidx.long()), desc.index_select(0, didx.long()),
+                                                      num_sample=self.num_sample, header_out=table[:, :ops.RES_HDR])
+        if pcd_m is not None:
+            ops.information_matrix_batched(pcd_m, sidx, didx, table[:, :12], table[:, ops.RES_HDR:])
         edges = []
-        for e, (s, d) in enumerate(pairs):
-            row = table[e]
-            R, T, conf, rmse = self.decoder.registration_forward(desc[s], desc[d], num_sample=self.num_sample,
-                                                                 header_out=row[:ops.RES_HDR])
-            info = None
-            if pcd_m is not None:
-                info = ops.information_matrix(pcd_m[s], pcd_m[d], row[:12], 1.0, out=row[ops.RES_HDR:]).view(6, 6)
-            edges.append(Edge(s, d, R, T, conf, rmse, info))
+        if materialize:
+            head = table[:, :ops.RES_HDR].cpu()
+            for e, (s, d) in enumerate(pairs):
+                n_in = int(head[e, 14])
+                info = table[e, ops.RES_HDR:].view(6, 6) if pcd_m is not None else None
+                edges.append(Edge(s, d, res[e, 0:9].view(3, 3), res[e, 9:12].view(3, 1),
+                                  res[e, ops.RES_HDR:ops.RES_HDR + n_in], float(head[e, 12]), info))
         return edges, table
 
     @torch.no_grad()
-    def step(self, points: torch.Tensor, padding: torch.Tensor, pcd_m: Optional[torch.Tensor]):
+    def step(self, points: torch.Tensor, padding: torch.Tensor, pcd_m: Optional[torch.Tensor], materialize: bool = True):
         """One batch: every frame is encoded and registered against its predecessor (frame 0 against
         the last frame of the batch, so a batch of F frames carries exactly F edges)."""
         desc = self.extract(points, padding)
         F = desc.shape[0]
-        edges, table = self.register(desc, pcd_m, [((f - 1) % F, f) for f in range(F)])
+        edges, table = self.register(desc, pcd_m, [((f - 1) % F, f) for f in range(F)], materialize=materialize)
         return desc, edges, table

@@ -86,6 +86,13 @@ int dpm_group_mlp_max(const float *xyz, const float *fea, const float *centers, 
 int dpm_linear(const float *x, int ldx, const float *W, int ldw, const float *bias,
                const float *residual, int ldr, float *out, int ldo, int R, int Cin, int Cout, int act,
                dpm_stream_t stream);
+/* same for `batch` independent problems: operand b lives at ptr + b*stride (strides in floats; a
+ * stride of 0 shares the operand).  With W = the second descriptor set this is the M x N similarity
+ * contraction of Decoder._descriptor_pairing (decoder.py:185).  fp32 MFMA (exact fp32). */
+int dpm_linear_batched(const float *x, int ldx, long long sx, const float *W, int ldw, long long sw,
+                       const float *bias, const float *residual, int ldr, long long sr, float *out,
+                       int ldo, long long so, int batch, int R, int Cin, int Cout, int act,
+                       dpm_stream_t stream);
 
 /* LayerNorm1d / nn.LayerNorm over the channel axis (network/encoder/utils.py:392-402,
  * descriptor_attention.py:20-22): out = act(LN(x + pre)*gamma + beta + post); pre/post NULL-able,
@@ -120,16 +127,17 @@ int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stre
 
 /* Decoder._descriptor_pairing tail (decoder.py:186-191): S (M,N) similarity, overwritten with
  * P = softmax_row(S/tau) * softmax_col(S/tau); then the k largest entries of the flattened P,
- * sorted descending: out_val (k), out_idx (k) flat indices (row = idx / N, col = idx % N). */
-size_t dpm_pairing_workspace_bytes(int M, int N);
-int dpm_dual_softmax_topk(float *S, int M, int N, double tau, int k, float *out_val, int32_t *out_idx,
-                          void *workspace, dpm_stream_t stream);
+ * sorted descending: out_val (k), out_idx (k) flat indices (row = idx / N, col = idx % N).
+ * `batch` independent (M,N) problems are laid out back to back (S (batch,M,N), outputs (batch,k)). */
+size_t dpm_pairing_workspace_bytes(int batch, int M, int N);
+int dpm_dual_softmax_topk(float *S, int batch, int M, int N, double tau, int k, float *out_val,
+                          int32_t *out_idx, void *workspace, dpm_stream_t stream);
 
 /* Decoder._get_corres_sets input assembly (decoder.py:204-205): for the k flat indices,
  * X[0:k] = [x[src] | y[dst]], X[k:2k] = [y[dst] | x[src]] (rows of 2E), and the decoded
- * src_idx/dst_idx (k). x (M,E), y (N,E). */
-int dpm_gather_pairs(const float *x, const float *y, const int32_t *flat_idx, int k, int N, int E,
-                     float *X, int32_t *src_idx, int32_t *dst_idx, dpm_stream_t stream);
+ * src_idx/dst_idx (k). x (batch,M,E), y (batch,N,E), X (batch,2k,2E). */
+int dpm_gather_pairs(const float *x, const float *y, const int32_t *flat_idx, int batch, int k, int M,
+                     int N, int E, float *X, int32_t *src_idx, int32_t *dst_idx, dpm_stream_t stream);
 
 /* torch.mean over the points of each batch element (OverlapHead, heads.py:64-65):
  * x (B,R,C) -> out[b, 0:C] with row stride ldo. */
@@ -143,12 +151,15 @@ int dpm_mean_rows(const float *x, int B, int R, int C, float *out, int ldo, dpm_
  * correspondence order.  result holds 20 + 2k floats; `header` (NULL-able) receives a copy of
  * result[0:20].  R = V U^T of the fp64 SVD, no reflection fix.
  * offsets == NULL: src_xyz/dst_xyz/conf are taken as k ready-made correspondences (rows) and
- * only _solve_transformation_SVD runs. */
-size_t dpm_kabsch_workspace_bytes(int k);
-int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, const float *dst_xyz,
-                    int ld_dst, const int32_t *src_idx, const int32_t *dst_idx, const float *conf, int k,
-                    double eps_offset, int num_iter, double std_ratio, void *workspace, float *result,
-                    float *header, dpm_stream_t stream);
+ * only _solve_transformation_SVD runs.  `batch` independent pairs: offsets (batch,2k,3), indices
+ * and conf (batch,k), coordinates at src_xyz + b*stride_src, result (batch, 20+2k), header rows
+ * header_stride floats apart. */
+size_t dpm_kabsch_workspace_bytes(int batch, int k);
+int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, long long stride_src,
+                    const float *dst_xyz, int ld_dst, long long stride_dst, const int32_t *src_idx,
+                    const int32_t *dst_idx, const float *conf, int batch, int k, double eps_offset,
+                    int num_iter, double std_ratio, void *workspace, float *result, float *header,
+                    int header_stride, dpm_stream_t stream);
 
 /* ---------------------------------------------------------------- registration edge ---- */
 
@@ -156,10 +167,16 @@ int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, cons
  * pcd1 (3,N1), pcd2 (3,N2) channel-first metres; Rt = 12 floats (R row-major, then T);
  * out6x6 = sum over source points whose transformed nearest target lies within `radius` of the
  * G^T G of that target point.  Exact nearest neighbours via a uniform grid. */
-size_t dpm_infomat_workspace_bytes(int N1, int N2);
+size_t dpm_infomat_workspace_bytes(int n_pairs, int N1, int N2);
 /* Rt may point into a dpm_corr_kabsch result (its first 12 floats are R row-major, T). */
 int dpm_information_matrix(const float *pcd1, int N1, const float *pcd2, int N2, const float *Rt,
                            double radius, float *out6x6, void *workspace, dpm_stream_t stream);
+/* n_pairs edges in one pass: pcd (F,3,N) scans in metres, pair p = (src_frame[p], dst_frame[p]);
+ * pose p at Rt + p*rt_stride (12 floats), output p at out + p*out_stride (36 floats). */
+int dpm_information_matrix_batched(const float *pcd, int N, const int32_t *src_frame,
+                                   const int32_t *dst_frame, int n_pairs, const float *Rt, int rt_stride,
+                                   double radius, float *out, int out_stride, void *workspace,
+                                   dpm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,7 @@ def test_kabsch_loop_vs_reference(name, ops):
     w, src, dst = T(g[name + ".w"]), T(g[name + ".src"]), T(g[name + ".dst"])
     res = ops.corr_kabsch(None, src.t().contiguous().to(DEV), dst.t().contiguous().to(DEV), None, None,
                           w.to(DEV), 2.0).cpu()
+    assert res.dim() == 1
     R, Tt, rmse, n, n_in = res[:9].view(3, 3), res[9:12].view(3, 1), float(res[12]), int(res[13]), int(res[14])
     assert n == w.numel() and n_in == int(g[name + ".mask"].sum())
     np.testing.assert_allclose(R.numpy(), g[name + ".R"], atol=2e-6)
@@ -106,7 +107,7 @@ def test_registration_forward_vs_reference(name, dec):
     assert R.is_cuda and tuple(R.shape) == (3, 3) and tuple(Tt.shape) == (3, 1) and isinstance(rmse, float)
     np.testing.assert_allclose(tr["x"].cpu().numpy(), g[name + ".src_corr"][:-3].T, atol=3e-4, rtol=0)
     np.testing.assert_allclose(tr["y"].cpu().numpy(), g[name + ".dst_corr"][:-3].T, atol=3e-4, rtol=0)
-    np.testing.assert_allclose(tr["conf"].cpu().numpy(), g[name + ".pair_conf"], rtol=3e-3, atol=0)
+    np.testing.assert_allclose(tr["conf"].cpu().numpy().reshape(-1), g[name + ".pair_conf"], rtol=3e-3, atol=0)
     assert tr["n_corr"] == g[name + ".corr_w"].shape[0]
     # the tolerance north_star states: 1e-4 m / 1e-4 rad
     dT = float((Tt.cpu() - T(g[name + ".T"])).norm())
@@ -157,3 +158,38 @@ def test_information_matrix_vs_oracle():
     assert float(got.abs().sum()) == 0.0
     got = calculate_information_matrix_from_pcd(a, a, torch.eye(4), device=DEV)
     assert float(got[3, 3]) == 3.0 and float(got[0, 4]) == -6.0 and float(got[1, 5]) == -30.0
+
+
+def test_batched_registration_equals_per_pair_calls(dec):
+    g = load_golden("decoder.npz")
+    names = ["synthetic01", "kitti01"]
+    S = torch.stack([T(g[n + ".src_desc"]) for n in names] + [T(g["kitti01.dst_desc"])])
+    D = torch.stack([T(g[n + ".dst_desc"]) for n in names] + [T(g["synthetic01.src_desc"])])
+    table = torch.zeros(3, 56, device=DEV)
+    res = dec.registration_forward_batch(S, D, 0.5, header_out=table[:, :20])
+    assert tuple(res.shape) == (3, 20 + 2 * 128)
+    for b in range(3):
+        R, Tt, conf, rmse = dec.registration_forward(S[b], D[b], num_sample=0.5)
+        n_in = int(res[b, 14])
+        assert torch.equal(res[b, :9].view(3, 3), R) and torch.equal(res[b, 9:12].view(3, 1), Tt)
+        assert n_in == conf.numel() and torch.equal(res[b, 20:20 + n_in], conf)
+        assert float(res[b, 12]) == rmse
+        assert torch.equal(table[b, :20], res[b, :20])
+
+
+def test_batched_information_matrix_equals_single(ops):
+    from deeppointmap_amd.registration import calculate_information_matrix_from_pcd
+    pts = torch.stack([synthetic.frame(f, 8192) * 60 for f in range(3)]).to(DEV)
+    table = torch.zeros(3, 56, device=DEV)
+    poses = []
+    for p in range(3):
+        SE3 = synthetic.relative_pose(p, (p + 1) % 3).float()
+        table[p, :9] = SE3[:3, :3].reshape(9)
+        table[p, 9:12] = SE3[:3, 3]
+        poses.append(SE3)
+    src = torch.tensor([0, 1, 2], dtype=torch.int32, device=DEV)
+    dst = torch.tensor([1, 2, 0], dtype=torch.int32, device=DEV)
+    ops.information_matrix_batched(pts, src, dst, table[:, :12], table[:, 20:])
+    for p in range(3):
+        want = calculate_information_matrix_from_pcd(pts[p], pts[(p + 1) % 3], poses[p], device=DEV)
+        np.testing.assert_allclose(table[p, 20:].view(6, 6).cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-3)
