@@ -26,7 +26,8 @@ SIGNATURES = {
     "dpm_fps_workspace_bytes": (c_size_t, [I, I, I]),
     "dpm_fps": (I, [P, P, I, I, I, P, P, P, P, P]),
     "dpm_fps_ex": (I, [P, P, I, I, I, P, P, P, P, I, P]),
-    "dpm_knn_hybrid": (I, [P, P, P, I, I, I, I, D, P, P]),
+    "dpm_knn_workspace_bytes": (c_size_t, [I, I]),
+    "dpm_knn_hybrid": (I, [P, P, P, I, I, I, I, D, P, P, P]),
     "dpm_group_mlp_max": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, D, P, P]),
     "dpm_linear": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
     "dpm_linear_batched": (I, [P, I, LL, P, I, LL, P, P, I, LL, P, I, LL, I, I, I, I, I, P]),

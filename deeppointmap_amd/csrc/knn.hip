@@ -4,8 +4,8 @@
 //
 // Semantics: the reference takes the K nearest points and then overwrites every slot whose
 // squared distance exceeds r^2 with slot 0 (the nearest).  That equals "the K nearest among the
-// points within r, padded with the nearest point", which is what is computed here: a scan keeps
-// only candidates with d <= min(r^2, current K-th best), so the per-centre candidate list stays
+// points within r, padded with the nearest point", which is what is computed here: only
+// candidates with d <= min(r^2, current K-th best) are kept, so the per-centre candidate list stays
 // tiny and no (S,N) distance matrix is ever materialised.  Distances reproduce the reference's
 // CPU path bit for bit: coordinate_distance (utils.py:288-295) evaluates the EXPANDED form
 //   d = ((-2 * dot) + |a|^2) + |b|^2,  dot = fma(az,bz, fma(ay,by, ax*bx)),  |v|^2 = (x*x+y*y)+z*z
@@ -24,27 +24,41 @@
 // exactly the reference's set.  For K*64 > N the reference uses std::nth_element; ties there
 // keep the smaller index (none occur on the shipped shapes).
 //
-// v1 structure: one wave handles CPW centres and streams all points of the frame (64 per step,
-// coalesced); a wave-aggregated append (ballot + popcount) puts survivors into a per-centre LDS
-// list; when the list is nearly full, or at the end, the K smallest are extracted by repeated
-// wave arg-min (ties: smaller index).
+// Two search strategies, same candidate logic:
+//  * BRUTE (N < 2048): one wave handles 4 centres and streams all points of the frame.
+//  * GRID  (N >= 2048): the frame's points are counting-sorted into a 2-D xy grid whose cell edge
+//    exceeds sqrt(r^2 + 2e-5) (the 2e-5 covers the rounding of the expanded form), so every
+//    admissible point lies in the 3x3 cells around the centre; cells of one grid row are contiguous
+//    in the sorted array, so a centre reads three short ranges.  65 536 x 4096 pair evaluations
+//    become ~150 per centre.  A centre with nothing inside the radius (only padded centres) falls
+//    back to a full scan for its nearest point.
 #include "dpm_common.h"
 
 namespace {
 
-constexpr int CPW = 4;    // centres per wave
+constexpr int CPW = 4;    // centres per wave (brute force)
 constexpr int WPB = 4;    // waves per block
 constexpr int CAP = 512;  // candidate slots per centre
 constexpr int KMAX = 64;
 constexpr int TMPN = 128;  // scratch entries per wave (>= KMAX + 1 and >= 64)
+constexpr int GDIM = 128;  // grid cells per axis (upper bound)
+constexpr int GRID_MIN_N = 2048;
 
 __device__ __forceinline__ void wave_mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
+__device__ __forceinline__ float sq3(float x, float y, float z) { return (x * x + y * y) + z * z; }
+
+// the reference's expanded-form squared distance (see header)
+__device__ __forceinline__ float exp_dist(float cx, float cy, float cz, float caa, float x, float y, float z,
+                                          float bb) {
+    return ((-2.f * fmaf(cz, z, fmaf(cy, y, cx * x))) + caa) + bb;
+}
+
 // Extract the k smallest (d asc, then index asc) of cd/ci[0..count) into od/oi[0..k); entries
-// taken are overwritten with +inf.  All 64 lanes participate.  Returns nothing; k <= count.
+// taken are overwritten with +inf.  All 64 lanes participate; k <= count.
 __device__ __forceinline__ void select_smallest(volatile float *cd, volatile int *ci, int count, int k,
                                                 volatile float *od, volatile int *oi) {
     const int lane = lane_id();
@@ -95,7 +109,7 @@ __device__ void heap_adjust(volatile float *hv, volatile int *hi, int hole, int 
     hv[hole] = val, hi[hole] = vi;
 }
 
-// Sequential emulation of std::partial_sort's heap-select over the whole row (see header).
+// Sequential emulation of std::partial_sort's heap-select over the whole row in ORIGINAL index order.
 // hv/hi: K-entry heap in LDS; tv: 64-entry staging.  On return hv/hi hold the K survivors.
 __device__ void heap_select_exact(const float *__restrict__ pts, int len, int K, float cx, float cy, float cz,
                                   float caa, volatile float *hv, volatile int *hi, volatile float *tv) {
@@ -103,8 +117,7 @@ __device__ void heap_select_exact(const float *__restrict__ pts, int len, int K,
     auto dist = [&](int i) -> float {
         if (i >= len) return __builtin_inff();
         const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-        const float bb = (x * x + y * y) + z * z;
-        return ((-2.f * fmaf(cz, z, fmaf(cy, y, cx * x))) + caa) + bb;
+        return exp_dist(cx, cy, cz, caa, x, y, z, sq3(x, y, z));
     };
     if (lane < K) hv[lane] = dist(lane), hi[lane] = lane;
     wave_mem_sync();
@@ -137,6 +150,98 @@ __device__ void heap_select_exact(const float *__restrict__ pts, int len, int K,
     }
 }
 
+// Per-centre running state (all fields wave-uniform except gd/gi which are per lane).
+struct Ctr {
+    float x, y, z, aa, thr, gd;
+    int gi, cnt;
+    bool tie;
+};
+
+__device__ __forceinline__ void ctr_init(Ctr &c, const float *p, float r2) {
+    c.x = p[0], c.y = p[1], c.z = p[2];
+    c.aa = sq3(c.x, c.y, c.z);
+    c.thr = r2, c.gd = __builtin_inff(), c.gi = 0x7fffffff, c.cnt = 0, c.tie = false;
+}
+
+// Offer one point per lane (ok = lane holds a valid point with original index i) to centre c.
+__device__ __forceinline__ void offer(Ctr &c, bool ok, float x, float y, float z, float bb, int i, int K,
+                                      volatile float *cd, volatile int *ci, volatile float *td, volatile int *ti) {
+    const int lane = lane_id();
+    const float d = ok ? exp_dist(c.x, c.y, c.z, c.aa, x, y, z, bb) : __builtin_inff();
+    if (d < c.gd || (d == c.gd && i < c.gi)) c.gd = d, c.gi = i;
+    const bool in = d <= c.thr;
+    const unsigned long long m = __ballot(in);
+    if (!m) return;
+    if (in) {
+        const int pos = c.cnt + __popcll(m & ((1ull << lane) - 1ull));
+        cd[pos] = d, ci[pos] = i;
+    }
+    c.cnt += __popcll(m);
+    if (c.cnt > CAP - 64) {  // compact: keep the K smallest, tighten the admission bound
+        wave_mem_sync();
+        const int k = min(K, c.cnt), k1 = min(K + 1, c.cnt);
+        select_smallest(cd, ci, c.cnt, k1, td, ti);  // one extra: is there a tie across the K-th slot?
+        if (k1 > K && td[K] == td[K - 1]) c.tie = true;
+        wave_mem_sync();
+        if (lane < k) cd[lane] = td[lane], ci[lane] = ti[lane];
+        wave_mem_sync();
+        c.cnt = k;
+        if (k == K) c.thr = fminf(c.thr, td[K - 1]);
+    }
+}
+
+// Turn the candidate list of centre c into the K output slots.
+__device__ __forceinline__ void finish(Ctr &c, const float *__restrict__ pts, int len, int N, int K, float r2,
+                                       volatile float *cd, volatile int *ci, volatile float *td, volatile int *ti,
+                                       int32_t *__restrict__ out) {
+    const int lane = lane_id();
+    wave_mem_sync();
+    // global nearest among the points examined (slot 0 when nothing lies within the radius)
+    float nd = c.gd;
+    int ni = c.gi;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od_ = __shfl_xor(nd, off, 64);
+        const int oi_ = __shfl_xor(ni, off, 64);
+        if (od_ < nd || (od_ == nd && oi_ < ni)) nd = od_, ni = oi_;
+    }
+    if (ni == 0x7fffffff) ni = 0;  // empty frame
+    const int k = min(K, c.cnt), k1 = min(K + 1, c.cnt);
+    select_smallest(cd, ci, c.cnt, k1, td, ti);
+    if (k1 > K && td[K] == td[K - 1]) c.tie = true;
+    const bool heap_regime = (long long)K * 64 <= (long long)N;  // torch.topk: partial_sort vs nth_element
+    if (c.tie && heap_regime && len >= K) {
+        // boundary tie: reproduce the reference's choice exactly (rare, sequential)
+        wave_mem_sync();
+        heap_select_exact(pts, len, K, c.x, c.y, c.z, c.aa, cd, ci, td);
+        float mv = (lane < K) ? cd[lane] : __builtin_inff();
+        int mi = (lane < K) ? ci[lane] : 0x7fffffff;
+        const float myv = mv;
+        const int myi = mi;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(mv, off, 64);
+            const int oi = __shfl_xor(mi, off, 64);
+            if (ov < mv || (ov == mv && oi < mi)) mv = ov, mi = oi;
+        }
+        int outv = (myv > r2) ? mi : myi;  // radius mask -> nearest (utils.py:85-87)
+        // slot 0 must be the nearest point: swap it (in registers) with whoever holds it
+        const unsigned long long hm = __ballot(lane < K && myi == mi);
+        const int L = hm ? __builtin_ctzll(hm) : 0;
+        const int v0 = __shfl(outv, 0, 64);
+        if (lane == L) outv = v0;
+        if (lane == 0) outv = mi;
+        if (lane < K) out[lane] = outv;
+    } else {
+        const int first = (k > 0) ? ti[0] : ni;
+        if (lane < K) out[lane] = (lane < k) ? ti[lane] : first;
+    }
+    wave_mem_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// BRUTE: one wave = CPW centres, streams every point
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__restrict__ points_all,
                                                               const int32_t *__restrict__ lengths,
                                                               const float *__restrict__ centers_all, int N,
@@ -152,114 +257,192 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
     const float *pts = points_all + (size_t)b * N * 3;
     const float *ctr = centers_all + (size_t)b * S * 3;
     const int len = min(max(lengths[b], 0), N);
-
-    float cx[CPW], cy[CPW], cz[CPW], caa[CPW], thr[CPW], gd[CPW];
-    int gi[CPW], cnt[CPW];
-    bool tie[CPW];
-    const bool heap_regime = (long long)K * 64 <= (long long)N;  // torch.topk: partial_sort vs nth_element
+    Ctr c[CPW];
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) {
-        const int s = min(s0 + j, S - 1);
-        cx[j] = ctr[3 * s], cy[j] = ctr[3 * s + 1], cz[j] = ctr[3 * s + 2];
-        caa[j] = (cx[j] * cx[j] + cy[j] * cy[j]) + cz[j] * cz[j];
-        thr[j] = r2, gd[j] = __builtin_inff(), gi[j] = 0x7fffffff, cnt[j] = 0, tie[j] = false;
-    }
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int j = 0; j < CPW; ++j) ctr_init(c[j], ctr + 3 * (size_t)min(s0 + j, S - 1), r2);
     for (int base = 0; base < len; base += 64) {
         const int i = base + lane;
         const bool ok = i < len;
         float x = 0.f, y = 0.f, z = 0.f;
         if (ok) x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-        const float bb = (x * x + y * y) + z * z;
+        const float bb = sq3(x, y, z);
 #pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            const float dot = fmaf(cz[j], z, fmaf(cy[j], y, cx[j] * x));
-            const float d = ok ? ((-2.f * dot) + caa[j]) + bb : __builtin_inff();
-            if (d < gd[j]) gd[j] = d, gi[j] = i;
-            const bool in = d <= thr[j];
-            const unsigned long long m = __ballot(in);
-            if (m) {
-                if (in) {
-                    const int pos = cnt[j] + __popcll(m & lt);
-                    s_d[w][j][pos] = d;
-                    s_i[w][j][pos] = i;
-                }
-                cnt[j] += __popcll(m);
-                if (cnt[j] > CAP - 64) {  // compact: keep the K smallest, tighten the admission bound
-                    wave_mem_sync();
-                    const int k = min(K, cnt[j]);
-                    const int k1 = min(K + 1, cnt[j]);  // one extra: is there a tie across the K-th slot?
-                    select_smallest(s_d[w][j], s_i[w][j], cnt[j], k1, s_td[w], s_ti[w]);
-                    if (k1 > K && s_td[w][K] == s_td[w][K - 1]) tie[j] = true;
-                    wave_mem_sync();
-                    if (lane < k) s_d[w][j][lane] = s_td[w][lane], s_i[w][j][lane] = s_ti[w][lane];
-                    wave_mem_sync();
-                    cnt[j] = k;
-                    if (k == K) thr[j] = fminf(thr[j], s_td[w][K - 1]);
-                }
-            }
-        }
+        for (int j = 0; j < CPW; ++j) offer(c[j], ok, x, y, z, bb, i, K, s_d[w][j], s_i[w][j], s_td[w], s_ti[w]);
     }
-    wave_mem_sync();
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
         if (s0 + j >= S) break;
-        // global nearest (slot 0 when nothing lies within the radius)
-        float nd = gd[j];
-        int ni = gi[j];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float od_ = __shfl_xor(nd, off, 64);
-            const int oi_ = __shfl_xor(ni, off, 64);
-            if (od_ < nd || (od_ == nd && oi_ < ni)) nd = od_, ni = oi_;
-        }
-        if (ni == 0x7fffffff) ni = 0;  // empty frame
-        const int k = min(K, cnt[j]);
-        const int k1 = min(K + 1, cnt[j]);
-        select_smallest(s_d[w][j], s_i[w][j], cnt[j], k1, s_td[w], s_ti[w]);
-        if (k1 > K && s_td[w][K] == s_td[w][K - 1]) tie[j] = true;
-        int32_t *out = idx_all + ((size_t)b * S + (s0 + j)) * K;
-        if (tie[j] && heap_regime && len >= K) {
-            // boundary tie: reproduce the reference's choice exactly (rare, sequential)
-            wave_mem_sync();
-            volatile float *hv = s_d[w][j];
-            volatile int *hi = s_i[w][j];
-            heap_select_exact(pts, len, K, cx[j], cy[j], cz[j], caa[j], hv, hi, s_td[w]);
-            float mv = (lane < K) ? hv[lane] : __builtin_inff();
-            int mi = (lane < K) ? hi[lane] : 0x7fffffff;
-            const float myv = mv;
-            const int myi = mi;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ov = __shfl_xor(mv, off, 64);
-                const int oi = __shfl_xor(mi, off, 64);
-                if (ov < mv || (ov == mv && oi < mi)) mv = ov, mi = oi;
-            }
-            int outv = (myv > r2) ? mi : myi;  // radius mask -> nearest (utils.py:85-87)
-            // slot 0 must be the nearest point: swap it (in registers) with whoever holds it
-            const unsigned long long hm = __ballot(lane < K && myi == mi);
-            const int L = hm ? __builtin_ctzll(hm) : 0;
-            const int v0 = __shfl(outv, 0, 64);
-            if (lane == L) outv = v0;
-            if (lane == 0) outv = mi;
-            if (lane < K) out[lane] = outv;
-        } else {
-            const int first = (k > 0) ? s_ti[w][0] : ni;
-            if (lane < K) out[lane] = (lane < k) ? s_ti[w][lane] : first;
-        }
-        wave_mem_sync();
+        finish(c[j], pts, len, N, K, r2, s_d[w][j], s_i[w][j], s_td[w], s_ti[w],
+               idx_all + ((size_t)b * S + (s0 + j)) * K);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRID build: counting sort of one frame into row-major xy cells (one 1024-thread block per frame)
+// ---------------------------------------------------------------------------------------------
+struct KnnGrid {  // per frame header in the workspace
+    float lox, loy, inv_cs;
+    int g;  // cells per axis
+};
+
+__global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float *__restrict__ points_all,
+                                                              const int32_t *__restrict__ lengths, int N,
+                                                              float cs_min, KnnGrid *__restrict__ hdr_all,
+                                                              int *__restrict__ start_all,
+                                                              float4 *__restrict__ sorted_all) {
+    __shared__ int s_hist[GDIM * GDIM];
+    __shared__ float s_red[4][16];
+    __shared__ int s_wsum[16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float *pts = points_all + (size_t)b * N * 3;
+    const int len = min(max(lengths[b], 0), N);
+    float lox = __builtin_inff(), loy = lox, hix = -lox, hiy = -lox;
+    for (int i = t; i < len; i += 1024) {
+        const float x = pts[3 * i], y = pts[3 * i + 1];
+        lox = fminf(lox, x), hix = fmaxf(hix, x), loy = fminf(loy, y), hiy = fmaxf(hiy, y);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lox = fminf(lox, __shfl_xor(lox, off, 64)), loy = fminf(loy, __shfl_xor(loy, off, 64));
+        hix = fmaxf(hix, __shfl_xor(hix, off, 64)), hiy = fmaxf(hiy, __shfl_xor(hiy, off, 64));
+    }
+    if (lane == 0) s_red[0][w] = lox, s_red[1][w] = loy, s_red[2][w] = hix, s_red[3][w] = hiy;
+    for (int c = t; c < GDIM * GDIM; c += 1024) s_hist[c] = 0;
+    __syncthreads();
+    for (int k = 0; k < 16; ++k) {
+        lox = fminf(lox, s_red[0][k]), loy = fminf(loy, s_red[1][k]);
+        hix = fmaxf(hix, s_red[2][k]), hiy = fmaxf(hiy, s_red[3][k]);
+    }
+    if (len == 0) lox = loy = hix = hiy = 0.f;
+    const float ext = fmaxf(fmaxf(hix - lox, hiy - loy), 1e-6f);
+    const float cs = fmaxf(cs_min, ext / (float)(GDIM - 1));
+    const float inv_cs = 1.0f / cs;
+    const int g = min(GDIM, (int)(ext * inv_cs) + 1);
+    auto cell = [&](float x, float y) -> int {
+        const int cx = min(max((int)floorf((x - lox) * inv_cs), 0), g - 1);
+        const int cy = min(max((int)floorf((y - loy) * inv_cs), 0), g - 1);
+        return cy * g + cx;
+    };
+    for (int i = t; i < len; i += 1024) atomicAdd(&s_hist[cell(pts[3 * i], pts[3 * i + 1])], 1);
+    __syncthreads();
+    // exclusive scan over the counters, 16 per thread
+    constexpr int PER = GDIM * GDIM / 1024;
+    int local[PER], tsum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) local[q] = s_hist[t * PER + q], tsum += local[q];
+    int inc = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wsum[w] = inc;
+    __syncthreads();
+    int run = inc - tsum;
+    for (int k = 0; k < w; ++k) run += s_wsum[k];
+    int *start = start_all + (size_t)b * (GDIM * GDIM + 1);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        s_hist[t * PER + q] = run;
+        start[t * PER + q] = run;
+        run += local[q];
+    }
+    if (t == 1023) start[GDIM * GDIM] = run;
+    if (t == 0) hdr_all[b] = KnnGrid{lox, loy, inv_cs, g};
+    __syncthreads();
+    float4 *sorted = sorted_all + (size_t)b * N;
+    for (int i = t; i < len; i += 1024) {
+        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        const int pos = atomicAdd(&s_hist[cell(x, y)], 1);
+        sorted[pos] = make_float4(x, y, z, __int_as_float(i));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRID search: one wave per centre
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restrict__ points_all,
+                                                            const int32_t *__restrict__ lengths,
+                                                            const float *__restrict__ centers_all, int N, int S,
+                                                            int K, float r2, const KnnGrid *__restrict__ hdr_all,
+                                                            const int *__restrict__ start_all,
+                                                            const float4 *__restrict__ sorted_all,
+                                                            int32_t *__restrict__ idx_all) {
+    __shared__ float s_d[WPB][CAP];
+    __shared__ int s_i[WPB][CAP];
+    __shared__ float s_td[WPB][TMPN];
+    __shared__ int s_ti[WPB][TMPN];
+    const int b = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * WPB + w;
+    if (s >= S) return;
+    const float *pts = points_all + (size_t)b * N * 3;
+    const int len = min(max(lengths[b], 0), N);
+    const KnnGrid G = hdr_all[b];
+    const int *start = start_all + (size_t)b * (GDIM * GDIM + 1);
+    const float4 *sorted = sorted_all + (size_t)b * N;
+    Ctr c;
+    ctr_init(c, centers_all + ((size_t)b * S + s) * 3, r2);
+    const int cx = (int)floorf((c.x - G.lox) * G.inv_cs), cy = (int)floorf((c.y - G.loy) * G.inv_cs);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.g - 1);
+    if (x0 <= x1) {
+        for (int yy = max(cy - 1, 0); yy <= min(cy + 1, G.g - 1); ++yy) {
+            const int lo = start[yy * G.g + x0], hi = start[yy * G.g + x1 + 1];
+            for (int base = lo; base < hi; base += 64) {
+                const int q = base + lane;
+                const bool ok = q < hi;
+                float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) p = sorted[q];
+                offer(c, ok, p.x, p.y, p.z, sq3(p.x, p.y, p.z), ok ? __float_as_int(p.w) : 0x7fffffff, K, s_d[w],
+                      s_i[w], s_td[w], s_ti[w]);
+            }
+        }
+    }
+    if (c.cnt == 0) {
+        // nothing within the radius (a padded centre): the answer is the nearest point overall
+        c.gd = __builtin_inff(), c.gi = 0x7fffffff;
+        for (int base = 0; base < len; base += 64) {
+            const int i = base + lane;
+            if (i < len) {
+                const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+                const float d = exp_dist(c.x, c.y, c.z, c.aa, x, y, z, sq3(x, y, z));
+                if (d < c.gd) c.gd = d, c.gi = i;
+            }
+        }
+    }
+    finish(c, pts, len, N, K, r2, s_d[w], s_i[w], s_td[w], s_ti[w], idx_all + ((size_t)b * S + s) * K);
 }
 
 }  // namespace
 
+extern "C" size_t dpm_knn_workspace_bytes(int B, int N) {
+    if (N < GRID_MIN_N) return 0;
+    return 1024 + sizeof(KnnGrid) * (size_t)B + sizeof(int) * (size_t)B * (GDIM * GDIM + 1) +
+           (size_t)B * (size_t)N * sizeof(float4);
+}
+
 extern "C" int dpm_knn_hybrid(const float *points, const int32_t *lengths, const float *centers, int B, int N,
-                              int S, int K, double radius, int32_t *idx, dpm_stream_t stream) {
+                              int S, int K, double radius, int32_t *idx, void *workspace, dpm_stream_t stream) {
     DPM_CHECK_ARG(points && lengths && centers && idx);
     DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && radius > 0.0);
     if (K > KMAX) return DPM_EUNSUPPORTED;
-    dim3 grid(dpm_cdiv(S, WPB * CPW), B);
-    hipLaunchKernelGGL(knn_hybrid_kernel, grid, dim3(WPB * 64), 0, (hipStream_t)stream, points, lengths,
-                       centers, N, S, K, (float)(radius * radius), idx);
+    hipStream_t st = (hipStream_t)stream;
+    const float r2 = (float)(radius * radius);
+    if (N >= GRID_MIN_N && workspace) {
+        uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+        KnnGrid *hdr = (KnnGrid *)p;
+        p = (p + sizeof(KnnGrid) * (size_t)B + 255) & ~(uintptr_t)255;
+        int *start = (int *)p;
+        p = (p + sizeof(int) * (size_t)B * (GDIM * GDIM + 1) + 255) & ~(uintptr_t)255;
+        float4 *sorted = (float4 *)p;
+        // cell edge > sqrt(r^2 + 2e-5): the expanded-form distance can undershoot the true one by ~1.5e-6
+        const float cs_min = (float)(sqrt(radius * radius + 2e-5) * 1.002);
+        hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, st, points, lengths, N, cs_min, hdr, start,
+                           sorted);
+        hipLaunchKernelGGL(knn_grid_kernel, dim3(dpm_cdiv(S, WPB), B), dim3(WPB * 64), 0, st, points, lengths, centers, N,
+                           S, K, r2, hdr, start, sorted, idx);
+        return dpm_launch_status();
+    }
+    hipLaunchKernelGGL(knn_hybrid_kernel, dim3(dpm_cdiv(S, WPB * CPW), B), dim3(WPB * 64), 0, st, points, lengths, centers,
+                       N, S, K, r2, idx);
     return dpm_launch_status();
 }

@@ -70,16 +70,19 @@ def fps(xyz: torch.Tensor, lengths: torch.Tensor, K: int, algo: int = 0):
 
 
 def knn_hybrid(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tensor, K: int,
-               radius: float) -> torch.Tensor:
-    """points (B,N,3), centers (B,S,3) -> idx (B,S,K) int32."""
+               radius: float, brute: bool = False) -> torch.Tensor:
+    """points (B,N,3), centers (B,S,3) -> idx (B,S,K) int32.  brute=True forces the all-pairs scan."""
     _chk(points, torch.float32, "points")
     _chk(centers, torch.float32, "centers")
     _chk(lengths, torch.int32, "lengths")
     B, N, _ = points.shape
     S = centers.shape[1]
     idx = torch.empty(B, S, K, device=points.device, dtype=torch.int32)
-    _lib.check(_lib.load().dpm_knn_hybrid(_ptr(points), _ptr(lengths), _ptr(centers), B, N, S, K, float(radius),
-                                          _ptr(idx), _stream(points)), "dpm_knn_hybrid")
+    lib = _lib.load()
+    nbytes = 0 if brute else lib.dpm_knn_workspace_bytes(B, N)
+    ws = torch.empty(nbytes, device=points.device, dtype=torch.uint8) if nbytes else None
+    _lib.check(lib.dpm_knn_hybrid(_ptr(points), _ptr(lengths), _ptr(centers), B, N, S, K, float(radius),
+                                  _ptr(idx), _ptr(ws), _stream(points)), "dpm_knn_hybrid")
     return idx
 
 

@@ -66,9 +66,12 @@ int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N, int K, in
 /* Querier.hybrid_query / hybrid_query_t3d == pytorch3d.ops.knn_points + radius mask
  * (network/encoder/utils.py:76-89,113-123): for each centre the K nearest valid points, slots
  * whose squared distance exceeds radius^2 replaced by the nearest index.  Slot 0 is the nearest
- * point.  idx (B,S,K). */
+ * point.  idx (B,S,K).  Distances and tie handling reproduce the reference's CPU path exactly
+ * (see csrc/knn.hip).  workspace: dpm_knn_workspace_bytes(B,N) bytes (0 for small N; NULL selects
+ * the brute-force path). */
+size_t dpm_knn_workspace_bytes(int B, int N);
 int dpm_knn_hybrid(const float *points, const int32_t *lengths, const float *centers, int B, int N,
-                   int S, int K, double radius, int32_t *idx, dpm_stream_t stream);
+                   int S, int K, double radius, int32_t *idx, void *workspace, dpm_stream_t stream);
 
 /* SetAbstraction / LocalAggregation body (network/encoder/pointnext.py:52-61,97-107):
  * out[b,s,:] = max_k relu(LN(W [fea[idx[b,s,k]], (xyz[idx]-center)/radius] + bias)).

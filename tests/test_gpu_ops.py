@@ -134,6 +134,22 @@ def test_knn_boundary_ties_follow_reference_topk(ops):
         assert idx_rows_equal_as_sets(got, want[0].numpy()).all(), (N, K)
 
 
+def test_knn_grid_equals_brute_force(ops):
+    # the grid search must return exactly what the all-pairs scan returns (sets, slot 0, padded centres)
+    gen = torch.Generator().manual_seed(77)
+    pts = torch.cat([synthetic.frame(2, 16384).t(), torch.zeros(100, 3)]).unsqueeze(0).repeat(2, 1, 1).contiguous()
+    pts[1, :16384] = pts[1, :16384] * torch.tensor([1.0, 0.3, 1.0])  # different extent per frame
+    lens = _lengths([16384, 12000])
+    ctr = torch.cat([pts[:, torch.randperm(12000, generator=gen)[:500]], torch.zeros(2, 12, 3) + 7.0], dim=1).contiguous()
+    for r, K in [(0.05, 32), (0.1, 32), (0.4, 16)]:
+        a = ops.knn_hybrid(pts.to(DEV), lens, ctr.to(DEV), K, r).cpu().numpy()
+        b = ops.knn_hybrid(pts.to(DEV), lens, ctr.to(DEV), K, r, brute=True).cpu().numpy()
+        for f in range(2):
+            assert idx_rows_equal_as_sets(a[f], b[f]).all(), (r, K, f)
+            assert (a[f][:, 0] == b[f][:, 0]).all()
+        assert (a[:, -12:] == a[:, -12:, :1]).all()  # far-away centres: every slot is the nearest point
+
+
 def test_knn_sparse_rows_pad_with_nearest(ops):
     pts = torch.tensor([[[0.0, 0, 0], [0.01, 0, 0], [5, 5, 5], [9, 9, 9]]])
     ctr = torch.tensor([[[0.0, 0, 0], [5.2, 5, 5], [100, 100, 100]]])
