@@ -20,6 +20,7 @@ SOURCES = {
     "knn.hip": [],
     "encoder_ops.hip": [],
     "gemm.hip": [],
+    "group_mlp.hip": [],
     "decoder_ops.hip": [],
     "infomat.hip": [],
 }

@@ -42,11 +42,12 @@ __global__ __launch_bounds__(256) void to_channel_first_kernel(const float *__re
 
 // ------------------------------------------------------------------------------------------
 // grouped MLP: one workgroup per centre.  v1 (plain VALU): gather K neighbour rows into LDS,
-// y[r][c] = b[c] + sum_k g[r][k] Wt[k][c], LayerNorm over c, ReLU, max over r.
+// y[r][c] = b[c] + sum_k g[r][k] W[c][k], LayerNorm over c, ReLU, max over r.  Generic fallback for
+// shapes the MFMA kernel (group_mlp.hip) does not cover.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void group_mlp_max_kernel(
     const float *__restrict__ xyz_all, const float *__restrict__ fea_all, const float *__restrict__ ctr_all,
-    const int32_t *__restrict__ idx_all, const float *__restrict__ Wt, const float *__restrict__ bias,
+    const int32_t *__restrict__ idx_all, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ gamma, const float *__restrict__ beta, int N, int S, int K, int Cin, int Cout,
     float inv_r, float *__restrict__ out_all) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void group_mlp_max_kernel(
         const int r = o / Cout, c = o - r * Cout;
         float acc = bias[c];
         const float *g = G + r * C3;
-        for (int k = 0; k < C3; ++k) acc = fmaf(g[k], Wt[(size_t)k * Cout + c], acc);
+        for (int k = 0; k < C3; ++k) acc = fmaf(g[k], W[(size_t)c * C3 + k], acc);
         Y[o] = acc;
     }
     __syncthreads();
@@ -210,10 +211,10 @@ extern "C" int dpm_to_channel_first(const float *x, int B, int R, int C, float *
     return dpm_launch_status();
 }
 
-extern "C" int dpm_group_mlp_max(const float *xyz, const float *fea, const float *centers, const int32_t *idx,
-                                 const float *Wt, const float *bias, const float *gamma, const float *beta, int B,
-                                 int N, int S, int K, int Cin, int Cout, double radius, float *out,
-                                 dpm_stream_t stream) {
+extern "C" int dpm_group_mlp_max_generic(const float *xyz, const float *fea, const float *centers, const int32_t *idx,
+                                         const float *Wt, const float *bias, const float *gamma, const float *beta, int B,
+                                         int N, int S, int K, int Cin, int Cout, double radius, float *out,
+                                         dpm_stream_t stream) {
     DPM_CHECK_ARG(xyz && fea && centers && idx && Wt && bias && gamma && beta && out);
     DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && K <= 64 && Cin >= 1 && Cout >= 1 && radius > 0.0);
     const size_t lds = sizeof(float) * ((size_t)K * (Cin + 3) + (size_t)K * Cout + 2 * K) + sizeof(int) * K;

@@ -33,7 +33,6 @@ class Encoder(ParamTree):
             if s["type"] not in ("fps", "fps-t3d"):
                 raise NotImplementedError(f"sampler {s['type']!r}: only farthest point sampling is implemented "
                                           "(all shipped configs use fps-t3d)")
-        self._wt_cache: Dict[str, tuple] = {}
         self.eval()
 
     # -- helpers -------------------------------------------------------------------------------
@@ -41,22 +40,12 @@ class Encoder(ParamTree):
     def device(self) -> torch.device:
         return self.p("point_mlp0.weight").device
 
-    def _wt(self, key: str) -> torch.Tensor:
-        """(Cout, Cin+3, 1, 1) conv weight -> cached (Cin+3, Cout) transpose the grouped-MLP kernel reads."""
-        w = self.p(key)
-        tag = (w.data_ptr(), w._version, w.device)
-        hit = self._wt_cache.get(key)
-        if hit is None or hit[0] != tag:
-            hit = (tag, w.detach().reshape(w.shape[0], w.shape[1]).t().contiguous())
-            self._wt_cache[key] = hit
-        return hit[1]
-
     def _mlp_ln(self, x: torch.Tensor, conv: str, ln: str, act: int, post: Optional[torch.Tensor] = None):
         y = ops.linear(x, self.p(conv + ".weight"), self.p(conv + ".bias"))
         return ops.layernorm(y, self.p(ln + ".weight"), self.p(ln + ".bias"), act=act, post=post)
 
     def _group(self, prefix: str, radius: float, xyz, fea, centers, idx):
-        return ops.group_mlp_max(xyz, fea, centers, idx, self._wt(prefix + ".0.weight"), self.p(prefix + ".0.bias"),
+        return ops.group_mlp_max(xyz, fea, centers, idx, self.p(prefix + ".0.weight"), self.p(prefix + ".0.bias"),
                                  self.p(prefix + ".1.ln.weight"), self.p(prefix + ".1.ln.bias"), radius)
 
     # -- forward -------------------------------------------------------------------------------

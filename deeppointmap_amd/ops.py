@@ -86,21 +86,23 @@ def knn_hybrid(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tenso
     return idx
 
 
-def group_mlp_max(xyz, fea, centers, idx, Wt, bias, gamma, beta, radius: float) -> torch.Tensor:
-    """xyz (B,N,3), fea (B,N,Cin), centers (B,S,3), idx (B,S,K), Wt (Cin+3,Cout) -> (B,S,Cout)."""
-    for n, t in (("xyz", xyz), ("fea", fea), ("centers", centers), ("Wt", Wt), ("bias", bias),
+def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, generic: bool = False) -> torch.Tensor:
+    """xyz (B,N,3), fea (B,N,Cin), centers (B,S,3), idx (B,S,K), W (Cout,Cin+3[,1,1]) -> (B,S,Cout).
+    generic=True forces the plain-VALU kernel (cross-check path)."""
+    for n, t in (("xyz", xyz), ("fea", fea), ("centers", centers), ("W", W), ("bias", bias),
                  ("gamma", gamma), ("beta", beta)):
         _chk(t, torch.float32, n)
     _chk(idx, torch.int32, "idx")
     B, N, Cin = fea.shape
     S, K = idx.shape[1], idx.shape[2]
-    Cout = Wt.shape[1]
-    if Wt.shape[0] != Cin + 3:
-        raise ValueError(f"Wt must be (Cin+3, Cout) = ({Cin + 3}, {Cout}), got {tuple(Wt.shape)}")
+    Cout = W.shape[0]
+    if W.shape[1] != Cin + 3:
+        raise ValueError(f"W must be (Cout, Cin+3) = ({Cout}, {Cin + 3}), got {tuple(W.shape)}")
     out = torch.empty(B, S, Cout, device=fea.device, dtype=torch.float32)
-    _lib.check(_lib.load().dpm_group_mlp_max(_ptr(xyz), _ptr(fea), _ptr(centers), _ptr(idx), _ptr(Wt), _ptr(bias),
-                                             _ptr(gamma), _ptr(beta), B, N, S, K, Cin, Cout, float(radius),
-                                             _ptr(out), _stream(fea)), "dpm_group_mlp_max")
+    lib = _lib.load()
+    fn = lib.dpm_group_mlp_max_generic if generic else lib.dpm_group_mlp_max
+    _lib.check(fn(_ptr(xyz), _ptr(fea), _ptr(centers), _ptr(idx), _ptr(W), _ptr(bias), _ptr(gamma), _ptr(beta),
+                  B, N, S, K, Cin, Cout, float(radius), _ptr(out), _stream(fea)), "dpm_group_mlp_max")
     return out
 
 

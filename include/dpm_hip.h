@@ -75,10 +75,16 @@ int dpm_knn_hybrid(const float *points, const int32_t *lengths, const float *cen
 
 /* SetAbstraction / LocalAggregation body (network/encoder/pointnext.py:52-61,97-107):
  * out[b,s,:] = max_k relu(LN(W [fea[idx[b,s,k]], (xyz[idx]-center)/radius] + bias)).
- * Wt (Cin+3, Cout) row-major = the TRANSPOSE of the Conv2d weight (Cout,Cin+3,1,1): first Cin
- * rows features, last 3 relative xyz.  LN: eps 1e-5, biased variance, affine (gamma, beta). */
+ * W (Cout, Cin+3) row-major exactly as the Conv2d weight (Cout,Cin+3,1,1): first Cin columns
+ * features, last 3 relative xyz.  LN: eps 1e-5, biased variance, affine (gamma, beta).
+ * fp32 MFMA for Cout in {32,64,128,256,512} and K in {16,32} (every shipped layer); the _generic
+ * entry is the plain-VALU kernel for any other shape (same contract). */
+int dpm_group_mlp_max_generic(const float *xyz, const float *fea, const float *centers,
+                              const int32_t *idx, const float *W, const float *bias, const float *gamma,
+                              const float *beta, int B, int N, int S, int K, int Cin, int Cout, double radius,
+                              float *out, dpm_stream_t stream);
 int dpm_group_mlp_max(const float *xyz, const float *fea, const float *centers, const int32_t *idx,
-                      const float *Wt, const float *bias, const float *gamma, const float *beta,
+                      const float *W, const float *bias, const float *gamma, const float *beta,
                       int B, int N, int S, int K, int Cin, int Cout, double radius, float *out,
                       dpm_stream_t stream);
 

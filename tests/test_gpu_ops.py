@@ -201,7 +201,8 @@ def test_three_interp_vs_oracle(ops):
 
 def test_group_mlp_max_vs_oracle(ops):
     gen = torch.Generator().manual_seed(21)
-    for (N, S, K, Cin, Cout) in [(500, 40, 32, 16, 32), (128, 16, 16, 256, 512), (300, 9, 32, 128, 256)]:
+    for (N, S, K, Cin, Cout) in [(500, 40, 32, 16, 32), (128, 16, 16, 256, 512), (300, 9, 32, 128, 256), (700, 33, 32, 32, 64),
+                                 (256, 7, 32, 64, 128), (64, 5, 16, 512, 512), (100, 6, 8, 10, 24)]:
         B = 2
         xyz, fea = torch.rand(B, N, 3, generator=gen), torch.randn(B, N, Cin, generator=gen)
         ctr = xyz[:, :S].contiguous()
@@ -210,10 +211,11 @@ def test_group_mlp_max_vs_oracle(ops):
               "m.0.bias": torch.randn(Cout, generator=gen) * 0.1,
               "m.1.ln.weight": 1 + 0.1 * torch.randn(Cout, generator=gen), "m.1.ln.bias": 0.1 * torch.randn(Cout, generator=gen)}
         want = O.grouped_mlp_max(sd, "m", 0.3, xyz, fea, ctr, idx)
-        Wt = sd["m.0.weight"].reshape(Cout, Cin + 3).t().contiguous()
-        got = ops.group_mlp_max(xyz.to(DEV), fea.to(DEV), ctr.to(DEV), idx.int().to(DEV), Wt.to(DEV), sd["m.0.bias"].to(DEV),
-                                sd["m.1.ln.weight"].to(DEV), sd["m.1.ln.bias"].to(DEV), 0.3).cpu()
-        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+        for generic in (False, True):
+            got = ops.group_mlp_max(xyz.to(DEV), fea.to(DEV), ctr.to(DEV), idx.int().to(DEV), sd["m.0.weight"].to(DEV),
+                                    sd["m.0.bias"].to(DEV), sd["m.1.ln.weight"].to(DEV), sd["m.1.ln.bias"].to(DEV), 0.3,
+                                    generic=generic).cpu()
+            torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
 
 
 def test_prepare_and_channel_first(ops):
