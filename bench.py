@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--points", type=int, default=65536)
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-pipeline", action="store_true", help="run every step start-to-finish on one stream")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time breakdown to stderr")
     args = ap.parse_args()
 
@@ -124,10 +125,21 @@ def main():
     enc_mod.ops.fps = timed_fps
 
     def step():
-        # edges stay on the device in `table` (header | information per frame); no host sync inside a step
-        desc, edges, table = hot.step(pts, pad, pcd_m, materialize=False)
-        gather_step_results(desc, table)
-        return desc, table
+        # Streaming mode (HotPath.submit): this batch's input staging + first-level FPS start on a side HIP
+        # stream and overlap with the previous batch's remaining stages on the main stream.  Edges stay on the
+        # device in `table` (header | information per frame); no host sync inside a step.
+        if args.no_pipeline:
+            desc, edges, table = hot.step(pts, pad, pcd_m, materialize=False)
+            gather_step_results(desc, table)
+            return
+        done = hot.submit(pts, pad, pcd_m)
+        if done is not None:
+            gather_step_results(*done)
+
+    def drain():  # the last submitted batch is finished INSIDE the timed region
+        done = hot.flush()
+        if done is not None:
+            gather_step_results(*done)
 
     def fence():
         torch.cuda.synchronize()
@@ -137,11 +149,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     fps_events.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -179,6 +193,7 @@ def main():
                                    "registration_forward (256x256) + information matrix per frame",
                        "frames_per_gpu_per_step": F, "points_per_frame": N,
                        "parallelism": f"frame-sharded x{world}, one RCCL gather of descriptors+edges per step",
+                       "pipeline": "none" if args.no_pipeline else "batch i+1 staging+FPS-0 on a side stream overlaps batch i",
                        "weights": "procedural (deeppointmap_amd/weights.py)"},
             "roofline": {"kernel": "fps_bucket_sort_kernel+fps_bucket_kernel (stage-0 farthest point sampling)",
                          "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -50,16 +50,33 @@ class Encoder(ParamTree):
 
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, points: torch.Tensor, points_padding: torch.Tensor, trace: Optional[dict] = None) -> List[torch.Tensor]:
+    def presample(self, points: torch.Tensor, points_padding: torch.Tensor) -> dict:
+        """Input staging + first-level farthest point sampling, on the CURRENT stream.  This part depends on
+        the raw scan only and is a 4095-round serial chain per frame that occupies one CU per frame, so a
+        streaming caller runs it for batch i+1 on a side stream while batch i finishes on the main stream
+        (pipeline.HotPath.submit).  Pass the result to forward(..., presampled=...)."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("deeppointmap_amd.Encoder runs on the GPU only: call .to('cuda') first "
+                               "(there is no CPU fallback)")
+        with torch.cuda.device(dev):
+            pts = points.to(device=dev, dtype=torch.float32).contiguous()
+            pad = points_padding.to(device=dev).contiguous()
+            xyz, lengths = ops.prepare_points(pts, pad)
+            fidx, new_xyz, new_len = ops.fps(xyz, lengths, self.encoder_cfg.npoint[0])
+        return dict(pts=pts, xyz=xyz, lengths=lengths, fidx=fidx, new_xyz=new_xyz, new_len=new_len)
+
+    @torch.no_grad()
+    def forward(self, points: torch.Tensor, points_padding: torch.Tensor, trace: Optional[dict] = None,
+                presampled: Optional[dict] = None) -> List[torch.Tensor]:
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("deeppointmap_amd.Encoder runs on the GPU only: call .to('cuda') first "
                                "(there is no CPU fallback)")
         enc = self.encoder_cfg
+        samp = presampled if presampled is not None else self.presample(points, points_padding)
         with torch.cuda.device(dev):
-            pts = points.to(device=dev, dtype=torch.float32).contiguous()
-            pad = points_padding.to(device=dev).contiguous()
-            xyz, lengths = ops.prepare_points(pts, pad)
+            pts, xyz, lengths = samp["pts"], samp["xyz"], samp["lengths"]
             if self.in_channel == 3:
                 fea = ops.linear(xyz, self.p("point_mlp0.weight"), self.p("point_mlp0.bias"))
             else:  # extra input channels: point-major copy of the first in_channel rows
@@ -70,7 +87,10 @@ class Encoder(ParamTree):
                 xyz, fea, lengths = levels[-1]
                 radii, ks = enc.radius_list[i], enc.nsample_list[i]
                 pre = f"downsampler.{i}"
-                fidx, new_xyz, new_len = ops.fps(xyz, lengths, npoint)
+                if i == 0:
+                    fidx, new_xyz, new_len = samp["fidx"], samp["new_xyz"], samp["new_len"]
+                else:
+                    fidx, new_xyz, new_len = ops.fps(xyz, lengths, npoint)
                 gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0])
                 new_fea = self._group(pre + ".sa.mlp", radii[0], xyz, fea, new_xyz, gidx)
                 if trace is not None:

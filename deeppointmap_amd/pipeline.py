@@ -37,11 +37,13 @@ class HotPath:
     def __init__(self, encoder: Encoder, decoder: Decoder, coor_scale: float = 60.0, num_sample=0.5):
         self.encoder, self.decoder = encoder, decoder
         self.coor_scale, self.num_sample = float(coor_scale), num_sample
+        self._side = None      # side HIP stream for the software pipeline (submit / flush)
+        self._pending = None
 
     @torch.no_grad()
-    def extract(self, points: torch.Tensor, padding: torch.Tensor) -> torch.Tensor:
+    def extract(self, points: torch.Tensor, padding: torch.Tensor, presampled=None) -> torch.Tensor:
         """(F,3,N) normalised scans -> unified descriptors (F,131,256): rows 0-127 feature, 128-130 xyz in metres."""
-        coor, fea, _ = self.encoder(points, padding)
+        coor, fea, _ = self.encoder(points, padding, presampled=presampled)
         return make_descriptors(coor, fea, self.coor_scale)
 
     @torch.no_grad()
@@ -80,3 +82,36 @@ class HotPath:
         F = desc.shape[0]
         edges, table = self.register(desc, pcd_m, [((f - 1) % F, f) for f in range(F)], materialize=materialize)
         return desc, edges, table
+
+    # -- streaming mode: two-stage software pipeline over consecutive batches ---------------------------
+    @torch.no_grad()
+    def submit(self, points: torch.Tensor, padding: torch.Tensor, pcd_m: Optional[torch.Tensor]):
+        """Enqueue a batch.  Its input staging + first-level FPS (one CU per frame, latency-bound) start at
+        once on a side stream; the rest of the PREVIOUS batch (remaining encoder stages, registration,
+        information matrices) is enqueued on the current stream and overlaps with it.  Returns the previous
+        batch's (desc, table) or None for the first call; flush() returns the last one.  Inputs must already
+        be ready on the device (they are read from the side stream without waiting for the current one)."""
+        dev = self.encoder.device
+        main = torch.cuda.current_stream(dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self._side):
+            pre = self.encoder.presample(points, padding)
+            ready = self._side.record_event()
+        for t in pre.values():
+            t.record_stream(main)  # produced on the side stream, consumed on the main one
+        prev, self._pending = self._pending, (pre, ready, points, padding, pcd_m)
+        return self._finish(prev) if prev is not None else None
+
+    @torch.no_grad()
+    def flush(self):
+        prev, self._pending = self._pending, None
+        return self._finish(prev) if prev is not None else None
+
+    def _finish(self, item):
+        pre, ready, points, padding, pcd_m = item
+        torch.cuda.current_stream(self.encoder.device).wait_event(ready)
+        desc = self.extract(points, padding, presampled=pre)
+        F = desc.shape[0]
+        _, table = self.register(desc, pcd_m, [((f - 1) % F, f) for f in range(F)], materialize=False)
+        return desc, table

@@ -63,3 +63,25 @@ def test_size_independent_properties(hot):
     edges, _ = hot.register(torch.stack([d0, d0]).to(DEV), None, [(0, 1)])
     assert float((edges[0].R.cpu() - torch.eye(3)).abs().max()) < 1e-4
     assert float(edges[0].T.cpu().abs().max()) < 1e-3
+
+
+def test_streaming_pipeline_equals_plain_steps(hot):
+    # submit/flush (side-stream presampling overlapped with the previous batch) must give bit-identical results
+    batches = []
+    for i in range(3):
+        pts, pad = synthetic.frames(2, 16384, start=2 * i)
+        batches.append((pts.to(DEV), pad.to(DEV), (pts * 60).to(DEV)))
+    plain = []
+    for p, m, q in batches:
+        desc, _, table = hot.step(p, m, q, materialize=False)
+        plain.append((desc.clone(), table.clone()))
+    outs = []
+    for p, m, q in batches:
+        r = hot.submit(p, m, q)
+        if r is not None:
+            outs.append(r)
+    outs.append(hot.flush())
+    assert hot.flush() is None and len(outs) == 3
+    torch.cuda.synchronize()
+    for (d0, t0), (d1, t1) in zip(plain, outs):
+        assert torch.equal(d0, d1) and torch.equal(t0, t1)
