@@ -54,6 +54,42 @@ __device__ __forceinline__ float sqdist(float sx, float sy, float sz, float x, f
     return (dx * dx + dy * dy) + dz * dz;
 }
 
+
+// ---- wave64 reductions on DPP (no LDS crossbar round trips).  After the call every lane holds the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v))));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v))));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v))));  // row_half_mirror
+    v = fmaxf(v, __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v))));  // row_mirror
+    v = fmaxf(v, __int_as_float(dpp_i<0x142, 0xA>(__float_as_int(v))));  // row_bcast:15 -> rows 1,3
+    v = fmaxf(v, __int_as_float(dpp_i<0x143, 0xC>(__float_as_int(v))));  // row_bcast:31 -> rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_dpp(int v) {
+    v = min(v, dpp_i<0xB1, 0xF>(v));
+    v = min(v, dpp_i<0x4E, 0xF>(v));
+    v = min(v, dpp_i<0x141, 0xF>(v));
+    v = min(v, dpp_i<0x140, 0xF>(v));
+    v = min(v, dpp_i<0x142, 0xA>(v));
+    v = min(v, dpp_i<0x143, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// lane holding the wave's best (largest v; among equal v the smallest idx).  Lanes that must not win pass v < 0.
+__device__ __forceinline__ int wave_argbest(float v, int idx, float &vmax) {
+    vmax = wave_max_dpp(v);
+    unsigned long long eq = __ballot(v == vmax);
+    if (__popcll(eq) > 1) {  // ties are rare: break them by the smallest original index
+        const int imin = wave_min_dpp((v == vmax) ? idx : 0x7fffffff);
+        eq = __ballot(v == vmax && idx == imin);
+    }
+    return __builtin_ctzll(eq);
+}
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int lane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
 // ------------------------------------------------------------------------------------------
 // REGISTER algorithm.  REG=false keeps `closest` in the workspace and re-reads xyz (fallback /
 // cross-check path for large N).
@@ -118,7 +154,11 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
                 if (c > best.v) best = Best{c, i};
             }
         }
-        best = wave_best(best);
+        {
+            float vmax;
+            const int L = wave_argbest(best.v, best.i, vmax);
+            best = Best{vmax, lane_i(best.i, L)};
+        }
         const int p = r & 1;
         if ((t & 63) == 0) {
             s_v[p][t >> 6] = best.v;
@@ -230,7 +270,11 @@ __global__ __launch_bounds__(FB) void fps_bucket_sort_kernel(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------
-// BUCKET algorithm, part 2: the sampling rounds
+// BUCKET algorithm, part 2: the sampling rounds.
+// Bucket b is owned by wave (b % NW), lane (b / NW): spatially adjacent buckets (consecutive b) belong to
+// different waves, so the handful of buckets a new point can change are updated by different waves in
+// parallel, each wave working only on its OWN buckets -- no work list, no atomics, and one barrier per round
+// (the cross-wave arg-max exchange, double-buffered by round parity).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict__ xyz_all,
                                                         const int32_t *__restrict__ lengths, int N, int K,
@@ -240,14 +284,8 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                                                         float *__restrict__ new_xyz_all,
                                                         int32_t *__restrict__ new_len) {
     constexpr int NW = FB / 64;
-    __shared__ float s_box[MAXBUCKETS][6];
-    __shared__ float s_bmax[MAXBUCKETS];
-    __shared__ int s_bidx[MAXBUCKETS];
-    __shared__ float s_bxyz[MAXBUCKETS][3];
-    __shared__ int s_list[MAXBUCKETS];
-    __shared__ int s_nact[2];
-    __shared__ float s_rv[NW];
-    __shared__ int s_ri[NW], s_rb[NW];
+    __shared__ float s_rv[2][NW], s_rx[2][NW], s_ry[2][NW], s_rz[2][NW];
+    __shared__ int s_ri[2][NW];
 
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float *xyz = xyz_all + (size_t)b * N * 3;
@@ -258,116 +296,80 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
     const int len = min(max(lengths[b], 0), N);
     const int kn = min(len, K);
     const int nb = (len + 63) >> 6;
+    const int my_bucket = lane * NW + w;
+    const bool mine = my_bucket < nb;
 
-    // bucket bounding boxes: wave w builds buckets w, w+NW, ...
-    for (int bk = w; bk < nb; bk += NW) {
-        const int q = bk * 64 + lane;
+    // bounding boxes of this wave's buckets, straight into the owner lane's registers
+    float bx0 = 0.f, by0 = 0.f, bz0 = 0.f, bx1 = 0.f, by1 = 0.f, bz1 = 0.f;
+    for (int l = 0; l * NW + w < nb; ++l) {
+        const int q = (l * NW + w) * 64 + lane;
         float x0 = __builtin_inff(), y0 = x0, z0 = x0, x1 = -x0, y1 = -x0, z1 = -x0;
         if (q < len) {
             const float4 p = pts[q];
             x0 = x1 = p.x, y0 = y1 = p.y, z0 = z1 = p.z;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            x0 = fminf(x0, __shfl_xor(x0, off, 64)), x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
-            y0 = fminf(y0, __shfl_xor(y0, off, 64)), y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
-            z0 = fminf(z0, __shfl_xor(z0, off, 64)), z1 = fmaxf(z1, __shfl_xor(z1, off, 64));
-        }
-        if (lane == 0) {
-            s_box[bk][0] = x0, s_box[bk][1] = y0, s_box[bk][2] = z0;
-            s_box[bk][3] = x1, s_box[bk][4] = y1, s_box[bk][5] = z1;
-        }
+        x0 = -wave_max_dpp(-x0), y0 = -wave_max_dpp(-y0), z0 = -wave_max_dpp(-z0);
+        x1 = wave_max_dpp(x1), y1 = wave_max_dpp(y1), z1 = wave_max_dpp(z1);
+        if (lane == l) bx0 = x0, by0 = y0, bz0 = z0, bx1 = x1, by1 = y1, bz1 = z1;
     }
     if (t == 0) {
-        s_nact[0] = 0, s_nact[1] = 0;
         idx[0] = 0;  // slot 0 is index 0 even for an empty frame (utils.py:249-250)
         new_xyz[0] = xyz[0], new_xyz[1] = xyz[1], new_xyz[2] = xyz[2];
         new_len[b] = max(kn, 1);
     }
-    __syncthreads();
-    const bool mine = t < nb;
-    const float bx0 = mine ? s_box[t][0] : 0.f, by0 = mine ? s_box[t][1] : 0.f, bz0 = mine ? s_box[t][2] : 0.f;
-    const float bx1 = mine ? s_box[t][3] : 0.f, by1 = mine ? s_box[t][4] : 0.f, bz1 = mine ? s_box[t][5] : 0.f;
     float bmax = __builtin_inff();  // every closest distance starts at +inf
     int bidx = 0x7fffffff;
+    float wx = 0.f, wy = 0.f, wz = 0.f;  // coordinates of this bucket's current best point
     float sx = xyz[0], sy = xyz[1], sz = xyz[2];
 
     for (int r = 1; r < kn; ++r) {
-        const int par = r & 1;
-        // ---- step 1: which buckets can change?  (box distance with the point-distance expression)
+        // ---- which of my wave's buckets can change?  box distance with the point-distance expression:
+        //      (s - clamp(s)) reproduces (s - x) monotonically, so box distance <= every point distance
         bool act = false;
         if (mine) {
-            // nearest point of the box to s, per axis; (s - clamp) reproduces (s - x) monotonically
             const float cx = fminf(fmaxf(sx, bx0), bx1), cy = fminf(fmaxf(sy, by0), by1),
                         cz = fminf(fmaxf(sz, bz0), bz1);
             act = sqdist(sx, sy, sz, cx, cy, cz) < bmax;
         }
-        const unsigned long long m = __ballot(act);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&s_nact[par], __popcll(m));
-        base = __shfl(base, 0, 64);
-        if (act) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
-        __syncthreads();  // B1: list + count complete
-        const int nact = s_nact[par];
-        // ---- step 2: update the active buckets, one wave per bucket
-        for (int a = w; a < nact; a += NW) {
-            const int bk = s_list[a];
-            const int q = bk * 64 + lane;
-            Best best{-1.f, 0x7fffffff};
-            float x = 0.f, y = 0.f, z = 0.f;
+        unsigned long long m = __ballot(act);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int q = (l * NW + w) * 64 + lane;
+            float v = -1.f, x = 0.f, y = 0.f, z = 0.f;
+            int oi = 0x7fffffff;
             if (q < len) {
                 const float4 p = pts[q];
+                oi = orig[q];
                 x = p.x, y = p.y, z = p.z;
                 const float d = sqdist(sx, sy, sz, x, y, z);
                 if (d < p.w) pts[q].w = d;
-                best = Best{fminf(d, p.w), orig[q]};
+                v = fminf(d, p.w);
             }
-            // reduce (value, original index) and remember which lane holds the winner
-            Best g = best;
-            int gl = lane;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                Best o;
-                o.v = __shfl_xor(g.v, off, 64);
-                o.i = __shfl_xor(g.i, off, 64);
-                const int ol = __shfl_xor(gl, off, 64);
-                if (o.v > g.v || (o.v == g.v && o.i < g.i)) g = o, gl = ol;
-            }
-            const float wx = __shfl(x, gl, 64), wy = __shfl(y, gl, 64), wz = __shfl(z, gl, 64);
-            if (lane == 0) {
-                s_bmax[bk] = g.v, s_bidx[bk] = g.i;
-                s_bxyz[bk][0] = wx, s_bxyz[bk][1] = wy, s_bxyz[bk][2] = wz;
-            }
+            float vmax;
+            const int L = wave_argbest(v, oi, vmax);
+            const int wi = lane_i(oi, L);
+            const float px = lane_f(x, L), py = lane_f(y, L), pz = lane_f(z, L);
+            if (lane == l) bmax = vmax, bidx = wi, wx = px, wy = py, wz = pz;
         }
-        __syncthreads();  // B2: bucket results visible
-        if (t == 0) s_nact[par] = 0;  // next use of this counter is two rounds away
-        if (act) bmax = s_bmax[t], bidx = s_bidx[t];
-        // ---- step 3: global argmax over the buckets
-        Best g{mine ? bmax : -1.f, mine ? bidx : 0x7fffffff};
-        int gb = t;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            Best o;
-            o.v = __shfl_xor(g.v, off, 64);
-            o.i = __shfl_xor(g.i, off, 64);
-            const int ob = __shfl_xor(gb, off, 64);
-            if (o.v > g.v || (o.v == g.v && o.i < g.i)) g = o, gb = ob;
-        }
-        if (lane == 0) s_rv[w] = g.v, s_ri[w] = g.i, s_rb[w] = gb;
-        __syncthreads();  // B3
-        g = Best{s_rv[0], s_ri[0]};
-        gb = s_rb[0];
+        // ---- arg-max over this wave's buckets, then across the waves
+        float vmax;
+        const int L = wave_argbest(mine ? bmax : -1.f, bidx, vmax);
+        const int par = r & 1;
+        if (lane == L) s_rv[par][w] = vmax, s_ri[par][w] = bidx, s_rx[par][w] = wx, s_ry[par][w] = wy, s_rz[par][w] = wz;
+        __syncthreads();
+        Best g{s_rv[par][0], s_ri[par][0]};
+        int gw = 0;
 #pragma unroll
         for (int k = 1; k < NW; ++k) {
-            const Best o{s_rv[k], s_ri[k]};
-            if (o.v > g.v || (o.v == g.v && o.i < g.i)) g = o, gb = s_rb[k];
+            const Best o{s_rv[par][k], s_ri[par][k]};
+            if (o.v > g.v || (o.v == g.v && o.i < g.i)) g = o, gw = k;
         }
-        sx = s_bxyz[gb][0], sy = s_bxyz[gb][1], sz = s_bxyz[gb][2];
+        sx = s_rx[par][gw], sy = s_ry[par][gw], sz = s_rz[par][gw];
         if (t == 0) {
             idx[r] = g.i;
             new_xyz[3 * r] = sx, new_xyz[3 * r + 1] = sy, new_xyz[3 * r + 2] = sz;
         }
-        // s_rv/s_ri/s_rb are rewritten only after B1 and B2 of the next round: no extra barrier
     }
     for (int r = max(kn, 1) + t; r < K; r += FB) {
         idx[r] = -1;
