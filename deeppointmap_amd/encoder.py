@@ -51,10 +51,11 @@ class Encoder(ParamTree):
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
     def presample(self, points: torch.Tensor, points_padding: torch.Tensor) -> dict:
-        """Input staging + first-level farthest point sampling, on the CURRENT stream.  This part depends on
-        the raw scan only and is a 4095-round serial chain per frame that occupies one CU per frame, so a
-        streaming caller runs it for batch i+1 on a side stream while batch i finishes on the main stream
-        (pipeline.HotPath.submit).  Pass the result to forward(..., presampled=...)."""
+        """Input staging + the whole farthest-point-sampling chain (all levels), on the CURRENT stream.
+        Sampling depends on coordinates only (level i+1 samples the points level i kept), never on features;
+        it is a serial chain of dependent rounds that occupies one CU per frame, so a streaming caller runs it
+        for batch i+1 on a side stream while batch i finishes on the main stream (pipeline.HotPath.submit).
+        Pass the result to forward(..., presampled=...)."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("deeppointmap_amd.Encoder runs on the GPU only: call .to('cuda') first "
@@ -63,8 +64,12 @@ class Encoder(ParamTree):
             pts = points.to(device=dev, dtype=torch.float32).contiguous()
             pad = points_padding.to(device=dev).contiguous()
             xyz, lengths = ops.prepare_points(pts, pad)
-            fidx, new_xyz, new_len = ops.fps(xyz, lengths, self.encoder_cfg.npoint[0])
-        return dict(pts=pts, xyz=xyz, lengths=lengths, fidx=fidx, new_xyz=new_xyz, new_len=new_len)
+            out = dict(pts=pts, xyz=xyz, lengths=lengths)
+            cur, cur_len = xyz, lengths
+            for i, npoint in enumerate(self.encoder_cfg.npoint):
+                fidx, cur, cur_len = ops.fps(cur, cur_len, npoint)
+                out[f"fidx{i}"], out[f"xyz{i}"], out[f"len{i}"] = fidx, cur, cur_len
+        return out
 
     @torch.no_grad()
     def forward(self, points: torch.Tensor, points_padding: torch.Tensor, trace: Optional[dict] = None,
@@ -87,10 +92,7 @@ class Encoder(ParamTree):
                 xyz, fea, lengths = levels[-1]
                 radii, ks = enc.radius_list[i], enc.nsample_list[i]
                 pre = f"downsampler.{i}"
-                if i == 0:
-                    fidx, new_xyz, new_len = samp["fidx"], samp["new_xyz"], samp["new_len"]
-                else:
-                    fidx, new_xyz, new_len = ops.fps(xyz, lengths, npoint)
+                fidx, new_xyz, new_len = samp[f"fidx{i}"], samp[f"xyz{i}"], samp[f"len{i}"]
                 gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0])
                 new_fea = self._group(pre + ".sa.mlp", radii[0], xyz, fea, new_xyz, gidx)
                 if trace is not None:
