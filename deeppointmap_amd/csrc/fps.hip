@@ -55,28 +55,6 @@ __device__ __forceinline__ float sqdist(float sx, float sy, float sz, float x, f
 }
 
 
-// ---- wave64 reductions on DPP (no LDS crossbar round trips).  After the call every lane holds the result.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
-
-__device__ __forceinline__ float wave_max_dpp(float v) {
-    v = fmaxf(v, __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v))));   // quad_perm [1,0,3,2]
-    v = fmaxf(v, __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v))));   // quad_perm [2,3,0,1]
-    v = fmaxf(v, __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v))));  // row_half_mirror
-    v = fmaxf(v, __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v))));  // row_mirror
-    v = fmaxf(v, __int_as_float(dpp_i<0x142, 0xA>(__float_as_int(v))));  // row_bcast:15 -> rows 1,3
-    v = fmaxf(v, __int_as_float(dpp_i<0x143, 0xC>(__float_as_int(v))));  // row_bcast:31 -> rows 2,3
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ int wave_min_dpp(int v) {
-    v = min(v, dpp_i<0xB1, 0xF>(v));
-    v = min(v, dpp_i<0x4E, 0xF>(v));
-    v = min(v, dpp_i<0x141, 0xF>(v));
-    v = min(v, dpp_i<0x140, 0xF>(v));
-    v = min(v, dpp_i<0x142, 0xA>(v));
-    v = min(v, dpp_i<0x143, 0xC>(v));
-    return __builtin_amdgcn_readlane(v, 63);
-}
 // lane holding the wave's best (largest v; among equal v the smallest idx).  Lanes that must not win pass v < 0.
 __device__ __forceinline__ int wave_argbest(float v, int idx, float &vmax) {
     vmax = wave_max_dpp(v);

@@ -57,33 +57,94 @@ __device__ __forceinline__ float exp_dist(float cx, float cy, float cz, float ca
     return ((-2.f * fmaf(cz, z, fmaf(cy, y, cx * x))) + caa) + bb;
 }
 
-// Extract the k smallest (d asc, then index asc) of cd/ci[0..count) into od/oi[0..k); entries
-// taken are overwritten with +inf.  All 64 lanes participate; k <= count.
-__device__ __forceinline__ void select_smallest(volatile float *cd, volatile int *ci, int count, int k,
-                                                volatile float *od, volatile int *oi) {
+// order-preserving map float -> int32 (signed compare): negative floats reversed, positives kept
+__device__ __forceinline__ int fkey(float d) {
+    const int u = __float_as_int(d);
+    return u >= 0 ? u : (u ^ 0x7fffffff);
+}
+
+// Select the K smallest of the C > K candidates cd/ci[0..C) (distance, then index).  The result is written
+// UNSORTED to od/oi[0..K) (downstream is a max-pool; only slot 0 matters and is fixed up by the caller).
+// Returns the K-th smallest distance; *tie is set when the K-th and (K+1)-th distances are bit-equal.
+// Bitwise search for the K-th smallest key with ballots: 32 steps x ceil(C/64) compares per lane, instead of
+// K rounds of arg-min extraction.
+__device__ __forceinline__ float select_k(volatile float *cd, volatile int *ci, int C, int K, volatile float *od,
+                                          volatile int *oi, bool *tie) {
     const int lane = lane_id();
-    for (int r = 0; r < k; ++r) {
-        float bd = __builtin_inff();
-        int bi = 0x7fffffff, bp = -1;
-        for (int p = lane; p < count; p += 64) {
-            const float d = cd[p];
-            const int i = ci[p];
-            if (d < bd || (d == bd && i < bi)) bd = d, bi = i, bp = p;
-        }
+    constexpr int R = 4;  // keys cached in registers per lane (C <= 256); the rest is re-read from LDS
+    int kr[R];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float od_ = __shfl_xor(bd, off, 64);
-            const int oi_ = __shfl_xor(bi, off, 64);
-            const int op_ = __shfl_xor(bp, off, 64);
-            if (od_ < bd || (od_ == bd && oi_ < bi)) bd = od_, bi = oi_, bp = op_;
-        }
-        if (lane == 0) {
-            od[r] = bd;
-            oi[r] = bi;
-            if (bp >= 0) cd[bp] = __builtin_inff();
-        }
-        wave_mem_sync();
+    for (int j = 0; j < R; ++j) {
+        const int p = lane + 64 * j;
+        kr[j] = p < C ? fkey(cd[p]) : 0x7fffffff;
     }
+    auto count_lt = [&](int probe) -> int {  // wave-uniform number of candidates with key < probe
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) c += __popcll(__ballot(kr[j] < probe && lane + 64 * j < C));
+        for (int p = lane + 64 * R; p < ((C + 63) & ~63); p += 64)
+            c += __popcll(__ballot(p < C && fkey(cd[p]) < probe));
+        return c;
+    };
+    // t = largest value with count(key < t) < K  ==  the K-th smallest key.  Keys are compared as signed ints,
+    // so search in the biased domain (key ^ 0x80000000 is unsigned-monotone).
+    unsigned tb = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = tb | (1u << bit);
+        if (count_lt((int)(cand ^ 0x80000000u)) < K) tb = cand;
+    }
+    const int t = (int)(tb ^ 0x80000000u);
+    const int c_lt = count_lt(t);
+    const int need = K - c_lt;  // >= 1 entries equal to t are taken
+    int c_eq = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) c_eq += __popcll(__ballot(kr[j] == t && lane + 64 * j < C));
+    for (int p = lane + 64 * R; p < ((C + 63) & ~63); p += 64) c_eq += __popcll(__ballot(p < C && fkey(cd[p]) == t));
+    *tie = c_eq > need;
+    // emit: everything below t, then `need` of the entries equal to t (smallest indices first when tied)
+    const unsigned long long ltm = (1ull << lane) - 1ull;
+    int base = 0, eq_taken = 0;
+    int last_idx = -1;
+    for (int p0 = 0; p0 < C; p0 += 64) {
+        const int p = p0 + lane;
+        const bool ok = p < C;
+        const float d = ok ? cd[p] : 0.f;
+        const int k = ok ? fkey(d) : 0x7fffffff;
+        const bool lt = ok && k < t;
+        const unsigned long long m = __ballot(lt);
+        if (lt) od[base + __popcll(m & ltm)] = d, oi[base + __popcll(m & ltm)] = ci[p];
+        base += __popcll(m);
+        if (!*tie) {
+            const bool eq = ok && k == t;
+            const unsigned long long me = __ballot(eq);
+            if (eq) od[c_lt + eq_taken + __popcll(me & ltm)] = d, oi[c_lt + eq_taken + __popcll(me & ltm)] = ci[p];
+            eq_taken += __popcll(me);
+        }
+    }
+    if (*tie) {  // rare: take the `need` smallest indices among the equal ones
+        for (int n = 0; n < need; ++n) {
+            int best = 0x7fffffff;
+            for (int p = lane; p < C; p += 64) {
+                const int i = ci[p];
+                if (fkey(cd[p]) == t && i > last_idx && i < best) best = i;
+            }
+            best = wave_min_dpp(best);
+            if (lane == 0) od[c_lt + n] = cd[0] * 0.f, oi[c_lt + n] = best;
+            last_idx = best;
+        }
+    }
+    wave_mem_sync();
+    // the K-th smallest distance itself (value of key t): read it back from any entry equal to t
+    float kth = 0.f;
+    {
+        float v = -__builtin_inff();
+        for (int p = lane; p < C; p += 64)
+            if (fkey(cd[p]) == t) v = cd[p];
+        kth = wave_max_dpp(v);
+    }
+    if (*tie && lane < need) od[c_lt + lane] = kth;
+    wave_mem_sync();
+    return kth;
 }
 
 // libstdc++ __adjust_heap + __push_heap on (value, index) pairs ordered by value only
@@ -179,14 +240,15 @@ __device__ __forceinline__ void offer(Ctr &c, bool ok, float x, float y, float z
     c.cnt += __popcll(m);
     if (c.cnt > CAP - 64) {  // compact: keep the K smallest, tighten the admission bound
         wave_mem_sync();
-        const int k = min(K, c.cnt), k1 = min(K + 1, c.cnt);
-        select_smallest(cd, ci, c.cnt, k1, td, ti);  // one extra: is there a tie across the K-th slot?
-        if (k1 > K && td[K] == td[K - 1]) c.tie = true;
-        wave_mem_sync();
-        if (lane < k) cd[lane] = td[lane], ci[lane] = ti[lane];
-        wave_mem_sync();
-        c.cnt = k;
-        if (k == K) c.thr = fminf(c.thr, td[K - 1]);
+        if (c.cnt > K) {
+            bool tie = false;
+            const float kth = select_k(cd, ci, c.cnt, K, td, ti, &tie);
+            c.tie |= tie;
+            if (lane < K) cd[lane] = td[lane], ci[lane] = ti[lane];
+            wave_mem_sync();
+            c.cnt = K;
+            c.thr = fminf(c.thr, kth);
+        }
     }
 }
 
@@ -206,9 +268,26 @@ __device__ __forceinline__ void finish(Ctr &c, const float *__restrict__ pts, in
         if (od_ < nd || (od_ == nd && oi_ < ni)) nd = od_, ni = oi_;
     }
     if (ni == 0x7fffffff) ni = 0;  // empty frame
-    const int k = min(K, c.cnt), k1 = min(K + 1, c.cnt);
-    select_smallest(cd, ci, c.cnt, k1, td, ti);
-    if (k1 > K && td[K] == td[K - 1]) c.tie = true;
+    // nearest candidate (slot 0): smallest distance, then smallest index
+    int first = ni;
+    if (c.cnt > 0) {
+        int kmin = 0x7fffffff;
+        for (int p = lane; p < c.cnt; p += 64) kmin = min(kmin, fkey(cd[p]));
+        kmin = wave_min_dpp(kmin);
+        int imin = 0x7fffffff;
+        for (int p = lane; p < c.cnt; p += 64)
+            if (fkey(cd[p]) == kmin) imin = min(imin, ci[p]);
+        first = wave_min_dpp(imin);
+    }
+    const int k = min(K, c.cnt);
+    if (c.cnt > K) {
+        bool tie = false;
+        select_k(cd, ci, c.cnt, K, td, ti, &tie);
+        c.tie |= tie;
+    } else {
+        for (int p = lane; p < c.cnt; p += 64) ti[p] = ci[p];
+        wave_mem_sync();
+    }
     const bool heap_regime = (long long)K * 64 <= (long long)N;  // torch.topk: partial_sort vs nth_element
     if (c.tie && heap_regime && len >= K) {
         // boundary tie: reproduce the reference's choice exactly (rare, sequential)
@@ -233,8 +312,14 @@ __device__ __forceinline__ void finish(Ctr &c, const float *__restrict__ pts, in
         if (lane == 0) outv = mi;
         if (lane < K) out[lane] = outv;
     } else {
-        const int first = (k > 0) ? ti[0] : ni;
-        if (lane < K) out[lane] = (lane < k) ? ti[lane] : first;
+        // unsorted selection: put the nearest point into slot 0 by swapping it with whatever sits there
+        int outv = (lane < k) ? ti[lane] : first;
+        const unsigned long long hm = __ballot(lane < k && outv == first);
+        const int L = hm ? __builtin_ctzll(hm) : 0;
+        const int v0 = __shfl(outv, 0, 64);
+        if (lane == L) outv = v0;
+        if (lane == 0) outv = first;
+        if (lane < K) out[lane] = outv;
     }
     wave_mem_sync();
 }
