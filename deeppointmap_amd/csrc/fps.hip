@@ -55,6 +55,11 @@ __device__ __forceinline__ float sqdist(float sx, float sy, float sz, float x, f
 }
 
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for the round
+// trip of every outstanding global store; in the sampling loops global data is wave-private (or written once and
+// read after the kernel), so only the LDS exchange needs ordering.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // lane holding the wave's best (largest v; among equal v the smallest idx).  Lanes that must not win pass v < 0.
 __device__ __forceinline__ int wave_argbest(float v, int idx, float &vmax) {
     vmax = wave_max_dpp(v);
@@ -79,8 +84,11 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
                                                     float *__restrict__ new_xyz_all,
                                                     int32_t *__restrict__ new_len, float *__restrict__ cd_ws) {
     constexpr int NW = BLOCK / 64;
-    __shared__ float s_v[2][NW];
+    constexpr int OB = 1024;  // picks buffered in LDS between flushes
+    __shared__ float s_v[2][NW], s_x[2][NW], s_y[2][NW], s_z[2][NW];
     __shared__ int s_i[2][NW];
+    __shared__ int s_oidx[OB];
+    __shared__ float s_oxyz[OB][3];
     const int b = blockIdx.x, t = threadIdx.x;
     const float *xyz = xyz_all + (size_t)b * N * 3;
     int32_t *idx = idx_all + (size_t)b * K;
@@ -112,9 +120,10 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
         new_xyz[2] = xyz[2];
         new_len[b] = max(kn, 1);
     }
+    float sx = xyz[0], sy = xyz[1], sz = xyz[2];
     for (int r = 1; r < kn; ++r) {
-        const float sx = xyz[3 * cur], sy = xyz[3 * cur + 1], sz = xyz[3 * cur + 2];
         Best best{-1.f, 0x7fffffff};
+        float bx = 0.f, by = 0.f, bz = 0.f;  // coordinates of this thread's best point
         if (REG) {
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
@@ -122,36 +131,46 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
                 if (i < len) {
                     const float c = fminf(sqdist(sx, sy, sz, px[j], py[j], pz[j]), cd[j]);
                     cd[j] = c;
-                    if (c > best.v) best = Best{c, i};  // ascending i: strict > keeps the first maximum
+                    if (c > best.v) best = Best{c, i}, bx = px[j], by = py[j], bz = pz[j];  // strict >: first maximum
                 }
             }
         } else {
             for (int i = t; i < len; i += BLOCK) {
-                const float c = fminf(sqdist(sx, sy, sz, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]), cdg[i]);
+                const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+                const float c = fminf(sqdist(sx, sy, sz, x, y, z), cdg[i]);
                 cdg[i] = c;
-                if (c > best.v) best = Best{c, i};
+                if (c > best.v) best = Best{c, i}, bx = x, by = y, bz = z;
             }
         }
-        {
-            float vmax;
-            const int L = wave_argbest(best.v, best.i, vmax);
-            best = Best{vmax, lane_i(best.i, L)};
-        }
+        const int lane = t & 63;
+        float vmax;
+        const int L = wave_argbest(best.v, best.i, vmax);
         const int p = r & 1;
-        if ((t & 63) == 0) {
-            s_v[p][t >> 6] = best.v;
-            s_i[p][t >> 6] = best.i;
-        }
-        __syncthreads();
-        Best g{s_v[p][0], s_i[p][0]};
-#pragma unroll
-        for (int w = 1; w < NW; ++w) g = better(g, Best{s_v[p][w], s_i[p][w]});
-        cur = g.i;
+        if (lane == L) s_v[p][t >> 6] = vmax, s_i[p][t >> 6] = best.i, s_x[p][t >> 6] = bx, s_y[p][t >> 6] = by, s_z[p][t >> 6] = bz;
+        if (NW > 1) lds_barrier();
+        // every lane reads entry (lane % NW); the best of the NW entries is found with a DPP max + ballot
+        const int e = lane & (NW - 1);
+        const float ev = s_v[p][e];
+        const int ei = s_i[p][e];
+        const float ex = s_x[p][e], ey = s_y[p][e], ez = s_z[p][e];
+        float gv;
+        const int gl = wave_argbest(ev, ei, gv);
+        cur = lane_i(ei, gl);
+        sx = lane_f(ex, gl), sy = lane_f(ey, gl), sz = lane_f(ez, gl);
         if (t == 0) {
-            idx[r] = cur;
-            new_xyz[3 * r] = xyz[3 * cur];
-            new_xyz[3 * r + 1] = xyz[3 * cur + 1];
-            new_xyz[3 * r + 2] = xyz[3 * cur + 2];
+            const int o = r & (OB - 1);
+            s_oidx[o] = cur, s_oxyz[o][0] = sx, s_oxyz[o][1] = sy, s_oxyz[o][2] = sz;
+        }
+        if ((r & (OB - 1)) == OB - 1 || r == kn - 1) {  // flush the buffered picks (uniform condition)
+            __syncthreads();
+            const int r0 = r & ~(OB - 1);
+            for (int q = r0 + t; q <= r; q += BLOCK) {
+                if (q == 0) continue;
+                const int o = q & (OB - 1);
+                idx[q] = s_oidx[o];
+                new_xyz[3 * q] = s_oxyz[o][0], new_xyz[3 * q + 1] = s_oxyz[o][1], new_xyz[3 * q + 2] = s_oxyz[o][2];
+            }
+            __syncthreads();
         }
     }
     // padding: -1 / zeros where the frame has fewer than K valid points
@@ -262,8 +281,11 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                                                         float *__restrict__ new_xyz_all,
                                                         int32_t *__restrict__ new_len) {
     constexpr int NW = FB / 64;
+    constexpr int OB = 2048;  // picks buffered in LDS between flushes to global memory
     __shared__ float s_rv[2][NW], s_rx[2][NW], s_ry[2][NW], s_rz[2][NW];
     __shared__ int s_ri[2][NW];
+    __shared__ int s_oidx[OB];
+    __shared__ float s_oxyz[OB][3];
 
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float *xyz = xyz_all + (size_t)b * N * 3;
@@ -310,43 +332,77 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
             act = sqdist(sx, sy, sz, cx, cy, cz) < bmax;
         }
         unsigned long long m = __ballot(act);
+#ifdef DPM_FPS_STATS
+        if (lane == 0 && m) atomicAdd(&((unsigned long long *)pts_all)[-1 - (b & 0)], (unsigned long long)__popcll(m)), atomicMax(&((int *)pts_all)[-4], __popcll(m));
+#endif
+        // two buckets per iteration: both global loads are in flight before either reduction starts
         while (m) {
-            const int l = __builtin_ctzll(m);
+            const int l0 = __builtin_ctzll(m);
             m &= m - 1;
-            const int q = (l * NW + w) * 64 + lane;
-            float v = -1.f, x = 0.f, y = 0.f, z = 0.f;
-            int oi = 0x7fffffff;
-            if (q < len) {
-                const float4 p = pts[q];
-                oi = orig[q];
-                x = p.x, y = p.y, z = p.z;
-                const float d = sqdist(sx, sy, sz, x, y, z);
-                if (d < p.w) pts[q].w = d;
-                v = fminf(d, p.w);
+            const bool two = m != 0;
+            const int l1 = two ? __builtin_ctzll(m) : l0;
+            if (two) m &= m - 1;
+            const int q0 = (l0 * NW + w) * 64 + lane, q1 = (l1 * NW + w) * 64 + lane;
+            const bool ok0 = q0 < len, ok1 = two && q1 < len;
+            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+            int o0 = 0x7fffffff, o1 = 0x7fffffff;
+            if (ok0) p0 = pts[q0], o0 = orig[q0];
+            if (ok1) p1 = pts[q1], o1 = orig[q1];
+            float v0 = -1.f, v1 = -1.f;
+            if (ok0) {
+                const float d = sqdist(sx, sy, sz, p0.x, p0.y, p0.z);
+                if (d < p0.w) pts[q0].w = d;
+                v0 = fminf(d, p0.w);
             }
-            float vmax;
-            const int L = wave_argbest(v, oi, vmax);
-            const int wi = lane_i(oi, L);
-            const float px = lane_f(x, L), py = lane_f(y, L), pz = lane_f(z, L);
-            if (lane == l) bmax = vmax, bidx = wi, wx = px, wy = py, wz = pz;
+            if (ok1) {
+                const float d = sqdist(sx, sy, sz, p1.x, p1.y, p1.z);
+                if (d < p1.w) pts[q1].w = d;
+                v1 = fminf(d, p1.w);
+            }
+            {
+                float vmax;
+                const int L = wave_argbest(v0, o0, vmax);
+                const int wi = lane_i(o0, L);
+                const float px = lane_f(p0.x, L), py = lane_f(p0.y, L), pz = lane_f(p0.z, L);
+                if (lane == l0) bmax = vmax, bidx = wi, wx = px, wy = py, wz = pz;
+            }
+            if (two) {
+                float vmax;
+                const int L = wave_argbest(v1, o1, vmax);
+                const int wi = lane_i(o1, L);
+                const float px = lane_f(p1.x, L), py = lane_f(p1.y, L), pz = lane_f(p1.z, L);
+                if (lane == l1) bmax = vmax, bidx = wi, wx = px, wy = py, wz = pz;
+            }
         }
         // ---- arg-max over this wave's buckets, then across the waves
         float vmax;
         const int L = wave_argbest(mine ? bmax : -1.f, bidx, vmax);
         const int par = r & 1;
         if (lane == L) s_rv[par][w] = vmax, s_ri[par][w] = bidx, s_rx[par][w] = wx, s_ry[par][w] = wy, s_rz[par][w] = wz;
-        __syncthreads();
-        Best g{s_rv[par][0], s_ri[par][0]};
-        int gw = 0;
-#pragma unroll
-        for (int k = 1; k < NW; ++k) {
-            const Best o{s_rv[par][k], s_ri[par][k]};
-            if (o.v > g.v || (o.v == g.v && o.i < g.i)) g = o, gw = k;
-        }
-        sx = s_rx[par][gw], sy = s_ry[par][gw], sz = s_rz[par][gw];
+        lds_barrier();
+        // every lane reads entry (lane & 15); the best of the 16 is found with a DPP max + ballot
+        const int e = lane & (NW - 1);
+        const float ev = s_rv[par][e];
+        const int ei = s_ri[par][e];
+        const float ex = s_rx[par][e], ey = s_ry[par][e], ez = s_rz[par][e];
+        float gv;
+        const int gl = wave_argbest(ev, ei, gv);
+        const int gi = lane_i(ei, gl);
+        sx = lane_f(ex, gl), sy = lane_f(ey, gl), sz = lane_f(ez, gl);
         if (t == 0) {
-            idx[r] = g.i;
-            new_xyz[3 * r] = sx, new_xyz[3 * r + 1] = sy, new_xyz[3 * r + 2] = sz;
+            const int o = r & (OB - 1);
+            s_oidx[o] = gi, s_oxyz[o][0] = sx, s_oxyz[o][1] = sy, s_oxyz[o][2] = sz;
+        }
+        if ((r & (OB - 1)) == OB - 1 || r == kn - 1) {  // flush the buffered picks (uniform condition)
+            __syncthreads();
+            const int r0 = r & ~(OB - 1);
+            for (int q = r0 + t; q <= r; q += FB) {
+                if (q == 0) continue;  // slot 0 was written up front
+                const int o = q & (OB - 1);
+                idx[q] = s_oidx[o];
+                new_xyz[3 * q] = s_oxyz[o][0], new_xyz[3 * q + 1] = s_oxyz[o][1], new_xyz[3 * q + 2] = s_oxyz[o][2];
+            }
+            __syncthreads();
         }
     }
     for (int r = max(kn, 1) + t; r < K; r += FB) {
@@ -368,7 +424,7 @@ int launch(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_
 extern "C" size_t dpm_fps_workspace_bytes(int B, int N, int K) {
     (void)K;
     // float4 sorted points (closest in .w) + int32 original ids, per frame
-    return (size_t)B * (size_t)N * (sizeof(float4) + sizeof(int32_t)) + 256;
+    return (size_t)B * (size_t)N * (sizeof(float4) + sizeof(int32_t)) + 512;
 }
 
 extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
@@ -382,8 +438,11 @@ extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N
     if (algo == 2) {
         if (N > 64 * MAXBUCKETS) return DPM_EUNSUPPORTED;
         DPM_CHECK_ARG(workspace != nullptr);
-        uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+        uintptr_t p = (((uintptr_t)workspace + 255) & ~(uintptr_t)255) + 256;  // 256 B of debug counters in front
         float4 *pts = (float4 *)p;
+#ifdef DPM_FPS_STATS
+        (void)hipMemsetAsync((void *)(p - 256), 0, 256, st);
+#endif
         int32_t *orig = (int32_t *)(pts + (size_t)B * N);
         hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, pts, orig);
         hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, orig, idx,
