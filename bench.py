@@ -38,6 +38,23 @@ def fps0_algorithmic_bytes(n_points: int, k: int) -> int:
     return n_points * 12 + k * 4 + k * 12
 
 
+def pmc_traffic_bytes(frames_per_launch: int):
+    """HBM-side bytes per launch of the roofline kernel pair, from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json; collected with separate --pmc FETCH_SIZE / WRITE_SIZE runs and corrected as
+    MI355X_MICROARCH.md prescribes).  None if the file is missing or was taken at another batch size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            j = json.load(f)
+        if j.get("frames_per_launch") != frames_per_launch:
+            return None
+        tot = 0
+        for k in ("fps_bucket_kernel", "fps_bucket_sort_kernel"):
+            tot += (2 * j[k]["FETCH_SIZE_KB"] + j[k]["WRITE_SIZE_KB"]) * 1024
+        return int(tot)
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_frames: int, n_points: int, threads: int):
     """The oracle (CPU restatement, oracle/dpm_oracle.py) on a bounded sample of the same workload."""
     from oracle import dpm_oracle as O
@@ -84,12 +101,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    # one rank per GPU; DPM_BENCH_BACKEND=gloo (+ ranks folded onto the visible GPUs) exists only to dry-run the
+    # N>1 code path on a single-GPU box
+    backend = os.environ.get("DPM_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from deeppointmap_amd import ops, synthetic
     from deeppointmap_amd.config import default_args
@@ -193,15 +217,17 @@ def main():
                                    "registration_forward (256x256) + information matrix per frame",
                        "frames_per_gpu_per_step": F, "points_per_frame": N,
                        "parallelism": f"frame-sharded x{world}, one RCCL gather of descriptors+edges per step",
-                       "pipeline": "none" if args.no_pipeline else "batch i+1 staging+FPS-0 on a side stream overlaps batch i",
+                       "pipeline": "none" if args.no_pipeline else "batch i+1 staging + FPS chain on a side HIP stream overlaps batch i",
                        "weights": "procedural (deeppointmap_amd/weights.py)"},
             "roofline": {"kernel": "fps_bucket_sort_kernel+fps_bucket_kernel (stage-0 farthest point sampling)",
                          "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / (HBM_PEAK / 1e9), 6), "traffic": None,
+                         "frac": round(achieved / (HBM_PEAK / 1e9), 6), "traffic": pmc_traffic_bytes(F),
                          "avg_launch_ms": round(fps_ms, 4), "algorithmic_bytes_per_launch": alg,
                          "whole_path_frac": round(value / world * B_ALG_FRAME / HBM_PEAK, 6),
-                         "note": "FPS is a chain of 4095 dependent argmax rounds per frame: latency-bound by "
-                                 "construction, see DESIGN.md"},
+                         "us_per_round": round(fps_ms * 1e3 / (cfg.encoder.npoint[0] - 1), 3),
+                         "note": "FPS is a chain of 4095 dependent argmax rounds per frame, one CU per frame: latency-"
+                                 "bound by construction (us_per_round is the figure that matters); traffic > algorithmic "
+                                 "bytes because each round re-reads the ~12 buckets the new point can change; see DESIGN.md"},
         }
         if world == 1 and args.cpu_frames > 0:
             # torch's intra-op pool stops scaling (and then collapses) well below the box's core count on

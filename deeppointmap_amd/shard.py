@@ -34,6 +34,9 @@ def gather_to_root(t: torch.Tensor, root: int = 0) -> Optional[torch.Tensor]:
         return t
     world, rank = dist.get_world_size(), dist.get_rank()
     t = t.contiguous()
+    if t.is_cuda and dist.get_backend() == "gloo":  # dry-run backend: gloo gathers host tensors only
+        out = gather_to_root(t.cpu(), root)
+        return out.to(t.device) if out is not None else None
     if rank == root:
         out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         dist.gather(t, gather_list=list(out.unbind(0)), dst=root)
