@@ -27,70 +27,137 @@ __global__ __launch_bounds__(256) void posemb_kernel(const float *__restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------
-// a12 attention core: out[b,m,h*32:(h+1)*32] = softmax(q k^T / sqrt(32)) v, head dim 32.
-// One workgroup = 16 queries x 16 key-lanes of one (batch, head); every thread runs an
-// independent online softmax over its keys, merged across the 16 key-lanes at the end.
+// a12 attention core on the matrix cores: out[b,m,h*32:(h+1)*32] = softmax(q k^T / sqrt(32)) v, head dim 32.
+// Flash-attention structure in exact fp32 (v_mfma_f32_16x16x4_f32): one workgroup = 64 queries of one
+// (batch, head), one wave = 16 queries.  Per 64-key tile: S = Q K^T (Q fragments stay in registers; K tile
+// in LDS as the B operand), online softmax on the C-layout registers (row statistics via DPP row
+// reductions), P transposed through a per-wave LDS tile into the A-operand layout, O += P V.
 // ------------------------------------------------------------------------------------------
 constexpr int HD = 32;
 constexpr int RES_HDR = 20;  // floats before the inlier-confidence list in a Kabsch `result`
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// max / sum over the 16 lanes of a DPP row (lanes sharing lane>>4)
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v))));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v)));
+    v += __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v)));
+    v += __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v)));
+    v += __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v)));
+    return v;
+}
+
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
                                                         const float *__restrict__ Kp, int ldk, long long sk,
                                                         const float *__restrict__ V, int ldv, long long sv,
                                                         float *__restrict__ O, int ldo, long long so, int M,
                                                         int N, float scale) {
-    __shared__ float Ks[64][HD + 1];
-    __shared__ float Vs[64][HD + 1];
-    const int b = blockIdx.z, h = blockIdx.y, t = threadIdx.x;
-    const int qi = t >> 4, kl = t & 15;
-    const int m = blockIdx.x * 16 + qi;
-    const float *q = Q + (size_t)b * sq + (size_t)min(m, M - 1) * ldq + h * HD;
-    float qr[HD], acc[HD];
+    constexpr int TK = 64;                 // keys per tile
+    __shared__ float Ks[TK][HD + 2];       // B operand of S = Q K^T: B[k=d][j=key] = Ks[key][d]
+    __shared__ float Vs[TK][HD + 16];      // B operand of O = P V:   B[k=key][j=d] = Vs[key][d]
+    __shared__ float Ps[4][16][TK + 2];    // per wave: P in row-major, re-read in the A-operand layout
+    const int b = blockIdx.z, h = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int q0 = blockIdx.x * 64 + w * 16;
+    const float *Qb = Q + (size_t)b * sq + h * HD;
+    const float *Kb = Kp + (size_t)b * sk + h * HD;
+    const float *Vb = V + (size_t)b * sv + h * HD;
+
+    // Q fragments (A operand: A[i=lane&15][k=lane>>4]) for the 8 k-steps of d = 32, pre-scaled
+    float qa[HD / 4];
+    {
+        const int qr = min(q0 + (lane & 15), M - 1);
 #pragma unroll
-    for (int d = 0; d < HD; ++d) qr[d] = q[d] * scale, acc[d] = 0.f;
-    float mx = -__builtin_inff(), l = 0.f;
-    for (int n0 = 0; n0 < N; n0 += 64) {
+        for (int ks = 0; ks < HD / 4; ++ks) qa[ks] = Qb[(size_t)qr * ldq + ks * 4 + (lane >> 4)] * scale;
+    }
+    f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float mrow[4], lrow[4];  // running max / sum of the 4 rows this lane holds ((lane>>4)*4 + q)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mrow[q] = -__builtin_inff(), lrow[q] = 0.f;
+
+    for (int n0 = 0; n0 < N; n0 += TK) {
         __syncthreads();
-        for (int e = t; e < 64 * HD; e += 256) {
-            const int kr = e >> 5, d = e & 31;
-            const bool ok = n0 + kr < N;
-            Ks[kr][d] = ok ? Kp[(size_t)b * sk + (size_t)(n0 + kr) * ldk + h * HD + d] : 0.f;
-            Vs[kr][d] = ok ? V[(size_t)b * sv + (size_t)(n0 + kr) * ldv + h * HD + d] : 0.f;
+        // stage K and V tiles: 64 rows x 32 floats each = 512 float4 per matrix, 2 per thread
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int e = t + p * 256, kr = e >> 3, c4 = (e & 7) * 4;
+            float kv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (n0 + kr < N) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    kv[j] = Kb[(size_t)(n0 + kr) * ldk + c4 + j];
+                    vv[j] = Vb[(size_t)(n0 + kr) * ldv + c4 + j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Ks[kr][c4 + j] = kv[j], Vs[kr][c4 + j] = vv[j];
         }
         __syncthreads();
+        // S tile: 16 queries x 64 keys = 4 MFMA blocks, 8 k-steps each
+        f32x4 sacc[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kr = kl + 16 * j;
-            if (n0 + kr >= N) continue;
-            float s = 0.f;
+        for (int j = 0; j < 4; ++j) sacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int d = 0; d < HD; ++d) s = fmaf(qr[d], Ks[kr][d], s);
-            const float nm = fmaxf(mx, s);
-            const float corr = __expf(mx - nm), p = __expf(s - nm);
-            l = fmaf(l, corr, p);
+        for (int ks = 0; ks < HD / 4; ++ks) {
 #pragma unroll
-            for (int d = 0; d < HD; ++d) acc[d] = fmaf(acc[d], corr, p * Vs[kr][d]);
-            mx = nm;
+            for (int j = 0; j < 4; ++j) {
+                const float bk = Ks[j * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+                sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[ks], bk, sacc[j], 0, 0, 0);
+            }
+        }
+        // mask keys beyond N, online softmax per row (row = (lane>>4)*4 + q, key = j*16 + (lane&15))
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n0 + j * 16 + (lane & 15) >= N) sacc[j] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float mx = fmaxf(fmaxf(sacc[0][q], sacc[1][q]), fmaxf(sacc[2][q], sacc[3][q]));
+            mx = row16_max(mx);
+            const float nm = fmaxf(mrow[q], mx);
+            const float corr = __expf(mrow[q] - nm);  // exp(-inf) = 0 on the first tile
+            float ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pv = __expf(sacc[j][q] - nm);
+                sacc[j][q] = pv;
+                ps += pv;
+            }
+            ps = row16_sum(ps);
+            lrow[q] = lrow[q] * corr + ps;
+            mrow[q] = nm;
+            oacc[0][q] *= corr, oacc[1][q] *= corr;
+        }
+        // P (C layout) -> LDS row-major -> A layout
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ps[w][(lane >> 4) * 4 + q][j * 16 + (lane & 15)] = sacc[j][q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: same-wave LDS ordering is enough
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < TK / 4; ++ks) {
+            const float pa = Ps[w][lane & 15][ks * 4 + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bv = Vs[ks * 4 + (lane >> 4)][j * 16 + (lane & 15)];
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, bv, oacc[j], 0, 0, 0);
+            }
         }
     }
-    // merge the 16 key-lanes of this query (lanes qi*16 .. qi*16+15 are contiguous in the wave)
+    // O: row = (lane>>4)*4 + q, column j*16 + (lane&15)
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
-        const float om = __shfl_xor(mx, off, 64), ol = __shfl_xor(l, off, 64);
-        const float nm = fmaxf(mx, om);
-        const float ca = (mx == -__builtin_inff()) ? 0.f : __expf(mx - nm);
-        const float cb = (om == -__builtin_inff()) ? 0.f : __expf(om - nm);
-        l = l * ca + ol * cb;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) acc[d] = acc[d] * ca + __shfl_xor(acc[d], off, 64) * cb;
-        mx = nm;
-    }
-    if (m < M) {
+    for (int q = 0; q < 4; ++q) {
+        const int m = q0 + (lane >> 4) * 4 + q;
+        if (m >= M) continue;
+        const float inv = 1.f / lrow[q];
         float *o = O + (size_t)b * so + (size_t)m * ldo + h * HD;
-        const float inv = 1.f / l;
-        // 16 lanes hold the same result: lane kl writes columns kl and kl+16 (static register indexing)
-#pragma unroll
-        for (int d = 0; d < HD; ++d)
-            if (d == kl || d == kl + 16) o[d] = acc[d] * inv;
+        o[lane & 15] = oacc[0][q] * inv;
+        o[16 + (lane & 15)] = oacc[1][q] * inv;
     }
 }
 
@@ -620,7 +687,7 @@ extern "C" int dpm_attention(const float *Q, int ldq, long long sq, const float 
                              int N, int heads, int head_dim, dpm_stream_t stream) {
     DPM_CHECK_ARG(Q && K && V && out && B >= 1 && M >= 1 && N >= 1 && heads >= 1);
     if (head_dim != HD) return DPM_EUNSUPPORTED;
-    hipLaunchKernelGGL(attention_kernel, dim3(dpm_cdiv(M, 16), heads, B), dim3(256), 0, (hipStream_t)stream, Q, ldq, sq,
+    hipLaunchKernelGGL(attention_kernel, dim3(dpm_cdiv(M, 64), heads, B), dim3(256), 0, (hipStream_t)stream, Q, ldq, sq,
                        K, ldk, sk, V, ldv, sv, out, ldo, so, M, N, (float)(1.0 / sqrt((double)head_dim)));
     return dpm_launch_status();
 }
