@@ -20,8 +20,8 @@
 //    distance >= its current max cannot change and is skipped -- the surviving ("active")
 //    buckets are the only global-memory traffic of the round.  Results are identical to brute
 //    force, bit for bit, including the first-index tie rule (buckets track the smallest
-//    original index among their maxima).  `closest` lives in the w component of the sorted
-//    float4 array in the caller's workspace.
+//    original index among their maxima).  The caller's workspace holds the sorted read-only
+//    float4 (x, y, z, original index) array and the running `closest` array.
 #include "dpm_common.h"
 
 #pragma clang fp contract(off)
@@ -200,14 +200,14 @@ __device__ __forceinline__ unsigned morton2_6(unsigned x, unsigned y) {
 __global__ __launch_bounds__(FB) void fps_bucket_sort_kernel(const float *__restrict__ xyz_all,
                                                              const int32_t *__restrict__ lengths, int N,
                                                              float4 *__restrict__ pts_all,
-                                                             int32_t *__restrict__ orig_all) {
+                                                             float *__restrict__ closest_all) {
     __shared__ int s_hist[CELLS];
     __shared__ float s_red[4][FB / 64];
     __shared__ int s_wsum[FB / 64];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float *xyz = xyz_all + (size_t)b * N * 3;
     float4 *pts = pts_all + (size_t)b * N;
-    int32_t *orig = orig_all + (size_t)b * N;
+    float *closest = closest_all + (size_t)b * N;
     const int len = min(max(lengths[b], 0), N);
 
     // xy bounding box of the valid points
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(FB) void fps_bucket_sort_kernel(const float *__rest
     for (int i = t; i < len; i += FB) {
         const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
         const int pos = atomicAdd(&s_hist[cell_of(x, y)], 1);
-        pts[pos] = make_float4(x, y, z, __builtin_inff());
-        orig[pos] = i;
+        pts[pos] = make_float4(x, y, z, __int_as_float(i));  // read-only from here on: coordinates + original index
+        closest[pos] = __builtin_inff();
     }
 }
 
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(FB) void fps_bucket_sort_kernel(const float *__rest
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict__ xyz_all,
                                                         const int32_t *__restrict__ lengths, int N, int K,
-                                                        float4 *__restrict__ pts_all,
-                                                        const int32_t *__restrict__ orig_all,
+                                                        const float4 *__restrict__ pts_all,
+                                                        float *__restrict__ closest_all,
                                                         int32_t *__restrict__ idx_all,
                                                         float *__restrict__ new_xyz_all,
                                                         int32_t *__restrict__ new_len) {
@@ -289,8 +289,8 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
 
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float *xyz = xyz_all + (size_t)b * N * 3;
-    float4 *pts = pts_all + (size_t)b * N;
-    const int32_t *orig = orig_all + (size_t)b * N;
+    const float4 *pts = pts_all + (size_t)b * N;
+    float *closest = closest_all + (size_t)b * N;
     int32_t *idx = idx_all + (size_t)b * K;
     float *new_xyz = new_xyz_all + (size_t)b * K * 3;
     const int len = min(max(lengths[b], 0), N);
@@ -345,19 +345,20 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
             const int q0 = (l0 * NW + w) * 64 + lane, q1 = (l1 * NW + w) * 64 + lane;
             const bool ok0 = q0 < len, ok1 = two && q1 < len;
             float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-            int o0 = 0x7fffffff, o1 = 0x7fffffff;
-            if (ok0) p0 = pts[q0], o0 = orig[q0];
-            if (ok1) p1 = pts[q1], o1 = orig[q1];
+            float c0 = 0.f, c1 = 0.f;
+            if (ok0) p0 = pts[q0], c0 = closest[q0];
+            if (ok1) p1 = pts[q1], c1 = closest[q1];
+            const int o0 = ok0 ? __float_as_int(p0.w) : 0x7fffffff, o1 = ok1 ? __float_as_int(p1.w) : 0x7fffffff;
             float v0 = -1.f, v1 = -1.f;
             if (ok0) {
                 const float d = sqdist(sx, sy, sz, p0.x, p0.y, p0.z);
-                if (d < p0.w) pts[q0].w = d;
-                v0 = fminf(d, p0.w);
+                if (d < c0) closest[q0] = d;
+                v0 = fminf(d, c0);
             }
             if (ok1) {
                 const float d = sqdist(sx, sy, sz, p1.x, p1.y, p1.z);
-                if (d < p1.w) pts[q1].w = d;
-                v1 = fminf(d, p1.w);
+                if (d < c1) closest[q1] = d;
+                v1 = fminf(d, c1);
             }
             {
                 float vmax;
@@ -443,9 +444,9 @@ extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N
 #ifdef DPM_FPS_STATS
         (void)hipMemsetAsync((void *)(p - 256), 0, 256, st);
 #endif
-        int32_t *orig = (int32_t *)(pts + (size_t)B * N);
-        hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, pts, orig);
-        hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, orig, idx,
+        float *closest = (float *)(pts + (size_t)B * N);
+        hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, pts, closest);
+        hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx,
                            new_xyz, new_lengths);
         return dpm_launch_status();
     }
