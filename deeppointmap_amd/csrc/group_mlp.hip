@@ -24,7 +24,10 @@ __global__ __launch_bounds__(256) void group_mlp_mfma_kernel(
     const float *__restrict__ xyz_all, const float *__restrict__ fea_all, const float *__restrict__ ctr_all,
     const int32_t *__restrict__ idx_all, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ gamma, const float *__restrict__ beta, int N, int S, int K, int Cin, float inv_r,
-    float *__restrict__ out_all) {
+    float *__restrict__ out_all, const float *__restrict__ W0, const float *__restrict__ b0) {
+    // W0/b0 != NULL: the input features are not read but computed on the fly as the per-point affine map
+    // fea[c] = b0[c] + W0[c,:] . xyz  (Encoder.point_mlp0, encoder.py:25,53) -- the level-0 feature tensor
+    // (N x 16 floats per frame) then never exists in HBM.
     static_assert(WM * WN == 4, "four waves");
     constexpr int RW = TM / WM, CW = COUT / WN, MB = RW / 16, NB = CW / 16, PW = COUT / 32;
     static_assert(MB >= 1 && NB >= 1, "wave tile too small");
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(256) void group_mlp_mfma_kernel(
     const int cpb = TM / K;                       // centres per workgroup (2 or 4)
     const int s0 = blockIdx.x * cpb;              // first centre
     const float *xyz = xyz_all + (size_t)b * N * 3;
-    const float *fea = fea_all + (size_t)b * N * Cin;
+    const float *fea = fea_all ? fea_all + (size_t)b * N * Cin : nullptr;
 
     if (t < TM) {
         const int s = min(s0 + t / K, S - 1);
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256) void group_mlp_mfma_kernel(
     __syncthreads();
 
     const int sr = t >> 3, sk = (t & 7) * 4;  // staging: row within a 32-row pass, k offset
-    const bool fvec = (Cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(fea) & 15) == 0);
+    const bool fvec = fea && (Cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(fea) & 15) == 0);
     const bool wvec = (C3 % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
 
     auto load_g = [&](int row, int k) -> float4 {  // 4 consecutive input channels of gathered row `row`
@@ -62,10 +65,13 @@ __global__ __launch_bounds__(256) void group_mlp_mfma_kernel(
             const float4 q = *reinterpret_cast<const float4 *>(fea + (size_t)n * Cin + k);
             return q;
         }
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (!fea) px = xyz[(size_t)n * 3], py = xyz[(size_t)n * 3 + 1], pz = xyz[(size_t)n * 3 + 2];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = k + j;
-            if (c < Cin) v[j] = fea[(size_t)n * Cin + c];
+            if (c < Cin) v[j] = fea ? fea[(size_t)n * Cin + c]
+                                    : fmaf(W0[3 * c + 2], pz, fmaf(W0[3 * c + 1], py, fmaf(W0[3 * c], px, b0[c])));
             else if (c < C3) v[j] = (xyz[(size_t)n * 3 + (c - Cin)] - s_ctr[row / K][c - Cin]) * inv_r;
         }
         return make_float4(v[0], v[1], v[2], v[3]);
@@ -224,10 +230,10 @@ __global__ __launch_bounds__(256) void group_mlp_mfma_kernel(
 template <int COUT, int WM, int WN>
 int launch(const float *xyz, const float *fea, const float *centers, const int32_t *idx, const float *W,
            const float *bias, const float *gamma, const float *beta, int B, int N, int S, int K, int Cin, float inv_r,
-           float *out, hipStream_t st) {
+           float *out, hipStream_t st, const float *W0 = nullptr, const float *b0 = nullptr) {
     const int cpb = TM / K;
     hipLaunchKernelGGL((group_mlp_mfma_kernel<COUT, WM, WN>), dim3(dpm_cdiv(S, cpb), B), dim3(256), 0, st, xyz, fea,
-                       centers, idx, W, bias, gamma, beta, N, S, K, Cin, inv_r, out);
+                       centers, idx, W, bias, gamma, beta, N, S, K, Cin, inv_r, out, W0, b0);
     return dpm_launch_status();
 }
 
@@ -259,4 +265,23 @@ extern "C" int dpm_group_mlp_max(const float *xyz, const float *fea, const float
     }
     return dpm_group_mlp_max_generic(xyz, fea, centers, idx, W, bias, gamma, beta, B, N, S, K, Cin, Cout, radius, out,
                                      stream);
+}
+
+// SetAbstraction of the FIRST stage with Encoder.point_mlp0 folded in: the per-point input features
+// fea = W0 xyz + b0 (W0 (Cin,3), b0 (Cin)) are evaluated inside the gather instead of being read.
+extern "C" int dpm_group_mlp_max_from_xyz(const float *xyz, const float *W0, const float *b0, const float *centers,
+                                          const int32_t *idx, const float *W, const float *bias, const float *gamma,
+                                          const float *beta, int B, int N, int S, int K, int Cin, int Cout,
+                                          double radius, float *out, dpm_stream_t stream) {
+    DPM_CHECK_ARG(xyz && W0 && b0 && centers && idx && W && bias && gamma && beta && out);
+    DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && Cin >= 1 && radius > 0.0);
+    if (!(K == 16 || K == 32)) return DPM_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_r = 1.0f / (float)radius;
+    switch (Cout) {
+        case 32: return launch<32, 4, 1>(xyz, nullptr, centers, idx, W, bias, gamma, beta, B, N, S, K, Cin, inv_r, out, st, W0, b0);
+        case 64: return launch<64, 2, 2>(xyz, nullptr, centers, idx, W, bias, gamma, beta, B, N, S, K, Cin, inv_r, out, st, W0, b0);
+        case 128: return launch<128, 2, 2>(xyz, nullptr, centers, idx, W, bias, gamma, beta, B, N, S, K, Cin, inv_r, out, st, W0, b0);
+        default: return DPM_EUNSUPPORTED;
+    }
 }

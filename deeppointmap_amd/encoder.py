@@ -82,11 +82,17 @@ class Encoder(ParamTree):
         samp = presampled if presampled is not None else self.presample(points, points_padding)
         with torch.cuda.device(dev):
             pts, xyz, lengths = samp["pts"], samp["xyz"], samp["lengths"]
-            if self.in_channel == 3:
-                fea = ops.linear(xyz, self.p("point_mlp0.weight"), self.p("point_mlp0.bias"))
+            # level-0 features = point_mlp0(points).  With xyz-only input (every shipped config) they are only ever
+            # consumed by the first SetAbstraction, which evaluates them inside its gather (fea = None here).
+            w0 = self.p("point_mlp0.weight")
+            fuse0 = (self.in_channel == 3 and w0.shape[0] % 4 == 0 and 2 * w0.shape[0] in (32, 64, 128)
+                     and enc.nsample_list[0][0] in (16, 32))
+            if fuse0:
+                fea = None
+            elif self.in_channel == 3:
+                fea = ops.linear(xyz, w0, self.p("point_mlp0.bias"))
             else:  # extra input channels: point-major copy of the first in_channel rows
-                fea = ops.linear(pts[:, :self.in_channel].transpose(1, 2).contiguous(),
-                                 self.p("point_mlp0.weight"), self.p("point_mlp0.bias"))
+                fea = ops.linear(pts[:, :self.in_channel].transpose(1, 2).contiguous(), w0, self.p("point_mlp0.bias"))
             levels = [(xyz, fea, lengths)]
             for i, npoint in enumerate(enc.npoint):
                 xyz, fea, lengths = levels[-1]
@@ -94,7 +100,13 @@ class Encoder(ParamTree):
                 pre = f"downsampler.{i}"
                 fidx, new_xyz, new_len = samp[f"fidx{i}"], samp[f"xyz{i}"], samp[f"len{i}"]
                 gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0])
-                new_fea = self._group(pre + ".sa.mlp", radii[0], xyz, fea, new_xyz, gidx)
+                if fea is None:
+                    m = pre + ".sa.mlp"
+                    new_fea = ops.group_mlp_max_from_xyz(xyz, w0, self.p("point_mlp0.bias"), new_xyz, gidx,
+                                                         self.p(m + ".0.weight"), self.p(m + ".0.bias"),
+                                                         self.p(m + ".1.ln.weight"), self.p(m + ".1.ln.bias"), radii[0])
+                else:
+                    new_fea = self._group(pre + ".sa.mlp", radii[0], xyz, fea, new_xyz, gidx)
                 if trace is not None:
                     trace[pre + ".fps.idx"], trace[pre + ".fps.new"] = fidx, new_xyz
                     trace[pre + ".sa.idx"], trace[pre + ".sa.out"] = gidx, new_fea

@@ -106,6 +106,27 @@ def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, g
     return out
 
 
+def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radius: float) -> torch.Tensor:
+    """First-stage SetAbstraction with the per-point input MLP (W0 (Cin,3[,1]), b0 (Cin)) folded into the gather:
+    xyz (B,N,3), centers (B,S,3), idx (B,S,K), W (Cout,Cin+3[,1,1]) -> (B,S,Cout).  Raises ValueError for
+    shapes the fused kernel does not cover (callers fall back to linear + group_mlp_max)."""
+    for n, t in (("xyz", xyz), ("W0", W0), ("b0", b0), ("centers", centers), ("W", W), ("bias", bias),
+                 ("gamma", gamma), ("beta", beta)):
+        _chk(t, torch.float32, n)
+    _chk(idx, torch.int32, "idx")
+    B, N, _ = xyz.shape
+    S, K = idx.shape[1], idx.shape[2]
+    Cin, Cout = W0.shape[0], W.shape[0]
+    if W0.shape[1] != 3 or W.shape[1] != Cin + 3:
+        raise ValueError("W0 must be (Cin,3) and W (Cout,Cin+3)")
+    out = torch.empty(B, S, Cout, device=xyz.device, dtype=torch.float32)
+    _lib.check(_lib.load().dpm_group_mlp_max_from_xyz(_ptr(xyz), _ptr(W0), _ptr(b0), _ptr(centers), _ptr(idx), _ptr(W),
+                                                      _ptr(bias), _ptr(gamma), _ptr(beta), B, N, S, K, Cin, Cout,
+                                                      float(radius), _ptr(out), _stream(xyz)),
+               "dpm_group_mlp_max_from_xyz")
+    return out
+
+
 def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x (..., Cin) (last dim contiguous rows), W (Cout, Cin[,1[,1]]) -> (..., Cout).

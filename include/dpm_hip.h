@@ -88,6 +88,15 @@ int dpm_group_mlp_max(const float *xyz, const float *fea, const float *centers, 
                       int B, int N, int S, int K, int Cin, int Cout, double radius, float *out,
                       dpm_stream_t stream);
 
+/* First-stage SetAbstraction with Encoder.point_mlp0 (encoder.py:25,53) folded in: the input
+ * features are W0 xyz + b0 (W0 (Cin,3) = the Conv1d weight, b0 (Cin)), evaluated inside the
+ * gather, so the (B,N,Cin) level-0 feature tensor is never written or read.  Cout in {32,64,128},
+ * K in {16,32}; otherwise DPM_EUNSUPPORTED (callers then materialise the features with dpm_linear). */
+int dpm_group_mlp_max_from_xyz(const float *xyz, const float *W0, const float *b0, const float *centers,
+                               const int32_t *idx, const float *W, const float *bias, const float *gamma,
+                               const float *beta, int B, int N, int S, int K, int Cin, int Cout,
+                               double radius, float *out, dpm_stream_t stream);
+
 /* 1x1 Conv1d / nn.Linear (build_mlp, network/encoder/utils.py:358-389; decoder heads):
  * out[r, :Cout] = act(x[r,:Cin] W^T + bias + residual[r]); W (Cout,Cin) row-major with leading
  * dimension ldw; x/out/residual have leading dimensions ldx/ldo/ldr (rows R). bias, residual

@@ -218,6 +218,22 @@ def test_group_mlp_max_vs_oracle(ops):
             torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
 
 
+def test_group_mlp_from_xyz_equals_materialised_features(ops):
+    gen = torch.Generator().manual_seed(23)
+    B, N, S, K, Cin, Cout = 2, 3000, 100, 32, 16, 32
+    xyz = torch.rand(B, N, 3, generator=gen)
+    W0, b0 = torch.randn(Cin, 3, 1, generator=gen), torch.randn(Cin, generator=gen) * 0.1
+    ctr = xyz[:, :S].contiguous()
+    idx = torch.randint(0, N, (B, S, K), generator=gen).int()
+    W = torch.randn(Cout, Cin + 3, 1, 1, generator=gen) / (Cin + 3) ** 0.5
+    bias, gm, bt = torch.randn(Cout, generator=gen) * 0.1, 1 + 0.1 * torch.randn(Cout, generator=gen), 0.1 * torch.randn(Cout, generator=gen)
+    d = lambda t: t.to(DEV)
+    fea = ops.linear(d(xyz), d(W0), d(b0))
+    want = ops.group_mlp_max(d(xyz), fea, d(ctr), d(idx), d(W), d(bias), d(gm), d(bt), 0.3)
+    got = ops.group_mlp_max_from_xyz(d(xyz), d(W0), d(b0), d(ctr), d(idx), d(W), d(bias), d(gm), d(bt), 0.3)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
 def test_prepare_and_channel_first(ops):
     gen = torch.Generator().manual_seed(5)
     pts = torch.randn(3, 4, 1000, generator=gen)
