@@ -136,6 +136,7 @@ extern "C" int dpm_linear_batched(const float *x, int ldx, long long sx, const f
     DPM_CHECK_ARG(act >= DPM_ACT_NONE && act <= DPM_ACT_SIGMOID);
     hipStream_t st = (hipStream_t)stream;
     const long long big = (long long)batch * dpm_cdiv(R, 64) * dpm_cdiv(Cout, 64);
+    // 64x64 tiles measured best or tied against 128x128 / 128x64 on every shape of the path (scripts/gemm_bench.py)
     if (big >= 192 || (R > 1024 && Cout > 32)) {
         hipLaunchKernelGGL((gemm_nt_mfma_kernel<64, 64>), dim3(dpm_cdiv(Cout, 64), dpm_cdiv(R, 64), batch), dim3(256), 0,
                            st, x, ldx, sx, W, ldw, sw, bias, residual, ldr, sr, out, ldo, so, R, Cin, Cout, act);
