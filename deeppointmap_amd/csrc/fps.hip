@@ -60,6 +60,28 @@ __device__ __forceinline__ float sqdist(float sx, float sy, float sz, float x, f
 // read after the kernel), so only the LDS exchange needs ordering.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// max / min over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane of the row gets the result
+__device__ __forceinline__ float row16_max_f(float v) {
+    v = fmaxf(v, __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v))));
+    return v;
+}
+__device__ __forceinline__ int row16_min_i(int v) {
+    v = min(v, dpp_i<0xB1, 0xF>(v));
+    v = min(v, dpp_i<0x4E, 0xF>(v));
+    v = min(v, dpp_i<0x141, 0xF>(v));
+    v = min(v, dpp_i<0x140, 0xF>(v));
+    return v;
+}
+
+#ifdef DPM_FPS_STATS
+#define FPS_T(i) do { const long long _n = clock64(); tacc[i] += _n - tprev; tprev = _n; } while (0)
+#else
+#define FPS_T(i) do { } while (0)
+#endif
+
 // lane holding the wave's best (largest v; among equal v the smallest idx).  Lanes that must not win pass v < 0.
 __device__ __forceinline__ int wave_argbest(float v, int idx, float &vmax) {
     vmax = wave_max_dpp(v);
@@ -322,7 +344,11 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
     float wx = 0.f, wy = 0.f, wz = 0.f;  // coordinates of this bucket's current best point
     float sx = xyz[0], sy = xyz[1], sz = xyz[2];
 
+#ifdef DPM_FPS_STATS
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
     for (int r = 1; r < kn; ++r) {
+        FPS_T(5);
         // ---- which of my wave's buckets can change?  box distance with the point-distance expression:
         //      (s - clamp(s)) reproduces (s - x) monotonically, so box distance <= every point distance
         bool act = false;
@@ -332,68 +358,90 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
             act = sqdist(sx, sy, sz, cx, cy, cz) < bmax;
         }
         unsigned long long m = __ballot(act);
+        FPS_T(0);
 #ifdef DPM_FPS_STATS
         if (lane == 0 && m) atomicAdd(&((unsigned long long *)pts_all)[-1 - (b & 0)], (unsigned long long)__popcll(m)), atomicMax(&((int *)pts_all)[-4], __popcll(m));
 #endif
-        // two buckets per iteration: both global loads are in flight before either reduction starts
-        while (m) {
-            const int l0 = __builtin_ctzll(m);
-            m &= m - 1;
+        // wave-level best so far, all values wave-uniform: (value, original index, coordinates)
+        float wv;
+        int wi;
+        float wbx, wby, wbz;
+        bool first = true;
+        do {
+            // up to two active buckets per pass; their global loads are issued first ...
+            const int l0 = m ? __builtin_ctzll(m) : 0;
+            const bool one = m != 0;
+            if (one) m &= m - 1;
             const bool two = m != 0;
             const int l1 = two ? __builtin_ctzll(m) : l0;
             if (two) m &= m - 1;
             const int q0 = (l0 * NW + w) * 64 + lane, q1 = (l1 * NW + w) * 64 + lane;
-            const bool ok0 = q0 < len, ok1 = two && q1 < len;
+            const bool ok0 = one && q0 < len, ok1 = two && q1 < len;
             float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
             float c0 = 0.f, c1 = 0.f;
             if (ok0) p0 = pts[q0], c0 = closest[q0];
             if (ok1) p1 = pts[q1], c1 = closest[q1];
-            const int o0 = ok0 ? __float_as_int(p0.w) : 0x7fffffff, o1 = ok1 ? __float_as_int(p1.w) : 0x7fffffff;
-            float v0 = -1.f, v1 = -1.f;
-            if (ok0) {
-                const float d = sqdist(sx, sy, sz, p0.x, p0.y, p0.z);
-                if (d < c0) closest[q0] = d;
-                v0 = fminf(d, c0);
+            if (first) {
+                // ... and while they are in flight: the best among this wave's UNCHANGED buckets
+                const int L = wave_argbest((mine && !act) ? bmax : -1.f, bidx, wv);
+                wi = lane_i(bidx, L), wbx = lane_f(wx, L), wby = lane_f(wy, L), wbz = lane_f(wz, L);
+                first = false;
             }
-            if (ok1) {
-                const float d = sqdist(sx, sy, sz, p1.x, p1.y, p1.z);
-                if (d < c1) closest[q1] = d;
-                v1 = fminf(d, c1);
-            }
-            {
+            if (one) {
+                const int o0 = ok0 ? __float_as_int(p0.w) : 0x7fffffff;
+                float v0 = -1.f;
+                if (ok0) {
+                    const float d = sqdist(sx, sy, sz, p0.x, p0.y, p0.z);
+                    if (d < c0) closest[q0] = d;
+                    v0 = fminf(d, c0);
+                }
                 float vmax;
                 const int L = wave_argbest(v0, o0, vmax);
-                const int wi = lane_i(o0, L);
+                const int bi = lane_i(o0, L);
                 const float px = lane_f(p0.x, L), py = lane_f(p0.y, L), pz = lane_f(p0.z, L);
-                if (lane == l0) bmax = vmax, bidx = wi, wx = px, wy = py, wz = pz;
+                if (lane == l0) bmax = vmax, bidx = bi, wx = px, wy = py, wz = pz;
+                if (vmax > wv || (vmax == wv && bi < wi)) wv = vmax, wi = bi, wbx = px, wby = py, wbz = pz;
             }
             if (two) {
+                const int o1 = ok1 ? __float_as_int(p1.w) : 0x7fffffff;
+                float v1 = -1.f;
+                if (ok1) {
+                    const float d = sqdist(sx, sy, sz, p1.x, p1.y, p1.z);
+                    if (d < c1) closest[q1] = d;
+                    v1 = fminf(d, c1);
+                }
                 float vmax;
                 const int L = wave_argbest(v1, o1, vmax);
-                const int wi = lane_i(o1, L);
+                const int bi = lane_i(o1, L);
                 const float px = lane_f(p1.x, L), py = lane_f(p1.y, L), pz = lane_f(p1.z, L);
-                if (lane == l1) bmax = vmax, bidx = wi, wx = px, wy = py, wz = pz;
+                if (lane == l1) bmax = vmax, bidx = bi, wx = px, wy = py, wz = pz;
+                if (vmax > wv || (vmax == wv && bi < wi)) wv = vmax, wi = bi, wbx = px, wby = py, wbz = pz;
             }
-        }
-        // ---- arg-max over this wave's buckets, then across the waves
-        float vmax;
-        const int L = wave_argbest(mine ? bmax : -1.f, bidx, vmax);
+        } while (m);
+        FPS_T(1);
         const int par = r & 1;
-        if (lane == L) s_rv[par][w] = vmax, s_ri[par][w] = bidx, s_rx[par][w] = wx, s_ry[par][w] = wy, s_rz[par][w] = wz;
+        if (lane == 0) s_rv[par][w] = wv, s_ri[par][w] = wi, s_rx[par][w] = wbx, s_ry[par][w] = wby, s_rz[par][w] = wbz;
+        FPS_T(2);
         lds_barrier();
-        // every lane reads entry (lane & 15); the best of the 16 is found with a DPP max + ballot
+        FPS_T(3);
+        // cross-wave arg-max: lane reads entry (lane & 15), 16-lane row reduction, winner's fields by broadcast reads
         const int e = lane & (NW - 1);
         const float ev = s_rv[par][e];
-        const int ei = s_ri[par][e];
-        const float ex = s_rx[par][e], ey = s_ry[par][e], ez = s_rz[par][e];
-        float gv;
-        const int gl = wave_argbest(ev, ei, gv);
-        const int gi = lane_i(ei, gl);
-        sx = lane_f(ex, gl), sy = lane_f(ey, gl), sz = lane_f(ez, gl);
+        const float gv = row16_max_f(ev);
+        unsigned eqm = (unsigned)(__ballot(ev == gv) & 0xFFFFull);
+        if (__popc(eqm) > 1) {  // equal maxima in different waves: smallest original index wins
+            const int ei = s_ri[par][e];
+            const int imin = row16_min_i(ev == gv ? ei : 0x7fffffff);
+            eqm = (unsigned)(__ballot(ev == gv && ei == imin) & 0xFFFFull);
+        }
+        const int gw = __builtin_ctz(eqm);
+        const int gi = s_ri[par][gw];
+        sx = s_rx[par][gw], sy = s_ry[par][gw], sz = s_rz[par][gw];
         if (t == 0) {
             const int o = r & (OB - 1);
             s_oidx[o] = gi, s_oxyz[o][0] = sx, s_oxyz[o][1] = sy, s_oxyz[o][2] = sz;
         }
+        FPS_T(4);
         if ((r & (OB - 1)) == OB - 1 || r == kn - 1) {  // flush the buffered picks (uniform condition)
             __syncthreads();
             const int r0 = r & ~(OB - 1);
@@ -410,6 +458,10 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
         idx[r] = -1;
         new_xyz[3 * r] = 0.f, new_xyz[3 * r + 1] = 0.f, new_xyz[3 * r + 2] = 0.f;
     }
+#ifdef DPM_FPS_STATS
+    if (b == 0 && lane == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long *)pts_all - 28 + i, (unsigned long long)tacc[i] / NW);
+#endif
 }
 
 template <int BLOCK, int PPT, bool REG>

@@ -23,4 +23,7 @@ for rep in range(2):
     off = base - ws.data_ptr()
     hdr = ws[off:off + 256].view(torch.int64).cpu()
     hdr32 = ws[off:off + 256].view(torch.int32).cpu()
+    ph = [int(hdr[32 - 28 + i]) for i in range(6)]
+    names = ['box+ballot', 'bucket updates', 'wave argbest+lds write', 'barrier', 'final reduce', 'loop/flush']
+    print('  phase cycles per round (mean over waves): ' + ', '.join(f'{n}={v / (K - 1):.0f}' for n, v in zip(names, ph)))
     print(f'rc={rc} time {e0.elapsed_time(e1):.3f} ms  total active buckets {int(hdr[31])}  per round {int(hdr[31]) / (K - 1):.2f}  max per wave-round {int(hdr32[60])}')
