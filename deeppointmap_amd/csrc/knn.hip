@@ -497,7 +497,53 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
     finish(c, pts, len, N, K, r2, s_d[w], s_i[w], s_td[w], s_ti[w], idx_all + ((size_t)b * S + s) * K);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Querier.ball_query (utils.py:57-73): the K smallest INDICES among the points within the radius, ascending,
+// padded with the first of them.  One wave per centre scans the frame in index order and stops at K hits.
+// (A centre with no point in range gets index N in every slot in the reference -- an out-of-range gather
+// there -- here the slots are filled with 0.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WPB * 64) void ball_query_kernel(const float *__restrict__ points_all,
+                                                              const int32_t *__restrict__ lengths,
+                                                              const float *__restrict__ centers_all, int N, int S,
+                                                              int K, float r2, int32_t *__restrict__ idx_all) {
+    const int b = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * WPB + w;
+    if (s >= S) return;
+    const float *pts = points_all + (size_t)b * N * 3;
+    const int len = min(max(lengths[b], 0), N);
+    const float *c = centers_all + ((size_t)b * S + s) * 3;
+    const float cx = c[0], cy = c[1], cz = c[2], caa = sq3(cx, cy, cz);
+    int32_t *out = idx_all + ((size_t)b * S + s) * K;
+    int cnt = 0, first = 0;
+    for (int base = 0; base < len && cnt < K; base += 64) {
+        const int i = base + lane;
+        bool in = false;
+        if (i < len) {
+            const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+            in = !(exp_dist(cx, cy, cz, caa, x, y, z, sq3(x, y, z)) > r2);
+        }
+        const unsigned long long m = __ballot(in);
+        if (m) {
+            if (cnt == 0) first = base + __builtin_ctzll(m);
+            const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+            if (in && pos < K) out[pos] = i;
+            cnt += __popcll(m);
+        }
+    }
+    for (int p = min(cnt, K) + lane; p < K; p += 64) out[p] = first;
+}
+
 }  // namespace
+
+extern "C" int dpm_ball_query(const float *points, const int32_t *lengths, const float *centers, int B, int N, int S,
+                              int K, double radius, int32_t *idx, dpm_stream_t stream) {
+    DPM_CHECK_ARG(points && lengths && centers && idx);
+    DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && radius > 0.0);
+    hipLaunchKernelGGL(ball_query_kernel, dim3(dpm_cdiv(S, WPB), B), dim3(WPB * 64), 0, (hipStream_t)stream, points,
+                       lengths, centers, N, S, K, (float)(radius * radius), idx);
+    return dpm_launch_status();
+}
 
 extern "C" size_t dpm_knn_workspace_bytes(int B, int N) {
     if (N < GRID_MIN_N) return 0;

@@ -86,6 +86,17 @@ def knn_hybrid(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tenso
     return idx
 
 
+def ball_query(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tensor, K: int, radius: float) -> torch.Tensor:
+    """points (B,N,3), centers (B,S,3) -> idx (B,S,K) int32: first K indices within the radius, padded with the first."""
+    _chk(points, torch.float32, "points"), _chk(centers, torch.float32, "centers"), _chk(lengths, torch.int32, "lengths")
+    B, N, _ = points.shape
+    S = centers.shape[1]
+    idx = torch.empty(B, S, K, device=points.device, dtype=torch.int32)
+    _lib.check(_lib.load().dpm_ball_query(_ptr(points), _ptr(lengths), _ptr(centers), B, N, S, K, float(radius),
+                                          _ptr(idx), _stream(points)), "dpm_ball_query")
+    return idx
+
+
 def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, generic: bool = False) -> torch.Tensor:
     """xyz (B,N,3), fea (B,N,Cin), centers (B,S,3), idx (B,S,K), W (Cout,Cin+3[,1,1]) -> (B,S,Cout).
     generic=True forces the plain-VALU kernel (cross-check path)."""

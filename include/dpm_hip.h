@@ -73,6 +73,12 @@ size_t dpm_knn_workspace_bytes(int B, int N);
 int dpm_knn_hybrid(const float *points, const int32_t *lengths, const float *centers, int B, int N,
                    int S, int K, double radius, int32_t *idx, void *workspace, dpm_stream_t stream);
 
+/* Querier.ball_query / ball_query_t3d == pytorch3d.ops.ball_query (utils.py:57-73,99-110): the K
+ * smallest indices among the valid points within `radius` (expanded-form distance, like the
+ * reference), ascending, padded with the first of them.  idx (B,S,K). */
+int dpm_ball_query(const float *points, const int32_t *lengths, const float *centers, int B, int N, int S,
+                   int K, double radius, int32_t *idx, dpm_stream_t stream);
+
 /* SetAbstraction / LocalAggregation body (network/encoder/pointnext.py:52-61,97-107):
  * out[b,s,:] = max_k relu(LN(W [fea[idx[b,s,k]], (xyz[idx]-center)/radius] + bias)).
  * W (Cout, Cin+3) row-major exactly as the Conv2d weight (Cout,Cin+3,1,1): first Cin columns

@@ -243,3 +243,38 @@ def test_prepare_and_channel_first(ops):
     assert lens.cpu().tolist() == [1000, 640, 1]
     x = torch.randn(2, 77, 131, generator=gen)
     assert torch.equal(ops.to_channel_first(x.to(DEV)).cpu(), x.transpose(1, 2).contiguous())
+
+
+def test_operator_tables_match_reference_semantics():
+    """Sampler / Querier mirrors (deeppointmap_amd/operators.py) against the oracle's restatement."""
+    from deeppointmap_amd.operators import Querier, Sampler
+    gen = torch.Generator().manual_seed(40)
+    pts = torch.rand(2, 3000, 3, generator=gen)
+    pad = torch.arange(3000).unsqueeze(0) >= torch.tensor([[3000], [2100]])
+    new, mask = Sampler("fps-t3d")(points=pts.to(DEV), points_padding=pad.to(DEV), K=400)
+    wn, wm, _ = O.fps(pts, pad, 400)
+    assert torch.equal(new.cpu(), wn) and torch.equal(mask.cpu(), wm)
+    ctr = wn.contiguous()
+    idx = Querier("hybrid-t3d")(radius=0.15, K=32, points=pts.to(DEV), centers=ctr.to(DEV), points_padding=pad.to(DEV))
+    assert idx.dtype == torch.int64
+    want = O.hybrid_query(0.15, 32, pts, ctr, pad)
+    for b in range(2):
+        assert idx_rows_equal_as_sets(idx[b].cpu().numpy(), want[b].numpy()).mean() > 0.999
+    # knn: no radius mask
+    kn = Querier("knn")(K=8, points=pts.to(DEV), centers=ctr.to(DEV), points_padding=pad.to(DEV)).cpu()
+    p2 = O.push_padding_far(pts, pad)
+    wk = torch.topk(O.expanded_sqdist(ctr, p2), 8, dim=-1, largest=False)[1]
+    for b in range(2):
+        assert idx_rows_equal_as_sets(kn[b].numpy(), wk[b].numpy()).mean() > 0.999
+    # ball: first K indices within the radius, padded with the first (utils.py:57-73)
+    bl = Querier("ball")(radius=0.2, K=16, points=pts.to(DEV), centers=ctr.to(DEV), points_padding=pad.to(DEV)).cpu()
+    d = O.expanded_sqdist(ctr, p2)
+    gi = torch.arange(3000).view(1, 1, -1).repeat(2, 400, 1)
+    gi[d > 0.2 ** 2] = 3000
+    gi = gi.sort(dim=-1)[0][:, :, :16]
+    first = gi[:, :, :1].expand_as(gi)
+    gi = torch.where(gi == 3000, first, gi)
+    valid = first[..., 0] < 3000  # rows with at least one point in range (the reference indexes out of range otherwise)
+    assert torch.equal(bl[valid], gi[valid])
+    with pytest.raises(NotImplementedError):
+        Sampler("voxel")(points=pts, points_padding=pad, K=4)
