@@ -241,8 +241,33 @@ def gen_decoder(enc_out):
     save("decoder.npz", **out)
 
 
+def gen_poses_full(n_frames=6):
+    """Consecutive-frame registrations at BASELINE.json's full size (65 536 points), reference end to end:
+    only the poses are stored; the inputs are regenerated from synthetic.py."""
+    cfg = default_args()
+    enc, dec = build_reference(cfg)
+    descs = []
+    for f in range(n_frames):
+        p = synthetic.frame(f).unsqueeze(0)
+        coor, fea, _ = enc(p, torch.zeros(1, p.shape[2], dtype=torch.bool))
+        descs.append(torch.cat([fea[0], coor[0] * cfg.slam_system.coor_scale], dim=0))
+    out = {}
+    for f in range(1, n_frames):
+        R, T, c, rmse = dec.registration_forward(descs[f - 1], descs[f], num_sample=0.5)
+        out[f"pair{f - 1}_{f}.R"], out[f"pair{f - 1}_{f}.T"] = R, T
+        out[f"pair{f - 1}_{f}.rmse"], out[f"pair{f - 1}_{f}.n_conf"] = rmse, c.shape[0]
+        out[f"pair{f - 1}_{f}.conf30"] = c.flatten()[:30].mean()
+    # num_sample variants on one pair (decoder.py:170-178)
+    for tag, ns in (("int100", 100), ("float300", 300.0), ("float0.25", 0.25)):
+        R, T, c, rmse = dec.registration_forward(descs[0], descs[1], num_sample=ns)
+        out[f"ns_{tag}.R"], out[f"ns_{tag}.T"], out[f"ns_{tag}.n_conf"] = R, T, c.shape[0]
+    save("poses_full.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fps", "knn", "encoder", "decoder"]
+    which = sys.argv[1:] or ["fps", "knn", "encoder", "decoder", "poses"]
+    if "poses" in which:
+        gen_poses_full()
     if "fps" in which:
         gen_fps()
     if "knn" in which:

@@ -62,3 +62,22 @@ def test_state_dict_layout(cfg_full):
     assert num(e) == 3824224 and num(d) == 2776260
     assert e["downsampler.0.sa.mlp.0.weight"] == (32, 19, 1, 1)
     assert d["descriptor_attention.2.cross_attn.in_proj_weight"] == (768, 256)
+
+
+def test_modules_deepcopy_and_state_dict_roundtrip(cfg_full):
+    """infer_multiagents.py:100,112-113 deep-copies the networks; infer.py:63-65 loads checkpoints by key."""
+    import copy
+    import torch
+    from deeppointmap_amd.decoder import Decoder
+    from deeppointmap_amd.encoder import Encoder
+    from deeppointmap_amd.weights import init_procedural
+    enc, dec = init_procedural(Encoder(cfg_full)), init_procedural(Decoder(cfg_full))
+    enc2, dec2 = copy.deepcopy(enc), copy.deepcopy(dec)
+    assert enc2.p("point_mlp0.weight") is not enc.p("point_mlp0.weight")
+    assert torch.equal(enc2.p("point_mlp0.weight"), enc.p("point_mlp0.weight"))
+    fresh = Encoder(cfg_full)
+    fresh.load_state_dict(enc.state_dict(), strict=True)
+    assert all(torch.equal(a, b) for a, b in zip(fresh.state_dict().values(), enc.state_dict().values()))
+    missing = Decoder(cfg_full).load_state_dict({k: v for k, v in dec.state_dict().items() if "coarse" not in k}, strict=False)
+    assert set(missing.missing_keys) == {k for k in dec.state_dict() if "coarse" in k}
+    assert not enc.training and not dec.training  # constructed in eval mode, like odometry.py:33,74 leave them

@@ -85,3 +85,62 @@ def test_streaming_pipeline_equals_plain_steps(hot):
     torch.cuda.synchronize()
     for (d0, t0), (d1, t1) in zip(plain, outs):
         assert torch.equal(d0, d1) and torch.equal(t0, t1)
+
+
+def test_five_consecutive_full_size_pairs_vs_reference(hot):
+    """BASELINE.json config 2 in miniature: six 65 536-point scans, five odometry edges, every pose within the
+    north_star tolerance of what the REFERENCE computes end to end (tests/golden/poses_full.npz)."""
+    g = load_golden("poses_full.npz")
+    pts, pad = synthetic.frames(6, 65536)
+    desc = hot.extract(pts.to(DEV), pad.to(DEV))
+    edges, table = hot.register(desc, (pts * 60).to(DEV), [(f - 1, f) for f in range(1, 6)])
+    worst_t = worst_r = 0.0
+    for e in edges:
+        k = f"pair{e.src}_{e.dst}"
+        worst_t = max(worst_t, float((e.T.cpu() - T(g[k + ".T"])).norm()))
+        worst_r = max(worst_r, rot_angle(e.R.cpu(), g[k + ".R"]))
+        assert e.conf.shape[0] == int(g[k + ".n_conf"]), k
+        assert abs(e.rmse - float(g[k + ".rmse"])) < 1e-3, k
+        assert abs(float(e.conf[:30].mean()) - float(g[k + ".conf30"])) < 1e-6 * 10, k
+    assert worst_t < 1e-4 and worst_r < 1e-4, (worst_t, worst_r)
+
+
+def test_num_sample_variants_vs_reference(hot):
+    g = load_golden("poses_full.npz")
+    pts, pad = synthetic.frames(2, 65536)
+    desc = hot.extract(pts.to(DEV), pad.to(DEV))
+    for tag, ns in (("int100", 100), ("float300", 300.0), ("float0.25", 0.25)):
+        R, Tt, conf, rmse = hot.decoder.registration_forward(desc[0], desc[1], num_sample=ns)
+        assert float((Tt.cpu() - T(g[f"ns_{tag}.T"])).norm()) < 1e-4 and rot_angle(R.cpu(), g[f"ns_{tag}.R"]) < 1e-4, tag
+        assert conf.shape[0] == int(g[f"ns_{tag}.n_conf"]), tag
+
+
+def test_kitti_sample_pair_end_to_end(hot):
+    ge, gd = load_golden("encoder_full.npz"), load_golden("decoder.npz")
+    pts = torch.stack([T(ge["kitti0.points"]), T(ge["kitti1.points"])])
+    desc = hot.extract(pts.to(DEV), torch.zeros(2, pts.shape[2], dtype=torch.bool, device=DEV))
+    R, Tt, conf, rmse = hot.decoder.registration_forward(desc[0], desc[1], num_sample=0.5)
+    assert float((Tt.cpu() - T(gd["kitti01.T"])).norm()) < 1e-4 and rot_angle(R.cpu(), gd["kitti01.R"]) < 1e-4
+
+
+def test_decoder_is_reentrant_across_threads(hot):
+    """system/core.py:55-57 drives ONE Decoder from three threads; results must not depend on interleaving."""
+    import threading
+    gd = load_golden("decoder.npz")
+    names = ["synthetic01", "kitti01", "map1024_vs_256"]
+    want = {n: hot.decoder.registration_forward(T(gd[n + ".src_desc"]), T(gd[n + ".dst_desc"]), num_sample=0.5) for n in names}
+    got, errs = {}, []
+
+    def work(n):
+        try:
+            for _ in range(5):
+                got[n] = hot.decoder.registration_forward(T(gd[n + ".src_desc"]), T(gd[n + ".dst_desc"]), num_sample=0.5)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(n,)) for n in names]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for n in names:
+        assert torch.equal(got[n][0], want[n][0]) and torch.equal(got[n][1], want[n][1]) and got[n][3] == want[n][3]

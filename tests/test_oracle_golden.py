@@ -145,3 +145,18 @@ def test_information_matrix_hand_computed():
     SE3[:3, 3] = torch.tensor([-29.0, 2.0, 3.0])
     G1 = O.information_matrix(src[:, 2:], tgt, SE3)
     assert G1[3, 3] == 1.0 and G1[0, 0] == 3.0 ** 2 + 2.0 ** 2
+
+
+def test_full_size_consecutive_poses(cfg_full, sd_enc, sd_dec):
+    """Oracle end to end at 65 536 points against the reference's poses for two consecutive pairs."""
+    g = load_golden("poses_full.npz")
+    descs = []
+    for f in range(3):
+        p = synthetic.frame(f).unsqueeze(0)
+        coor, fea, _ = O.encoder_forward(sd_enc, cfg_full, p, torch.zeros(1, 65536, dtype=torch.bool), fast_fps=True)
+        descs.append(torch.cat([fea[0], coor[0] * 60.0], 0))
+    for f in (1, 2):
+        R, Tt, conf, rmse = O.registration_forward(sd_dec, cfg_full, descs[f - 1], descs[f], 0.5)
+        k = f"pair{f - 1}_{f}"
+        assert float((Tt - T(g[k + ".T"])).norm()) < 1e-4 and rot_angle(R, g[k + ".R"]) < 1e-4
+        assert conf.shape[0] == int(g[k + ".n_conf"])
