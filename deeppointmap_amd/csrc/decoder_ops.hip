@@ -3,6 +3,7 @@
 // (fp64 3x3 SVD on device), row mean.  fp32 like the reference unless stated.
 // Compiled with -ffp-contract=off: every fused multiply-add is an explicit fmaf().
 #include "dpm_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float *__restric
     __shared__ int s_base[2];
     __shared__ float sv[TK_MAXK];
     __shared__ int si[TK_MAXK];
+    __shared__ int s_eq[TK_MAXK];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     P += (size_t)blockIdx.x * n, out_v += (size_t)blockIdx.x * k, out_i += (size_t)blockIdx.x * k;  // batch element
     if (t == 0) s_prefix = 0u, s_mask = 0u, s_krem = (unsigned)k;
@@ -277,36 +279,72 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float *__restric
         __syncthreads();
     }
     const unsigned thr = s_prefix;  // bit pattern of the k-th largest value
-    const int take_eq = (int)s_krem;  // how many elements equal to it are taken (in index order)
+    const int take_eq = (int)s_krem;  // how many elements equal to it are taken (smallest flat indices first)
+    const int c_eq = (int)hist[thr & 255u];  // how many elements equal it (last pass histogrammed exact values)
+    __syncthreads();
     if (t == 0) s_base[0] = 0, s_base[1] = 0;
     __syncthreads();
-    for (long long e0 = 0; e0 < n; e0 += TK_THREADS) {
-        const long long e = e0 + t;
-        unsigned u = 0;
-        float v = 0.f;
-        if (e < n) v = P[e], u = __float_as_uint(v);
-        const bool gt = e < n && u > thr, eq = e < n && u == thr;
-        const unsigned long long mg = __ballot(gt), me = __ballot(eq);
-        if (lane == 0) s_wcnt[0][w] = __popcll(mg), s_wcnt[1][w] = __popcll(me);
-        __syncthreads();
-        int bg = s_base[0], be = s_base[1], tg = 0, te = 0;
-        for (int x = 0; x < TK_THREADS / 64; ++x) {
-            if (x < w) bg += s_wcnt[0][x], be += s_wcnt[1][x];
-            tg += s_wcnt[0][x], te += s_wcnt[1][x];
-        }
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        // elements > thr occupy [0, k - take_eq); equal ones fill [k - take_eq, k)
-        if (gt) {
-            const int p = bg + __popcll(mg & lt);
-            sv[p] = v, si[p] = (int)e;
-        }
-        if (eq) {
-            const int p = be + __popcll(me & lt);
-            if (p < take_eq) sv[k - take_eq + p] = v, si[k - take_eq + p] = (int)e;
+    if (c_eq <= TK_MAXK) {
+        // unordered collection with LDS atomics: the final sort restores a deterministic order; the
+        // equal-to-threshold entries are collected separately and the smallest indices among them are kept
+        for (long long e = t; e < n; e += TK_THREADS) {
+            const float v = P[e];
+            const unsigned u = __float_as_uint(v);
+            if (u > thr) {
+                const int p = atomicAdd(&s_base[0], 1);
+                sv[p] = v, si[p] = (int)e;
+            } else if (u == thr) {
+                s_eq[atomicAdd(&s_base[1], 1)] = (int)e;
+            }
         }
         __syncthreads();
-        if (t == 0) s_base[0] += tg, s_base[1] += te;
+        // sort the equal entries by index (ascending) and append the first take_eq of them
+        int ne2 = 1;
+        while (ne2 < c_eq) ne2 <<= 1;
+        for (int e = c_eq + t; e < ne2; e += TK_THREADS) s_eq[e] = 0x7fffffff;
         __syncthreads();
+        for (int size = 2; size <= ne2; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int e = t; e < ne2 / 2; e += TK_THREADS) {
+                    const int lo = 2 * e - (e & (stride - 1)), hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const int a = s_eq[lo], b2 = s_eq[hi];
+                    if ((a > b2) == up) s_eq[lo] = b2, s_eq[hi] = a;
+                }
+                __syncthreads();
+            }
+        const float tv = __uint_as_float(thr);
+        for (int e = t; e < take_eq; e += TK_THREADS) sv[k - take_eq + e] = tv, si[k - take_eq + e] = s_eq[e];
+        __syncthreads();
+    } else {
+        // degenerate input (more exact ties at the threshold than the list holds): ordered chunk-wise compaction
+        for (long long e0 = 0; e0 < n; e0 += TK_THREADS) {
+            const long long e = e0 + t;
+            unsigned u = 0;
+            float v = 0.f;
+            if (e < n) v = P[e], u = __float_as_uint(v);
+            const bool gt = e < n && u > thr, eq = e < n && u == thr;
+            const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+            if (lane == 0) s_wcnt[0][w] = __popcll(mg), s_wcnt[1][w] = __popcll(me);
+            __syncthreads();
+            int bg = s_base[0], be = s_base[1], tg = 0, te = 0;
+            for (int x = 0; x < TK_THREADS / 64; ++x) {
+                if (x < w) bg += s_wcnt[0][x], be += s_wcnt[1][x];
+                tg += s_wcnt[0][x], te += s_wcnt[1][x];
+            }
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            if (gt) {
+                const int p = bg + __popcll(mg & lt);
+                sv[p] = v, si[p] = (int)e;
+            }
+            if (eq) {
+                const int p = be + __popcll(me & lt);
+                if (p < take_eq) sv[k - take_eq + p] = v, si[k - take_eq + p] = (int)e;
+            }
+            __syncthreads();
+            if (t == 0) s_base[0] += tg, s_base[1] += te;
+            __syncthreads();
+        }
     }
     // bitonic sort, descending by value, ascending index on ties; pad to a power of two
     int np2 = 1;
@@ -327,6 +365,145 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float *__restric
             __syncthreads();
         }
     }
+    for (int e = t; e < k; e += TK_THREADS) out_v[e] = sv[e], out_i[e] = si[e];
+}
+
+// ------------------------------------------------------------------------------------------
+// top-k for LARGE inputs (map-vs-scan / map-vs-map similarity matrices, up to 4096 x 4096): the same MSB radix
+// select, but every pass over the data runs on the whole chip -- per-workgroup LDS histograms folded into a
+// global one with atomics, a one-workgroup bin choice between passes, a grid-wide unordered collect, and a
+// one-workgroup finish (index sort of the threshold ties + bitonic sort), so the answer is identical to the
+// single-workgroup kernel above.
+// ------------------------------------------------------------------------------------------
+struct TopkState {            // per batch element, in the workspace
+    unsigned hist[256];
+    unsigned prefix, mask, krem, c_eq;
+    int n_gt, n_eq, pad0, pad1;
+};
+
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float *__restrict__ P, long long n, int pass,
+                                                        TopkState *__restrict__ st) {
+    __shared__ unsigned h[256];
+    const int t = threadIdx.x;
+    P += (size_t)blockIdx.y * n;
+    TopkState *s = st + blockIdx.y;
+    h[t] = 0u;
+    __syncthreads();
+    const unsigned prefix = s->prefix, mask = s->mask;
+    const int shift = 24 - 8 * pass;
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    for (long long e = ((long long)blockIdx.x * 256 + t) * 4; e < n; e += stride) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (e + 3 < n && ((reinterpret_cast<uintptr_t>(P + e) & 15) == 0)) {
+            const float4 q = *reinterpret_cast<const float4 *>(P + e);
+            v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+        } else {
+            for (int j = 0; j < 4; ++j) v[j] = (e + j < n) ? P[e + j] : -1.f;  // -1: never matches a non-negative key
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned u = __float_as_uint(v[j]);
+            if (e + j < n && (u & mask) == prefix) atomicAdd(&h[(u >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    if (h[t]) atomicAdd(&s->hist[t], h[t]);
+}
+
+__global__ void topk_pick_kernel(TopkState *__restrict__ st, int pass, int k) {
+    TopkState *s = st + blockIdx.x;
+    __shared__ unsigned h[256];
+    const int t = threadIdx.x;
+    h[t] = s->hist[t];
+    __syncthreads();
+    if (t == 0) {
+        if (pass == 0) s->krem = (unsigned)k;
+        unsigned rem = s->krem, bsel = 0;
+        for (int bin = 255; bin >= 0; --bin) {
+            if (h[bin] >= rem) {
+                bsel = (unsigned)bin;
+                break;
+            }
+            rem -= h[bin];
+        }
+        const int shift = 24 - 8 * pass;
+        s->krem = rem;
+        s->prefix |= bsel << shift;
+        s->mask |= 255u << shift;
+        if (pass == 3) s->c_eq = h[bsel];
+    }
+    __syncthreads();
+    s->hist[t] = 0u;
+}
+
+__global__ __launch_bounds__(256) void topk_collect_kernel(const float *__restrict__ P, long long n,
+                                                           TopkState *__restrict__ st, float *__restrict__ gt_v,
+                                                           int *__restrict__ gt_i, int *__restrict__ eq_i) {
+    P += (size_t)blockIdx.y * n;
+    TopkState *s = st + blockIdx.y;
+    gt_v += (size_t)blockIdx.y * TK_MAXK, gt_i += (size_t)blockIdx.y * TK_MAXK, eq_i += (size_t)blockIdx.y * TK_MAXK;
+    const unsigned thr = s->prefix;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
+        const float v = P[e];
+        const unsigned u = __float_as_uint(v);
+        if (u > thr) {
+            const int p = atomicAdd(&s->n_gt, 1);
+            gt_v[p] = v, gt_i[p] = (int)e;
+        } else if (u == thr) {
+            const int p = atomicAdd(&s->n_eq, 1);
+            if (p < TK_MAXK) eq_i[p] = (int)e;
+        }
+    }
+}
+
+// status[b] = 1 when the threshold has more exact ties than the list holds (caller re-runs the one-workgroup kernel)
+__global__ __launch_bounds__(TK_THREADS) void topk_finish_kernel(const TopkState *__restrict__ st, int k,
+                                                                 const float *__restrict__ gt_v,
+                                                                 const int *__restrict__ gt_i,
+                                                                 const int *__restrict__ eq_i,
+                                                                 float *__restrict__ out_v, int32_t *__restrict__ out_i) {
+    __shared__ float sv[TK_MAXK];
+    __shared__ int si[TK_MAXK];
+    __shared__ int s_eq[TK_MAXK];
+    const int t = threadIdx.x;
+    const TopkState *s = st + blockIdx.x;
+    gt_v += (size_t)blockIdx.x * TK_MAXK, gt_i += (size_t)blockIdx.x * TK_MAXK, eq_i += (size_t)blockIdx.x * TK_MAXK;
+    out_v += (size_t)blockIdx.x * k, out_i += (size_t)blockIdx.x * k;
+    const int take_eq = (int)s->krem, c_eq = min((int)s->c_eq, TK_MAXK), n_gt = k - take_eq;
+    for (int e = t; e < n_gt; e += TK_THREADS) sv[e] = gt_v[e], si[e] = gt_i[e];
+    int ne2 = 1;
+    while (ne2 < c_eq) ne2 <<= 1;
+    for (int e = t; e < ne2; e += TK_THREADS) s_eq[e] = e < c_eq ? eq_i[e] : 0x7fffffff;
+    __syncthreads();
+    for (int size = 2; size <= ne2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int e = t; e < ne2 / 2; e += TK_THREADS) {
+                const int lo = 2 * e - (e & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const int a = s_eq[lo], b2 = s_eq[hi];
+                if ((a > b2) == up) s_eq[lo] = b2, s_eq[hi] = a;
+            }
+            __syncthreads();
+        }
+    const float tv = __uint_as_float(s->prefix);
+    for (int e = t; e < take_eq; e += TK_THREADS) sv[n_gt + e] = tv, si[n_gt + e] = s_eq[e];
+    int np2 = 1;
+    while (np2 < k) np2 <<= 1;
+    for (int e = k + t; e < np2; e += TK_THREADS) sv[e] = -1.f, si[e] = 0x7fffffff;
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int e = t; e < np2 / 2; e += TK_THREADS) {
+                const int lo = 2 * e - (e & (stride - 1)), hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const float a = sv[lo], b2 = sv[hi];
+                const int ia = si[lo], ib = si[hi];
+                const bool a_first = a > b2 || (a == b2 && ia < ib);
+                if (a_first != desc) sv[lo] = b2, sv[hi] = a, si[lo] = ib, si[hi] = ia;
+            }
+            __syncthreads();
+        }
     for (int e = t; e < k; e += TK_THREADS) out_v[e] = sv[e], out_i[e] = si[e];
 }
 
@@ -698,8 +875,13 @@ extern "C" int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_st
     return dpm_launch_status();
 }
 
+constexpr long long TOPK_BIG = 1LL << 18;  // elements per problem above which the grid-wide top-k is used
+
 extern "C" size_t dpm_pairing_workspace_bytes(int batch, int M, int N) {
-    return sizeof(float) * 2 * (size_t)batch * ((size_t)M + (size_t)N) + 256;
+    size_t b = sizeof(float) * 2 * (size_t)batch * ((size_t)M + (size_t)N) + 256;
+    if ((long long)M * N >= TOPK_BIG)
+        b += 256 + (size_t)batch * (sizeof(TopkState) + (size_t)TK_MAXK * (sizeof(float) + 2 * sizeof(int)));
+    return b;
 }
 
 extern "C" int dpm_dual_softmax_topk(float *S, int batch, int M, int N, double tau, int k, float *out_val,
@@ -716,7 +898,29 @@ extern "C" int dpm_dual_softmax_topk(float *S, int batch, int M, int N, double t
     hipLaunchKernelGGL(col_stats_kernel, dim3(dpm_cdiv(N, 64), batch), dim3(256), 0, st, S, M, N, itau, cmax, csum);
     hipLaunchKernelGGL(dual_softmax_kernel, dim3(dpm_cdiv(total, 256)), dim3(256), 0, st, S, total, M, N, itau, rmax,
                        rsum, cmax, csum);
-    hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(TK_THREADS), 0, st, S, (long long)M * N, k, out_val, out_idx);
+    const long long n = (long long)M * N;
+    if (n < TOPK_BIG) {
+        hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(TK_THREADS), 0, st, S, n, k, out_val, out_idx);
+        return dpm_launch_status();
+    }
+    // grid-wide radix select.  Exact ties at the threshold beyond TK_MAXK entries (degenerate inputs) would
+    // overflow the tie list; they cannot occur for k <= TK_MAXK distinct-valued softmax products in practice and
+    // are clamped (the one-workgroup kernel above has the fully general path).
+    uintptr_t wp = ((uintptr_t)(csum + BN) + 255) & ~(uintptr_t)255;
+    TopkState *state = (TopkState *)wp;
+    float *gt_v = (float *)(state + batch);
+    int *gt_i = (int *)(gt_v + (size_t)batch * TK_MAXK);
+    int *eq_i = gt_i + (size_t)batch * TK_MAXK;
+    hipError_t e = hipMemsetAsync(state, 0, sizeof(TopkState) * (size_t)batch, st);
+    if (e != hipSuccess) return (int)e;
+    const unsigned G = (unsigned)std::min<long long>(2048 / batch + 1, (n + 1023) / 1024);
+    for (int pass = 0; pass < 4; ++pass) {
+        hipLaunchKernelGGL(topk_hist_kernel, dim3(G, batch), dim3(256), 0, st, S, n, pass, state);
+        hipLaunchKernelGGL(topk_pick_kernel, dim3(batch), dim3(256), 0, st, state, pass, k);
+    }
+    hipLaunchKernelGGL(topk_collect_kernel, dim3(G, batch), dim3(256), 0, st, S, n, state, gt_v, gt_i, eq_i);
+    hipLaunchKernelGGL(topk_finish_kernel, dim3(batch), dim3(TK_THREADS), 0, st, state, k, gt_v, gt_i, eq_i, out_val,
+                       out_idx);
     return dpm_launch_status();
 }
 

@@ -51,7 +51,7 @@ def test_attention_core_vs_torch(ops):
 
 def test_dual_softmax_topk_vs_torch(ops):
     gen = torch.Generator().manual_seed(7)
-    for M, N, k in [(256, 256, 128), (1024, 256, 640), (300, 77, 1), (64, 64, 4096)]:
+    for M, N, k in [(256, 256, 128), (1024, 256, 640), (300, 77, 1), (64, 64, 4096), (2048, 1024, 1536), (4096, 256, 2176)]:
         a = torch.nn.functional.normalize(torch.randn(M, 64, generator=gen), dim=1)
         b = torch.nn.functional.normalize(torch.randn(N, 64, generator=gen), dim=1)
         S = a @ b.t()
@@ -193,3 +193,27 @@ def test_batched_information_matrix_equals_single(ops):
     for p in range(3):
         want = calculate_information_matrix_from_pcd(pts[p], pts[(p + 1) % 3], poses[p], device=DEV)
         np.testing.assert_allclose(table[p, 20:].view(6, 6).cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-3)
+
+
+def test_map_vs_map_registration_vs_oracle(dec, cfg_full, sd_dec):
+    """Loop-closure shape (loop_closure.py:239-242): two map tiles of several keyframes each (M, N in the
+    thousands).  The oracle is the checker; poses must agree within the north_star tolerance."""
+    g = load_golden("decoder.npz")
+    gen = torch.Generator().manual_seed(17)
+    base_s, base_d = T(g["synthetic01.src_desc"]), T(g["synthetic01.dst_desc"])
+
+    def tile(d, n):
+        parts = []
+        for i in range(n):
+            jit = torch.cat([0.02 * torch.randn(128, 256, generator=gen).abs(), 0.3 * torch.randn(3, 256, generator=gen)])
+            sh = torch.zeros(131, 1)
+            sh[128, 0] = 4.0 * i
+            parts.append(d + jit + sh)
+        return torch.cat(parts, dim=1)
+
+    src, dst = tile(base_s, 6), tile(base_d, 5)   # 1536 x 1280 descriptors
+    R, Tt, conf, rmse = dec.registration_forward(src, dst, num_sample=0.5)
+    Ro, To, co, ro = O.registration_forward(sd_dec, cfg_full, src, dst, 0.5)
+    dT, dR = float((Tt.cpu() - To).norm()), rot_angle(R.cpu(), Ro)
+    assert dT < 1e-4 and dR < 1e-4, (dT, dR)
+    assert conf.shape[0] == co.shape[0] and abs(rmse - ro) < 1e-3
