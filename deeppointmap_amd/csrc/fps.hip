@@ -9,7 +9,8 @@
 // One workgroup per frame (the K-1 rounds of a frame are strictly serial); two algorithms:
 //
 //  * REGISTER (N <= 16384): every thread keeps PPT points (x,y,z,closest) in registers for the
-//    whole run; a round = PPT distance updates + one wave reduction + one LDS exchange.
+//    whole run; a round = PPT distance updates + one DPP wave arg-max + one LDS exchange (the
+//    winner's coordinates travel with it, so nothing is re-read from memory).
 //
 //  * BUCKET (N up to 65536): points are counting-sorted by a 64x64 xy grid cell in Z-order and
 //    cut into buckets of 64 consecutive points (one bucket = one wave-wide load).  Thread t owns
@@ -32,22 +33,6 @@ struct Best {
     float v;
     int i;
 };
-
-__device__ __forceinline__ Best better(Best a, Best b) {
-    // larger value wins; on equal value the smaller index wins (torch.argmax = first maximum)
-    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
-}
-
-__device__ __forceinline__ Best wave_best(Best x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        Best o;
-        o.v = __shfl_xor(x.v, off, 64);
-        o.i = __shfl_xor(x.i, off, 64);
-        x = better(x, o);
-    }
-    return x;
-}
 
 __device__ __forceinline__ float sqdist(float sx, float sy, float sz, float x, float y, float z) {
     const float dx = sx - x, dy = sy - y, dz = sz - z;
