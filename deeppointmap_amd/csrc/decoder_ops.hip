@@ -849,7 +849,47 @@ __global__ __launch_bounds__(KB) void corr_kabsch_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Map-tile assembly (PoseGraph.__global_mapping + the centring of global_map_query_graph,
+// system/modules/pose_graph.py:373-409,504-510): tile[:, k*S + s] = key_points[sel[k]][:, s] with the last three
+// rows (xyz, metres) mapped by  R_c^T ((R_k x + t_k) - t_c);  feature rows are copied.  Both 3x3 products are
+// evaluated like the reference's fp32 matmuls (k-ordered fma chains, then the broadcast add / subtract).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void map_tile_kernel(const float *__restrict__ kp, const int32_t *__restrict__ sel,
+                                                       const float *__restrict__ poses /* (n_scans,12) */,
+                                                       const float *__restrict__ center /* 12 */, int C, int S, int K,
+                                                       float *__restrict__ out) {
+    const int k = blockIdx.y, sc = sel ? sel[k] : k;
+    const float *src = kp + (size_t)sc * C * S;
+    const int ld = K * S;
+    const int cf = C - 3;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < cf * S; e += gridDim.x * 256) {
+        const int c = e / S, s_ = e - c * S;
+        out[(size_t)c * ld + k * S + s_] = src[e];
+    }
+    const float *P = poses + (size_t)sc * 12;
+    for (int s_ = blockIdx.x * 256 + threadIdx.x; s_ < S; s_ += gridDim.x * 256) {
+        const float x = src[(size_t)cf * S + s_], y = src[(size_t)(cf + 1) * S + s_], z = src[(size_t)(cf + 2) * S + s_];
+        float w[3], d[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) w[a] = fmaf(P[3 * a + 2], z, fmaf(P[3 * a + 1], y, P[3 * a] * x)) + P[9 + a];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) d[a] = w[a] - center[9 + a];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)  // row a of R_c^T = column a of R_c
+            out[(size_t)(cf + a) * ld + k * S + s_] = fmaf(center[6 + a], d[2], fmaf(center[3 + a], d[1], center[a] * d[0]));
+    }
+}
+
 }  // namespace
+
+extern "C" int dpm_map_tile(const float *key_points, const int32_t *select, const float *poses, const float *centering,
+                            int C, int S, int K, float *out, dpm_stream_t stream) {
+    DPM_CHECK_ARG(key_points && poses && centering && out && C > 3 && S >= 1 && K >= 1);
+    hipLaunchKernelGGL(map_tile_kernel, dim3(dpm_cdiv((long long)(C - 3) * S, 256 * 4), K), dim3(256), 0, (hipStream_t)stream,
+                       key_points, select, poses, centering, C, S, K, out);
+    return dpm_launch_status();
+}
 
 extern "C" int dpm_posemb(const float *xyz, int ld, const float *dim_t, int F, int E, int R, float *out,
                           dpm_stream_t stream) {

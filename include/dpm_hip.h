@@ -185,6 +185,15 @@ int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, long
                     int num_iter, double std_ratio, void *workspace, float *result, float *header,
                     int header_stride, dpm_stream_t stream);
 
+/* ---------------------------------------------------------------- map tiles ------------- */
+
+/* PoseGraph.__global_mapping + centring of global_map_query_graph (system/modules/pose_graph.py:373-409,
+ * 504-510): key_points (n_scans,C,S) device-resident unified descriptors (last three rows xyz in metres),
+ * select (K) scan indices in tile order (NULL: 0..K-1), poses (n_scans,12) [R row-major, T] = SE3_pred,
+ * centering (12) -> out (C, K*S): features copied, xyz -> R_c^T ((R_k x + t_k) - t_c). */
+int dpm_map_tile(const float *key_points, const int32_t *select, const float *poses, const float *centering,
+                 int C, int S, int K, float *out, dpm_stream_t stream);
+
 /* ---------------------------------------------------------------- registration edge ---- */
 
 /* calculate_information_matrix_from_pcd (system/modules/utils.py:60-113), pytorch3d branch:

@@ -482,3 +482,19 @@ def rotation_angle(R: Tensor) -> float:
 
 def simvec_to_num(v: Tensor) -> float:
     return v.flatten()[:30].mean().item()
+
+
+# ----------------------------------------------------------------------------------------------
+# map tiles                          system/modules/pose_graph.py:373-409, 504-510
+# ----------------------------------------------------------------------------------------------
+def map_tile(key_points: Sequence[Tensor], SE3_pred: Sequence[Tensor], centering_SE3: Tensor) -> Tensor:
+    """key_points: (C,S) unified descriptors in tile order -> (C, K*S): xyz rows -> R_c^T ((R_k x + t_k) - t_c)."""
+    parts = []
+    for kp, se3 in zip(key_points, SE3_pred):
+        p = kp.clone()
+        p[-3:, :] = se3[:3, :3] @ p[-3:, :] + se3[:3, 3:]
+        parts.append(p)
+    tile = torch.cat(parts, dim=1)
+    R, t = centering_SE3[:3, :3], centering_SE3[:3, 3:]
+    tile[-3:, :] = R.T @ (tile[-3:, :] - t)
+    return tile

@@ -264,8 +264,64 @@ def gen_poses_full(n_frames=6):
     save("poses_full.npz", **out)
 
 
+def gen_maptile():
+    """PoseGraph.global_map_query_graph (system/modules/pose_graph.py:471-511) on a 6-scan chain: the reference's own
+    map-tile assembly (per-scan SE3 transform of the descriptor coordinates, concat in BFS order, re-centring).
+    Needs import stubs for packages the container lacks (open3d, readerwriterlock); none of them is executed."""
+    import types
+    o3d = types.ModuleType("open3d")
+    sys.modules.setdefault("open3d", o3d)
+    rw = types.ModuleType("readerwriterlock")
+    rwl = types.ModuleType("readerwriterlock.rwlock")
+
+    class _L:
+        def acquire(self, blocking=True):
+            return True
+
+        def release(self):
+            pass
+
+    class RWLockFair:
+        def gen_rlock(self):
+            return _L()
+
+        def gen_wlock(self):
+            return _L()
+
+    rwl.RWLockFair = RWLockFair
+    rw.rwlock = rwl
+    sys.modules.setdefault("readerwriterlock", rw)
+    sys.modules.setdefault("readerwriterlock.rwlock", rwl)
+    from system.modules.pose_graph import PoseGraph, PoseGraph_Edge, ScanPack  # noqa: E402  (reference)
+
+    g = torch.Generator().manual_seed(21)
+    enc = np.load(os.path.join(HERE, "encoder_full.npz"))
+    base = torch.cat([torch.from_numpy(enc["synthetic0.fea"]), torch.from_numpy(enc["synthetic0.coor"]) * 60.0], 0)
+    pg = PoseGraph(args=None, agent_id=0, device="cpu")
+    kps, poses = [], []
+    for i in range(6):
+        kp = base + torch.cat([0.01 * torch.rand(128, 256, generator=g), 0.5 * torch.randn(3, 256, generator=g)])
+        a = 0.3 * i
+        SE3 = torch.eye(4)
+        SE3[:3, :3] = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float32)
+        SE3[:3, 3] = torch.tensor([4.0 * i, 1.5 * i * (-1) ** i, 0.1 * i])
+        sp = ScanPack(timestamp=float(i), agent_id=0, timestep=i, key_points=kp, full_pcd=None, SE3_pred=SE3, coor_sys=0)
+        if i == 4:
+            sp = sp.nonkeyframe()  # must be skipped by the query
+        pg.add_vertex(sp)
+        kps.append(kp)
+        poses.append(SE3)
+    for i in range(5):
+        pg.add_edge(PoseGraph_Edge(i, i + 1, torch.eye(4), torch.eye(6), "odom" if i != 2 else "loop"))
+    center = poses[2].clone()
+    tile, tok = pg.global_map_query_graph(token=2, neighbor_level=5, coor_sys=0, max_dist=11.0, centering_SE3=center)
+    save("maptile.npz", key_points=torch.stack(kps), SE3=torch.stack(poses), centering=center, tile=tile, tokens=tok)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fps", "knn", "encoder", "decoder", "poses"]
+    which = sys.argv[1:] or ["fps", "knn", "encoder", "decoder", "poses", "maptile"]
+    if "maptile" in which:
+        gen_maptile()
     if "poses" in which:
         gen_poses_full()
     if "fps" in which:
