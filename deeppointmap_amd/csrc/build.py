@@ -23,6 +23,7 @@ SOURCES = {
     "group_mlp.hip": [],
     "decoder_ops.hip": [],
     "infomat.hip": [],
+    "preprocess.hip": [],
 }
 
 

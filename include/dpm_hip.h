@@ -185,6 +185,19 @@ int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, long
                     int num_iter, double std_ratio, void *workspace, float *result, float *header,
                     int header_stride, dpm_stream_t stream);
 
+/* ---------------------------------------------------------------- scan pre-processing ---- */
+
+/* VoxelSample(voxel_size, 'first') -> DistanceSample(min_dis, max_dis) -> CoordinatesNormalization(ratio)
+ * (dataloader/transforms.py:322-356,387-397,400-407): xyz = N raw points, `stride` floats apart (3 for packed
+ * xyz, 4 for KITTI .bin records).  Output: the kept points in ascending voxel-id order, divided by ratio
+ * (out_xyz (out_capacity,3)), their original indices (out_idx, NULL-able), status[0] = number kept,
+ * status[1] = 1 if the voxel grid (X*Y*Z cells) exceeded max_cells (nothing is written then).
+ * workspace: dpm_preprocess_workspace_bytes(max_cells). */
+size_t dpm_preprocess_workspace_bytes(long long max_cells);
+int dpm_preprocess_scan(const float *xyz, int N, int stride, double voxel_size, double min_dis, double max_dis,
+                        double ratio, long long max_cells, float *out_xyz, int32_t *out_idx, int out_capacity,
+                        int32_t *status, void *workspace, dpm_stream_t stream);
+
 /* ---------------------------------------------------------------- map tiles ------------- */
 
 /* PoseGraph.__global_mapping + centring of global_map_query_graph (system/modules/pose_graph.py:373-409,

@@ -498,3 +498,23 @@ def map_tile(key_points: Sequence[Tensor], SE3_pred: Sequence[Tensor], centering
     R, t = centering_SE3[:3, :3], centering_SE3[:3, 3:]
     tile[-3:, :] = R.T @ (tile[-3:, :] - t)
     return tile
+
+
+# ----------------------------------------------------------------------------------------------
+# scan pre-processing                dataloader/transforms.py:322-356, 387-407
+# ----------------------------------------------------------------------------------------------
+def preprocess_scan(xyz: Tensor, voxel_size: float = 0.3, min_dis: float = 1.0, max_dis: float = 60.0,
+                    ratio: float = 60.0) -> Tuple[Tensor, Tensor]:
+    """xyz (N,3) f32 -> (kept points (M,3) / ratio, their original indices (M,)).
+    VoxelSample(retention='first'): first point of every occupied voxel, voxels in ascending id order;
+    DistanceSample: min_dis <= ||p|| <= max_dis; CoordinatesNormalization: true division."""
+    p = xyz.numpy().astype(np.float32)
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    X, Y, Z = ((hi - lo) / voxel_size).astype(np.int32) + 1
+    v = ((p - lo) / voxel_size).astype(np.int32)
+    vid = (v[:, 0] + v[:, 1] * X + v[:, 2] * X * Y).astype(np.int32)
+    _, first = np.unique(vid, return_index=True)
+    q = torch.from_numpy(p[first])
+    d = torch.norm(q, p=2, dim=1)
+    keep = (min_dis <= d) & (d <= max_dis)
+    return q[keep] / ratio, torch.from_numpy(first)[keep]

@@ -318,8 +318,34 @@ def gen_maptile():
     save("maptile.npz", key_points=torch.stack(kps), SE3=torch.stack(poses), centering=center, tile=tile, tokens=tok)
 
 
+sys.path.insert(0, HERE)
+from raw_scan import raw_scan  # noqa: E402  (tests/golden/raw_scan.py: the seeded synthetic raw scan)
+
+
+def gen_preprocess():
+    """VoxelSample(0.3,'first') -> DistanceSample(1,60) -> CoordinatesNormalization(60) with the reference's own
+    transform classes (dataloader/transforms.py; open3d stubbed, never executed)."""
+    import types
+    sys.modules.setdefault("open3d", types.ModuleType("open3d"))
+    from dataloader.transforms import CoordinatesNormalization, DistanceSample, PointCloud, VoxelSample  # noqa: E402
+    out = {}
+    enc = np.load(os.path.join(HERE, "encoder_full.npz"))
+    cases = {"raw120k": raw_scan(), "kitti0_m": torch.from_numpy(enc["kitti0.points"]).t().contiguous() * 60.0}
+    for name, xyz in cases.items():
+        pcd = PointCloud(xyz.numpy().copy())
+        for tf in (VoxelSample(voxel_size=0.3, retention="first"), DistanceSample(min_dis=1.0, max_dis=60.0),
+                   CoordinatesNormalization(ratio=60.0)):
+            pcd = tf(pcd)
+        out[name + ".out"] = pcd.xyz
+        if name != "raw120k":
+            out[name + ".in"] = xyz
+    save("preprocess.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fps", "knn", "encoder", "decoder", "poses", "maptile"]
+    which = sys.argv[1:] or ["fps", "knn", "encoder", "decoder", "poses", "maptile", "preprocess"]
+    if "preprocess" in which:
+        gen_preprocess()
     if "maptile" in which:
         gen_maptile()
     if "poses" in which:
