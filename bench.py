@@ -160,9 +160,8 @@ def main():
         if done is not None:
             gather_step_results(*done)
 
-    def drain():  # the last submitted batch is finished INSIDE the timed region
-        done = hot.flush()
-        if done is not None:
+    def drain():  # the batches still in the pipe are finished INSIDE the timed region
+        for done in hot.flush():
             gather_step_results(*done)
 
     def fence():
@@ -217,7 +216,7 @@ def main():
                                    "registration_forward (256x256) + information matrix per frame",
                        "frames_per_gpu_per_step": F, "points_per_frame": N,
                        "parallelism": f"frame-sharded x{world}, one RCCL gather of descriptors+edges per step",
-                       "pipeline": "none" if args.no_pipeline else "batch i+1 staging + FPS chain on a side HIP stream overlaps batch i",
+                       "pipeline": "none" if args.no_pipeline else "3 stages on 3 HIP streams: geometry (staging+FPS chain) of batch i | features of batch i-1 | registration+information matrices of batch i-2",
                        "weights": "procedural (deeppointmap_amd/weights.py)"},
             "roofline": {"kernel": "fps_bucket_sort_kernel+fps_bucket_kernel (stage-0 farthest point sampling)",
                          "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",

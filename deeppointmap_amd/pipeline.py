@@ -83,35 +83,73 @@ class HotPath:
         edges, table = self.register(desc, pcd_m, [((f - 1) % F, f) for f in range(F)], materialize=materialize)
         return desc, edges, table
 
-    # -- streaming mode: two-stage software pipeline over consecutive batches ---------------------------
+    # -- streaming mode: three-stage software pipeline over consecutive batches ---------------------------
+    #   stage G (stream A): geometry of batch i      -- staging + the FPS chain (one CU per frame, latency-bound)
+    #   stage F (caller's stream): features of batch i-1 -- kNN, grouped MLPs, GEMMs -> descriptors
+    #   stage R (stream B): registration of batch i-2 -- decoder + information matrices (many small-grid kernels)
+    # The three stages touch disjoint data, so they overlap on the chip; flush() drains the pipe, so K submits +
+    # flush contain exactly K batches of work.
     @torch.no_grad()
     def submit(self, points: torch.Tensor, padding: torch.Tensor, pcd_m: Optional[torch.Tensor]):
-        """Enqueue a batch.  Its input staging + first-level FPS (one CU per frame, latency-bound) start at
-        once on a side stream; the rest of the PREVIOUS batch (remaining encoder stages, registration,
-        information matrices) is enqueued on the current stream and overlaps with it.  Returns the previous
-        batch's (desc, table) or None for the first call; flush() returns the last one.  Inputs must already
-        be ready on the device (they are read from the side stream without waiting for the current one)."""
+        """Enqueue a batch; returns the (desc, table) of the batch submitted two calls earlier (None while the
+        pipe fills).  Inputs must already be ready on the device (stage G reads them without waiting for the
+        caller's stream)."""
         dev = self.encoder.device
         main = torch.cuda.current_stream(dev)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(self._side):
+            self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            self._pending = [None, None]  # [awaiting features, awaiting registration]
+        sa, sb = self._side
+        with torch.cuda.stream(sa):
             pre = self.encoder.presample(points, padding)
-            ready = self._side.record_event()
+            ready = sa.record_event()
         for t in pre.values():
-            t.record_stream(main)  # produced on the side stream, consumed on the main one
-        prev, self._pending = self._pending, (pre, ready, points, padding, pcd_m)
-        return self._finish(prev) if prev is not None else None
+            t.record_stream(main)  # produced on stream A, consumed on the caller's stream
+        geo, self._pending[0] = self._pending[0], (pre, ready, points, padding, pcd_m)
+        done = None
+        if geo is not None:
+            done = self._advance(geo)
+        return done
+
+    def _advance(self, geo):
+        """features of `geo` on the caller's stream, then registration of the batch before it on stream B."""
+        dev = self.encoder.device
+        main = torch.cuda.current_stream(dev)
+        sb = self._side[1]
+        pre, ready, points, padding, pcd_m = geo
+        main.wait_event(ready)
+        desc = self.extract(points, padding, presampled=pre)
+        desc_ready = main.record_event()
+        desc.record_stream(sb)
+        reg, self._pending[1] = self._pending[1], (desc, desc_ready, pcd_m)
+        return self._register_on_b(reg) if reg is not None else None
+
+    def _register_on_b(self, reg):
+        dev = self.encoder.device
+        main = torch.cuda.current_stream(dev)
+        sb = self._side[1]
+        desc, desc_ready, pcd_m = reg
+        with torch.cuda.stream(sb):
+            sb.wait_event(desc_ready)
+            F = desc.shape[0]
+            _, table = self.register(desc, pcd_m, [((f - 1) % F, f) for f in range(F)], materialize=False)
+            done = sb.record_event()
+        table.record_stream(main)
+        main.wait_event(done)  # the caller's stream sees finished results (e.g. for the RCCL gather)
+        return desc, table
 
     @torch.no_grad()
     def flush(self):
-        prev, self._pending = self._pending, None
-        return self._finish(prev) if prev is not None else None
-
-    def _finish(self, item):
-        pre, ready, points, padding, pcd_m = item
-        torch.cuda.current_stream(self.encoder.device).wait_event(ready)
-        desc = self.extract(points, padding, presampled=pre)
-        F = desc.shape[0]
-        _, table = self.register(desc, pcd_m, [((f - 1) % F, f) for f in range(F)], materialize=False)
-        return desc, table
+        """Drain the pipe: returns the list of (desc, table) still in flight, oldest first."""
+        out = []
+        if self._side is None:
+            return out
+        if self._pending[0] is not None:
+            geo, self._pending[0] = self._pending[0], None
+            r = self._advance(geo)
+            if r is not None:
+                out.append(r)
+        if self._pending[1] is not None:
+            reg, self._pending[1] = self._pending[1], None
+            out.append(self._register_on_b(reg))
+        return out

@@ -80,8 +80,8 @@ def test_streaming_pipeline_equals_plain_steps(hot):
         r = hot.submit(p, m, q)
         if r is not None:
             outs.append(r)
-    outs.append(hot.flush())
-    assert hot.flush() is None and len(outs) == 3
+    outs.extend(hot.flush())
+    assert hot.flush() == [] and len(outs) == 3
     torch.cuda.synchronize()
     for (d0, t0), (d1, t1) in zip(plain, outs):
         assert torch.equal(d0, d1) and torch.equal(t0, t1)
