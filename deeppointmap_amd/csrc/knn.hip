@@ -331,7 +331,9 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
                                                               const int32_t *__restrict__ lengths,
                                                               const float *__restrict__ centers_all, int N,
                                                               int S, int K, float r2,
-                                                              int32_t *__restrict__ idx_all) {
+                                                              int32_t *__restrict__ idx_all,
+                                                              const int32_t *__restrict__ reuse_idx,
+                                                              const int32_t *__restrict__ center_src) {
     __shared__ float s_d[WPB][CPW][CAP];
     __shared__ int s_i[WPB][CPW][CAP];
     __shared__ float s_td[WPB][TMPN];
@@ -339,6 +341,19 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
     const int b = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s0 = (blockIdx.x * WPB + w) * CPW;
     if (s0 >= S) return;  // whole wave exits together; no block-wide barrier is used below
+    if (reuse_idx) {
+        // centres that ARE points of this frame (center_src >= 0) were already answered by the self-query over
+        // all points with the same radius and K: copy those rows; only padded centres are computed
+        bool all = true;
+        for (int j = 0; j < CPW && s0 + j < S; ++j) all &= center_src[(size_t)b * S + s0 + j] >= 0;
+        if (all) {
+            for (int j = 0; j < CPW && s0 + j < S; ++j) {
+                const int src = center_src[(size_t)b * S + s0 + j];
+                if (lane < K) idx_all[((size_t)b * S + s0 + j) * K + lane] = reuse_idx[((size_t)b * N + src) * K + lane];
+            }
+            return;
+        }
+    }
     const float *pts = points_all + (size_t)b * N * 3;
     const float *ctr = centers_all + (size_t)b * S * 3;
     const int len = min(max(lengths[b], 0), N);
@@ -452,7 +467,9 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
                                                             int K, float r2, const KnnGrid *__restrict__ hdr_all,
                                                             const int *__restrict__ start_all,
                                                             const float4 *__restrict__ sorted_all,
-                                                            int32_t *__restrict__ idx_all) {
+                                                            int32_t *__restrict__ idx_all,
+                                                            const int32_t *__restrict__ reuse_idx,
+                                                            const int32_t *__restrict__ center_src) {
     __shared__ float s_d[WPB][CAP];
     __shared__ int s_i[WPB][CAP];
     __shared__ float s_td[WPB][TMPN];
@@ -460,6 +477,13 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
     const int b = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * WPB + w;
     if (s >= S) return;
+    if (reuse_idx) {
+        const int src = center_src[(size_t)b * S + s];
+        if (src >= 0) {  // this centre is point `src` of the frame: its row of the self-query is the answer
+            if (lane < K) idx_all[((size_t)b * S + s) * K + lane] = reuse_idx[((size_t)b * N + src) * K + lane];
+            return;
+        }
+    }
     const float *pts = points_all + (size_t)b * N * 3;
     const int len = min(max(lengths[b], 0), N);
     const KnnGrid G = hdr_all[b];
@@ -551,9 +575,11 @@ extern "C" size_t dpm_knn_workspace_bytes(int B, int N) {
            (size_t)B * (size_t)N * sizeof(float4);
 }
 
-extern "C" int dpm_knn_hybrid(const float *points, const int32_t *lengths, const float *centers, int B, int N,
-                              int S, int K, double radius, int32_t *idx, void *workspace, dpm_stream_t stream) {
+extern "C" int dpm_knn_hybrid_reuse(const float *points, const int32_t *lengths, const float *centers, int B, int N,
+                                    int S, int K, double radius, int32_t *idx, void *workspace,
+                                    const int32_t *reuse_idx, const int32_t *center_src, dpm_stream_t stream) {
     DPM_CHECK_ARG(points && lengths && centers && idx);
+    DPM_CHECK_ARG((reuse_idx == nullptr) == (center_src == nullptr));
     DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && radius > 0.0);
     if (K > KMAX) return DPM_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -570,10 +596,15 @@ extern "C" int dpm_knn_hybrid(const float *points, const int32_t *lengths, const
         hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, st, points, lengths, N, cs_min, hdr, start,
                            sorted);
         hipLaunchKernelGGL(knn_grid_kernel, dim3(dpm_cdiv(S, WPB), B), dim3(WPB * 64), 0, st, points, lengths, centers, N,
-                           S, K, r2, hdr, start, sorted, idx);
+                           S, K, r2, hdr, start, sorted, idx, reuse_idx, center_src);
         return dpm_launch_status();
     }
     hipLaunchKernelGGL(knn_hybrid_kernel, dim3(dpm_cdiv(S, WPB * CPW), B), dim3(WPB * 64), 0, st, points, lengths, centers,
-                       N, S, K, r2, idx);
+                       N, S, K, r2, idx, reuse_idx, center_src);
     return dpm_launch_status();
+}
+
+extern "C" int dpm_knn_hybrid(const float *points, const int32_t *lengths, const float *centers, int B, int N,
+                              int S, int K, double radius, int32_t *idx, void *workspace, dpm_stream_t stream) {
+    return dpm_knn_hybrid_reuse(points, lengths, centers, B, N, S, K, radius, idx, workspace, nullptr, nullptr, stream);
 }

@@ -94,12 +94,20 @@ class Encoder(ParamTree):
             else:  # extra input channels: point-major copy of the first in_channel rows
                 fea = ops.linear(pts[:, :self.in_channel].transpose(1, 2).contiguous(), w0, self.p("point_mlp0.bias"))
             levels = [(xyz, fea, lengths)]
+            # Neighbour queries repeat: a SetAbstraction asks, for the FPS-picked subset of a level's points, exactly
+            # what the preceding LocalAggregation answered for ALL of them when radius and K coincide (they do in every
+            # shipped config), and consecutive LocalAggregations of a stage may share (radius, K) too.  `self_q`
+            # remembers the self-queries of the current level: (radius, K) -> idx (B,N,K).
+            self_q = {}
             for i, npoint in enumerate(enc.npoint):
                 xyz, fea, lengths = levels[-1]
                 radii, ks = enc.radius_list[i], enc.nsample_list[i]
                 pre = f"downsampler.{i}"
                 fidx, new_xyz, new_len = samp[f"fidx{i}"], samp[f"xyz{i}"], samp[f"len{i}"]
-                gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0])
+                prev = self_q.get((float(radii[0]), int(ks[0])))
+                gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0], reuse_idx=prev,
+                                      center_src=fidx if prev is not None else None)
+                self_q = {}  # from here on the level is the sampled one
                 if fea is None:
                     m = pre + ".sa.mlp"
                     new_fea = ops.group_mlp_max_from_xyz(xyz, w0, self.p("point_mlp0.bias"), new_xyz, gidx,
@@ -112,7 +120,10 @@ class Encoder(ParamTree):
                     trace[pre + ".sa.idx"], trace[pre + ".sa.out"] = gidx, new_fea
                 for j in range(1, len(radii)):
                     q = f"{pre}.irm.{j - 1}"
-                    lidx = ops.knn_hybrid(new_xyz, new_len, new_xyz, ks[j], radii[j])
+                    key = (float(radii[j]), int(ks[j]))
+                    if key not in self_q:
+                        self_q[key] = ops.knn_hybrid(new_xyz, new_len, new_xyz, ks[j], radii[j])
+                    lidx = self_q[key]
                     t = self._group(q + ".la.mlp", radii[j], new_xyz, new_fea, new_xyz, lidx)
                     u = self._mlp_ln(t, q + ".pw_conv.0", q + ".pw_conv.1.ln", ops.ACT_RELU)
                     new_fea = self._mlp_ln(u, q + ".pw_conv.3", q + ".pw_conv.4.ln", ops.ACT_RELU, post=new_fea)

@@ -70,8 +70,11 @@ def fps(xyz: torch.Tensor, lengths: torch.Tensor, K: int, algo: int = 0):
 
 
 def knn_hybrid(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tensor, K: int,
-               radius: float, brute: bool = False) -> torch.Tensor:
-    """points (B,N,3), centers (B,S,3) -> idx (B,S,K) int32.  brute=True forces the all-pairs scan."""
+               radius: float, brute: bool = False, reuse_idx: Optional[torch.Tensor] = None,
+               center_src: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """points (B,N,3), centers (B,S,3) -> idx (B,S,K) int32.  brute=True forces the all-pairs scan.
+    reuse_idx (B,N,K) + center_src (B,S): centres that are points of the frame (center_src >= 0) copy their row of
+    the already computed self-query (same radius, same K); only padded centres are searched."""
     _chk(points, torch.float32, "points")
     _chk(centers, torch.float32, "centers")
     _chk(lengths, torch.int32, "lengths")
@@ -81,8 +84,13 @@ def knn_hybrid(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tenso
     lib = _lib.load()
     nbytes = 0 if brute else lib.dpm_knn_workspace_bytes(B, N)
     ws = torch.empty(nbytes, device=points.device, dtype=torch.uint8) if nbytes else None
-    _lib.check(lib.dpm_knn_hybrid(_ptr(points), _ptr(lengths), _ptr(centers), B, N, S, K, float(radius),
-                                  _ptr(idx), _ptr(ws), _stream(points)), "dpm_knn_hybrid")
+    if reuse_idx is not None:
+        _chk(reuse_idx, torch.int32, "reuse_idx"), _chk(center_src, torch.int32, "center_src")
+        if tuple(reuse_idx.shape) != (B, N, K) or tuple(center_src.shape) != (B, S):
+            raise ValueError("reuse_idx must be (B,N,K) and center_src (B,S)")
+    _lib.check(lib.dpm_knn_hybrid_reuse(_ptr(points), _ptr(lengths), _ptr(centers), B, N, S, K, float(radius),
+                                        _ptr(idx), _ptr(ws), _ptr(reuse_idx), _ptr(center_src), _stream(points)),
+               "dpm_knn_hybrid")
     return idx
 
 

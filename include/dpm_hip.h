@@ -73,6 +73,14 @@ size_t dpm_knn_workspace_bytes(int B, int N);
 int dpm_knn_hybrid(const float *points, const int32_t *lengths, const float *centers, int B, int N,
                    int S, int K, double radius, int32_t *idx, void *workspace, dpm_stream_t stream);
 
+/* Same query when the centres are a SUBSET of the points (SetAbstraction centres are FPS picks of `points`) and the
+ * self-query of ALL points with the same radius and K has already been answered (the preceding LocalAggregation):
+ * center_src (B,S) = index of centre s in `points` (the FPS index, -1 for padded centres), reuse_idx (B,N,K) = that
+ * earlier answer.  Rows with center_src >= 0 are copied (they are the identical computation), padded ones computed. */
+int dpm_knn_hybrid_reuse(const float *points, const int32_t *lengths, const float *centers, int B, int N,
+                         int S, int K, double radius, int32_t *idx, void *workspace, const int32_t *reuse_idx,
+                         const int32_t *center_src, dpm_stream_t stream);
+
 /* Querier.ball_query / ball_query_t3d == pytorch3d.ops.ball_query (utils.py:57-73,99-110): the K
  * smallest indices among the valid points within `radius` (expanded-form distance, like the
  * reference), ascending, padded with the first of them.  idx (B,S,K). */

@@ -150,6 +150,24 @@ def test_knn_grid_equals_brute_force(ops):
         assert (a[:, -12:] == a[:, -12:, :1]).all()  # far-away centres: every slot is the nearest point
 
 
+def test_knn_reuse_of_self_query_is_identical(ops):
+    # SetAbstraction centres = FPS picks of the points: rows copied from the self-query must equal a fresh search,
+    # including frames with padded centres (fewer valid points than picks), on both the grid and the brute path
+    gen = torch.Generator().manual_seed(90)
+    for N, S, K, r in [(4096, 1024, 32, 0.1), (600, 256, 32, 0.3), (64, 16, 16, 1.6)]:
+        pts = torch.rand(3, N, 3, generator=gen)
+        lens = _lengths([N, max(S // 2, 4), N - 7])  # frame 1 has fewer valid points than S -> padded centres
+        fidx, ctr, clen = ops.fps(pts.to(DEV), lens, S)
+        full = ops.knn_hybrid(pts.to(DEV), lens, pts.to(DEV), K, r)
+        fresh = ops.knn_hybrid(pts.to(DEV), lens, ctr, K, r)
+        reused = ops.knn_hybrid(pts.to(DEV), lens, ctr, K, r, reuse_idx=full, center_src=fidx)
+        # same SETS and same slot 0 (the order of the other slots is unspecified: the grid is built with atomics)
+        for b in range(3):
+            assert idx_rows_equal_as_sets(fresh[b].cpu().numpy(), reused[b].cpu().numpy()).all(), (N, S, b)
+        assert torch.equal(fresh[..., 0], reused[..., 0])
+        assert int((fidx[1] < 0).sum()) > 0
+
+
 def test_knn_sparse_rows_pad_with_nearest(ops):
     pts = torch.tensor([[[0.0, 0, 0], [0.01, 0, 0], [5, 5, 5], [9, 9, 9]]])
     ctr = torch.tensor([[[0.0, 0, 0], [5.2, 5, 5], [100, 100, 100]]])
