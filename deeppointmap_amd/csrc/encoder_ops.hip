@@ -13,17 +13,23 @@ __global__ __launch_bounds__(256) void prepare_points_kernel(const float *__rest
                                                              const uint8_t *__restrict__ pad, int C, int N,
                                                              float *__restrict__ xyz,
                                                              int32_t *__restrict__ lengths) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // 256 points per block: the three coordinate planes are read coalesced, interleaved through LDS, and the
+    // 768 output floats are written coalesced
+    __shared__ float tile[3 * 256];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int i0 = blockIdx.x * 256, i = i0 + t;
+    const float *p = pcf + (size_t)b * C * N;
     int valid = 0;
     if (i < N) {
-        const float *p = pcf + (size_t)b * C * N;
-        float *o = xyz + ((size_t)b * N + i) * 3;
-        o[0] = p[i], o[1] = p[(size_t)N + i], o[2] = p[2 * (size_t)N + i];
+        tile[3 * t] = p[i], tile[3 * t + 1] = p[(size_t)N + i], tile[3 * t + 2] = p[2 * (size_t)N + i];
         valid = pad[(size_t)b * N + i] ? 0 : 1;
     }
+    __syncthreads();
+    const int n = min(256, N - i0);
+    float *o = xyz + ((size_t)b * N + i0) * 3;
+    for (int e = t; e < 3 * n; e += 256) o[e] = tile[e];
     const unsigned long long m = __ballot(valid);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&lengths[b], __popcll(m));
+    if ((t & 63) == 0 && m) atomicAdd(&lengths[b], __popcll(m));
 }
 
 __global__ __launch_bounds__(256) void to_channel_first_kernel(const float *__restrict__ x, int R, int C,
