@@ -50,12 +50,13 @@ class Encoder(ParamTree):
 
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
-    def presample(self, points: torch.Tensor, points_padding: torch.Tensor) -> dict:
+    def presample(self, points: torch.Tensor, points_padding: torch.Tensor, levels: Optional[int] = None) -> dict:
         """Input staging + the whole farthest-point-sampling chain (all levels), on the CURRENT stream.
         Sampling depends on coordinates only (level i+1 samples the points level i kept), never on features;
         it is a serial chain of dependent rounds that occupies one CU per frame, so a streaming caller runs it
         for batch i+1 on a side stream while batch i finishes on the main stream (pipeline.HotPath.submit).
-        Pass the result to forward(..., presampled=...)."""
+        Pass the result to forward(..., presampled=...).  `levels` limits the pass to the first FPS levels (the
+        remaining, much shorter ones then run inside forward) -- a knob for balancing pipeline stages."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("deeppointmap_amd.Encoder runs on the GPU only: call .to('cuda') first "
@@ -66,7 +67,8 @@ class Encoder(ParamTree):
             xyz, lengths = ops.prepare_points(pts, pad)
             out = dict(pts=pts, xyz=xyz, lengths=lengths)
             cur, cur_len = xyz, lengths
-            for i, npoint in enumerate(self.encoder_cfg.npoint):
+            n_levels = len(self.encoder_cfg.npoint) if levels is None else levels
+            for i, npoint in enumerate(self.encoder_cfg.npoint[:n_levels]):
                 fidx, cur, cur_len = ops.fps(cur, cur_len, npoint)
                 out[f"fidx{i}"], out[f"xyz{i}"], out[f"len{i}"] = fidx, cur, cur_len
         return out
@@ -103,7 +105,10 @@ class Encoder(ParamTree):
                 xyz, fea, lengths = levels[-1]
                 radii, ks = enc.radius_list[i], enc.nsample_list[i]
                 pre = f"downsampler.{i}"
-                fidx, new_xyz, new_len = samp[f"fidx{i}"], samp[f"xyz{i}"], samp[f"len{i}"]
+                if f"fidx{i}" in samp:
+                    fidx, new_xyz, new_len = samp[f"fidx{i}"], samp[f"xyz{i}"], samp[f"len{i}"]
+                else:  # levels the geometry pass left to this stream
+                    fidx, new_xyz, new_len = ops.fps(xyz, lengths, npoint)
                 prev = self_q.get((float(radii[0]), int(ks[0])))
                 gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0], reuse_idx=prev,
                                       center_src=fidx if prev is not None else None)

@@ -37,7 +37,8 @@ class HotPath:
     def __init__(self, encoder: Encoder, decoder: Decoder, coor_scale: float = 60.0, num_sample=0.5):
         self.encoder, self.decoder = encoder, decoder
         self.coor_scale, self.num_sample = float(coor_scale), num_sample
-        self._side = None      # side HIP stream for the software pipeline (submit / flush)
+        self.geometry_levels = None  # FPS levels run by the geometry stage (None = all; measured best on MI355X)
+        self._side = None      # side HIP streams for the software pipeline (submit / flush)
         self._pending = None
 
     @torch.no_grad()
@@ -101,7 +102,7 @@ class HotPath:
             self._pending = [None, None]  # [awaiting features, awaiting registration]
         sa, sb = self._side
         with torch.cuda.stream(sa):
-            pre = self.encoder.presample(points, padding)
+            pre = self.encoder.presample(points, padding, levels=self.geometry_levels)
             ready = sa.record_event()
         for t in pre.values():
             t.record_stream(main)  # produced on stream A, consumed on the caller's stream
