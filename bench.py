@@ -83,8 +83,8 @@ def cpu_baseline(n_frames: int, n_points: int, threads: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--points", type=int, default=65536)
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the cpu_baseline sample (0 = skip)")
@@ -216,7 +216,7 @@ def main():
                                    "registration_forward (256x256) + information matrix per frame",
                        "frames_per_gpu_per_step": F, "points_per_frame": N,
                        "parallelism": f"frame-sharded x{world}, one RCCL gather of descriptors+edges per step",
-                       "pipeline": "none" if args.no_pipeline else "3 stages on 3 HIP streams: geometry (staging+FPS chain) of batch i | features of batch i-1 | registration+information matrices of batch i-2",
+                       "pipeline": "none" if args.no_pipeline else "HIP-stream pipeline: geometry (staging+FPS chain) of batches i, i-1 on two alternating streams | features of batch i-2 | registration+information matrices of batch i-3",
                        "weights": "procedural (deeppointmap_amd/weights.py)"},
             "roofline": {"kernel": "fps_bucket_sort_kernel+fps_bucket_kernel (stage-0 farthest point sampling)",
                          "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",

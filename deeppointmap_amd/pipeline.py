@@ -38,6 +38,7 @@ class HotPath:
         self.encoder, self.decoder = encoder, decoder
         self.coor_scale, self.num_sample = float(coor_scale), num_sample
         self.geometry_levels = None  # FPS levels run by the geometry stage (None = all; measured best on MI355X)
+        self.geometry_depth = 2      # batches whose geometry pass is in flight ahead of the feature stage
         self._side = None      # side HIP streams for the software pipeline (submit / flush)
         self._pending = None
 
@@ -84,51 +85,55 @@ class HotPath:
         edges, table = self.register(desc, pcd_m, [((f - 1) % F, f) for f in range(F)], materialize=materialize)
         return desc, edges, table
 
-    # -- streaming mode: three-stage software pipeline over consecutive batches ---------------------------
-    #   stage G (stream A): geometry of batch i      -- staging + the FPS chain (one CU per frame, latency-bound)
-    #   stage F (caller's stream): features of batch i-1 -- kNN, grouped MLPs, GEMMs -> descriptors
-    #   stage R (stream B): registration of batch i-2 -- decoder + information matrices (many small-grid kernels)
-    # The three stages touch disjoint data, so they overlap on the chip; flush() drains the pipe, so K submits +
-    # flush contain exactly K batches of work.
+    # -- streaming mode: software pipeline over consecutive batches ----------------------------------------
+    #   stage G (streams A0/A1, alternating): geometry of batch i -- staging + the FPS chain.  It is a latency
+    #            chain on one CU per frame, so TWO batches' geometry passes are kept in flight (`geometry_depth`):
+    #            the stage's throughput, not its latency, then bounds the step.
+    #   stage F (caller's stream): features of batch i-depth -- kNN, grouped MLPs, GEMMs -> descriptors
+    #   stage R (stream B): registration of the batch before that -- decoder + information matrices
+    # The stages touch disjoint data, so they overlap on the chip; flush() drains the pipe, so K submits + flush
+    # contain exactly K batches of work.
     @torch.no_grad()
     def submit(self, points: torch.Tensor, padding: torch.Tensor, pcd_m: Optional[torch.Tensor]):
-        """Enqueue a batch; returns the (desc, table) of the batch submitted two calls earlier (None while the
-        pipe fills).  Inputs must already be ready on the device (stage G reads them without waiting for the
-        caller's stream)."""
+        """Enqueue a batch; returns the (desc, table) of an earlier batch once the pipe is full (None while it
+        fills).  Inputs must already be ready on the device (stage G reads them without waiting for the caller's
+        stream)."""
         dev = self.encoder.device
         main = torch.cuda.current_stream(dev)
         if self._side is None:
-            self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-            self._pending = [None, None]  # [awaiting features, awaiting registration]
-        sa, sb = self._side
+            self._side = dict(geo=[torch.cuda.Stream(device=dev) for _ in range(max(1, self.geometry_depth))],
+                              reg=torch.cuda.Stream(device=dev))
+            self._pending = dict(geo=[], reg=None, n=0)
+        sa = self._side["geo"][self._pending["n"] % len(self._side["geo"])]
+        self._pending["n"] += 1
         with torch.cuda.stream(sa):
             pre = self.encoder.presample(points, padding, levels=self.geometry_levels)
             ready = sa.record_event()
         for t in pre.values():
-            t.record_stream(main)  # produced on stream A, consumed on the caller's stream
-        geo, self._pending[0] = self._pending[0], (pre, ready, points, padding, pcd_m)
+            t.record_stream(main)  # produced on a geometry stream, consumed on the caller's stream
+        self._pending["geo"].append((pre, ready, points, padding, pcd_m))
         done = None
-        if geo is not None:
-            done = self._advance(geo)
+        if len(self._pending["geo"]) > self.geometry_depth:
+            done = self._advance(self._pending["geo"].pop(0))
         return done
 
     def _advance(self, geo):
         """features of `geo` on the caller's stream, then registration of the batch before it on stream B."""
         dev = self.encoder.device
         main = torch.cuda.current_stream(dev)
-        sb = self._side[1]
+        sb = self._side["reg"]
         pre, ready, points, padding, pcd_m = geo
         main.wait_event(ready)
         desc = self.extract(points, padding, presampled=pre)
         desc_ready = main.record_event()
         desc.record_stream(sb)
-        reg, self._pending[1] = self._pending[1], (desc, desc_ready, pcd_m)
+        reg, self._pending["reg"] = self._pending["reg"], (desc, desc_ready, pcd_m)
         return self._register_on_b(reg) if reg is not None else None
 
     def _register_on_b(self, reg):
         dev = self.encoder.device
         main = torch.cuda.current_stream(dev)
-        sb = self._side[1]
+        sb = self._side["reg"]
         desc, desc_ready, pcd_m = reg
         with torch.cuda.stream(sb):
             sb.wait_event(desc_ready)
@@ -145,12 +150,11 @@ class HotPath:
         out = []
         if self._side is None:
             return out
-        if self._pending[0] is not None:
-            geo, self._pending[0] = self._pending[0], None
-            r = self._advance(geo)
+        while self._pending["geo"]:
+            r = self._advance(self._pending["geo"].pop(0))
             if r is not None:
                 out.append(r)
-        if self._pending[1] is not None:
-            reg, self._pending[1] = self._pending[1], None
+        if self._pending["reg"] is not None:
+            reg, self._pending["reg"] = self._pending["reg"], None
             out.append(self._register_on_b(reg))
         return out
