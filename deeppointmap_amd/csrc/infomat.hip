@@ -34,7 +34,6 @@ struct GridHdr {       // lives at the start of each workspace slice
     float lox, loy, inv_cs;
     int gx, gy, ncell;
     int pad[2];
-    double sums[10];
 };
 
 __device__ __forceinline__ const float *pair_p1(const PairArgs &a, int p) {
@@ -45,9 +44,12 @@ __device__ __forceinline__ const float *pair_p2(const PairArgs &a, int p) {
 }
 __device__ __forceinline__ GridHdr *pair_hdr(const PairArgs &a, int p) { return (GridHdr *)(a.ws + (size_t)p * a.ws_stride); }
 __device__ __forceinline__ int *pair_count(const PairArgs &a, int p) { return (int *)(a.ws + (size_t)p * a.ws_stride + 256); }
-__device__ __forceinline__ int *pair_cursor(const PairArgs &a, int p) { return pair_count(a, p) + (GMAX * GMAX + 1); }
 __device__ __forceinline__ float4 *pair_sorted(const PairArgs &a, int p) {
-    return (float4 *)(a.ws + (size_t)p * a.ws_stride + 256 + 2 * sizeof(int) * (size_t)(GMAX * GMAX + 1) + 8);
+    return (float4 *)(a.ws + (size_t)p * a.ws_stride + 256 + sizeof(int) * (size_t)(GMAX * GMAX + 1) + 12);
+}
+// per-block partial moments [cdiv(N1,256)][10], after the sorted points
+__device__ __forceinline__ double *pair_partial(const PairArgs &a, int p) {
+    return (double *)(pair_sorted(a, p) + a.N2);
 }
 
 __global__ __launch_bounds__(1024) void grid_setup_kernel(PairArgs A, float radius) {
@@ -55,9 +57,7 @@ __global__ __launch_bounds__(1024) void grid_setup_kernel(PairArgs A, float radi
     const float *p2 = pair_p2(A, pair);
     const int N2 = A.N2;
     GridHdr *hdr = pair_hdr(A, pair);
-    int *count = pair_count(A, pair);
     __shared__ float red[4][16];
-    __shared__ int s_ncell;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     float lox = __builtin_inff(), loy = lox, hix = -lox, hiy = -lox;
     for (int i = t; i < N2; i += 1024) {
@@ -82,42 +82,86 @@ __global__ __launch_bounds__(1024) void grid_setup_kernel(PairArgs A, float radi
         hdr->gx = min(GMAX, (int)((hix - lox) / cs) + 1);
         hdr->gy = min(GMAX, (int)((hiy - loy) / cs) + 1);
         hdr->ncell = hdr->gx * hdr->gy;
-        s_ncell = hdr->ncell;
-        for (int k = 0; k < 10; ++k) hdr->sums[k] = 0.0;
     }
-    __syncthreads();
-    for (int c = t; c <= s_ncell; c += 1024) count[c] = 0;
+}
+
+// Grid (nblk, n_pairs) -> (block within the pair, pair) such that ALL blocks of one pair run on the SAME XCD.
+// Workgroups are dealt round-robin to the 8 XCDs by linear id and every XCD has a private 4 MB L2; with the
+// plain mapping each L2 sees the grids of all pairs at once (64 x 1 MB: every candidate load misses to the
+// fabric -- 4.8 GB per launch measured), with this one it holds the one or two pairs it is working on.
+__device__ __forceinline__ void pair_block(int &blk, int &pair) {
+    const int nblk = gridDim.x, npair = gridDim.y;
+    if (npair % 8 == 0) {
+        const unsigned L = blockIdx.y * nblk + blockIdx.x;
+        const unsigned xcd = L & 7, slot = L >> 3;
+        pair = (int)((slot / nblk) * 8 + xcd), blk = (int)(slot % nblk);
+    } else {
+        pair = blockIdx.y, blk = blockIdx.x;
+    }
 }
 
 __device__ __forceinline__ int cell_coord(float v, float lo, float inv_cs, int g) {
     return min(max((int)floorf((v - lo) * inv_cs), 0), g - 1);
 }
 
-__global__ __launch_bounds__(256) void grid_count_kernel(PairArgs A) {
-    const int pair = blockIdx.y;
+// Counting sort of pcd2 into the grid, entirely in LDS: the cells are split into SLABS contiguous index ranges
+// and one 1024-thread workgroup owns one slab of one pair.  It streams the pair's points twice (count, then
+// place), keeps its cells' counters / cursors in LDS and derives its global base offset from the number of
+// points that fall into earlier slabs, so slabs need no communication and there is no global atomic at all
+// (the three-kernel count / scan / scatter version spent 0.35 ms per launch in device-scope atomics).
+constexpr int SLABS = 8;
+constexpr int SLAB_CELLS = GMAX * GMAX / SLABS;  // 32768 counters = 128 KB of LDS
+
+__global__ __launch_bounds__(1024) void grid_build_kernel(PairArgs A) {
+    int pair, slab;
+    pair_block(slab, pair);
     const float *p2 = pair_p2(A, pair);
     const int N2 = A.N2;
     const GridHdr *hdr = pair_hdr(A, pair);
-    int *count = pair_count(A, pair);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N2) return;
-    const int cx = cell_coord(p2[i], hdr->lox, hdr->inv_cs, hdr->gx);
-    const int cy = cell_coord(p2[(size_t)N2 + i], hdr->loy, hdr->inv_cs, hdr->gy);
-    atomicAdd(&count[cy * hdr->gx + cx], 1);
-}
-
-// exclusive scan of count[0..ncell) in place -> cell start offsets; cursor = copy for the scatter
-__global__ __launch_bounds__(1024) void grid_scan_kernel(PairArgs A) {
-    const GridHdr *hdr = pair_hdr(A, blockIdx.x);
-    int *count = pair_count(A, blockIdx.x), *cursor = pair_cursor(A, blockIdx.x);
+    int *start = pair_count(A, pair);
+    float4 *sorted = pair_sorted(A, pair);
+    __shared__ int cnt[SLAB_CELLS];
     __shared__ int wsum[16];
+    __shared__ int s_before;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int ncell = hdr->ncell;
-    const int per = (ncell + 1023) / 1024;
-    const int c0 = t * per, c1 = min(c0 + per, ncell);
-    int s = 0;
-    for (int c = c0; c < c1; ++c) s += count[c];
-    int inc = s;
+    const int ncell = hdr->ncell, gx = hdr->gx, gy = hdr->gy;
+    const float lox = hdr->lox, loy = hdr->loy, inv_cs = hdr->inv_cs;
+    // as few slabs as the LDS allows (one for any grid up to 32768 cells, i.e. 180 m x 180 m at the 1 m radius):
+    // every slab streams all points, so extra slabs only cost; the surplus workgroups leave at once
+    const int used = (ncell + SLAB_CELLS - 1) / SLAB_CELLS;
+    if (slab >= used) return;
+    const int per = (ncell + used - 1) / used;
+    const int c0 = min(slab * per, ncell), c1 = min(c0 + per, ncell), nc = c1 - c0;
+    for (int c = t; c < nc; c += 1024) cnt[c] = 0;
+    if (t == 0) s_before = 0;
+    __syncthreads();
+    int before = 0;
+    constexpr int UB = 8;  // points per thread per batch: all loads of a batch are in flight before any is used
+    for (int i0 = t; i0 < N2; i0 += 1024 * UB) {
+        float xs[UB], ys[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = min(i0 + u * 1024, N2 - 1);
+            xs[u] = p2[i], ys[u] = p2[(size_t)N2 + i];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (i0 + u * 1024 >= N2) break;
+            const int cell = cell_coord(ys[u], loy, inv_cs, gy) * gx + cell_coord(xs[u], lox, inv_cs, gx);
+            if (cell < c0) ++before;
+            else if (cell < c1) atomicAdd(&cnt[cell - c0], 1);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    if (lane == 0 && before) atomicAdd(&s_before, before);
+    __syncthreads();
+    // exclusive scan of the slab's counters (base = points of earlier slabs) -> cell start offsets
+    const int chunk = (nc + 1023) / 1024;
+    const int a = min(t * chunk, nc), b = min(a + chunk, nc);
+    int sum = 0;
+    for (int c = a; c < b; ++c) sum += cnt[c];
+    int inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int o = __shfl_up(inc, off, 64);
@@ -125,70 +169,140 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(PairArgs A) {
     }
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    int base = 0;
-    for (int k = 0; k < w; ++k) base += wsum[k];
-    int run = base + inc - s;
-    for (int c = c0; c < c1; ++c) {
-        const int v = count[c];
-        count[c] = run, cursor[c] = run;
+    int run = s_before + inc - sum;
+    for (int k = 0; k < w; ++k) run += wsum[k];
+    for (int c = a; c < b; ++c) {
+        const int v = cnt[c];
+        cnt[c] = run, start[c0 + c] = run;
         run += v;
     }
-    if (t == 1023) count[ncell] = run;  // == N2
+    if (slab == used - 1 && t == 0) start[ncell] = N2;
+    __syncthreads();
+    for (int i0 = t; i0 < N2; i0 += 1024 * UB) {
+        float xs[UB], ys[UB], zs[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = min(i0 + u * 1024, N2 - 1);
+            xs[u] = p2[i], ys[u] = p2[(size_t)N2 + i], zs[u] = p2[2 * (size_t)N2 + i];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + u * 1024;
+            if (i >= N2) break;
+            const int cell = cell_coord(ys[u], loy, inv_cs, gy) * gx + cell_coord(xs[u], lox, inv_cs, gx);
+            if (cell >= c0 && cell < c1) {
+                const int pos = atomicAdd(&cnt[cell - c0], 1);
+                sorted[pos] = make_float4(xs[u], ys[u], zs[u], __int_as_float(i));
+            }
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void grid_scatter_kernel(PairArgs A) {
-    const int pair = blockIdx.y;
-    const float *p2 = pair_p2(A, pair);
-    const int N2 = A.N2;
-    const GridHdr *hdr = pair_hdr(A, pair);
-    int *cursor = pair_cursor(A, pair);
-    float4 *sorted = pair_sorted(A, pair);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N2) return;
-    const float x = p2[i], y = p2[(size_t)N2 + i], z = p2[2 * (size_t)N2 + i];
-    const int cx = cell_coord(x, hdr->lox, hdr->inv_cs, hdr->gx);
-    const int cy = cell_coord(y, hdr->loy, hdr->inv_cs, hdr->gy);
-    const int pos = atomicAdd(&cursor[cy * hdr->gx + cx], 1);
-    sorted[pos] = make_float4(x, y, z, __int_as_float(i));
+// quad_perm exchanges inside groups of 4 lanes (DPP, no LDS traffic)
+__device__ __forceinline__ float quad_xor1(float v) { return __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v))); }
+__device__ __forceinline__ float quad_xor2(float v) { return __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v))); }
+__device__ __forceinline__ float quad_min(float v) {
+    v = fminf(v, quad_xor1(v));
+    return fminf(v, quad_xor2(v));
 }
 
+// FOUR lanes per query: they scan consecutive candidates of the same cell range, so one 64-byte request serves
+// the quad (a lane-per-query scan issues 64 unrelated 16-byte requests per load instruction and is bound by the
+// texture-address unit, not by bytes).  A block still covers 256 queries, each quad taking four of them in turn.
 __global__ __launch_bounds__(256) void nn1_moments_kernel(PairArgs A, float r2) {
-    const int pair = blockIdx.y;
+    int pair, blk;
+    pair_block(blk, pair);
     const float *p1 = pair_p1(A, pair);
     const int N1 = A.N1;
     const float *Rt = A.Rt + (size_t)pair * A.rt_stride;  // 12 floats: R row-major, T
-    GridHdr *hdr = pair_hdr(A, pair);
+    const GridHdr *hdr = pair_hdr(A, pair);
     const int *start = pair_count(A, pair);
     const float4 *sorted = pair_sorted(A, pair);
     __shared__ double sred[4][10];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int quad = threadIdx.x >> 2, ql = threadIdx.x & 3;
+    const int gx = hdr->gx, gy = hdr->gy;
+    const float inv_cs = hdr->inv_cs, cs = 1.0f / inv_cs, lox = hdr->lox, loy = hdr->loy;
+    const float k2 = cs * cs * (1.f - 1e-5f);
     double m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (i < N1) {
+    for (int j = 0; j < 4; ++j) {
+        const int i = blk * 256 + j * 64 + quad;
+        if (i >= N1) break;  // uniform inside a quad
         const float x = p1[i], y = p1[(size_t)N1 + i], z = p1[2 * (size_t)N1 + i];
         // R @ pcd1 + T in fp32 (sgemm k-order fma chain, then the broadcast add)
         const float qx = fmaf(Rt[2], z, fmaf(Rt[1], y, Rt[0] * x)) + Rt[9];
         const float qy = fmaf(Rt[5], z, fmaf(Rt[4], y, Rt[3] * x)) + Rt[10];
         const float qz = fmaf(Rt[8], z, fmaf(Rt[7], y, Rt[6] * x)) + Rt[11];
-        const int gx = hdr->gx, gy = hdr->gy;
-        const int cx = (int)floorf((qx - hdr->lox) * hdr->inv_cs), cy = (int)floorf((qy - hdr->loy) * hdr->inv_cs);
+        const float fx = (qx - lox) * inv_cs, fy = (qy - loy) * inv_cs;  // position in cell units
+        const float flx = floorf(fx), fly = floorf(fy);
+        const int cx = (int)fmaxf(fminf(flx, 1e6f), -1e6f), cy = (int)fmaxf(fminf(fly, 1e6f), -1e6f);
+        // start offsets of the 3x3 neighbourhood, loaded up front (12 independent loads).  Cells of one grid row
+        // are contiguous in `sorted`, so rs[r][k] .. rs[r][k+1] is cell (cx-1+k, cy-1+r); columns outside the
+        // grid collapse to empty ranges through the clamp, rows outside the grid are all-zero.
+        int rs[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = cy - 1 + r;
+            const bool in = yy >= 0 && yy < gy;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rs[r][k] = in ? start[yy * gx + min(max(cx - 1 + k, 0), gx)] : 0;
+        }
+        // Distances (cell units) from the query to the neighbouring columns / rows, shrunk by a margin that
+        // covers the fp32 rounding of the cell assignment: (d - margin)^2 * cs^2 * (1 - 1e-5) is a strict lower
+        // bound of the computed distance to any point stored there, so skipping a cell whose bound exceeds the
+        // best distance so far (or radius^2 -- farther matches are discarded anyway) never changes the result.
+        const float mg = 1e-3f;
+        const float dl = fmaxf(fx - flx - mg, 0.f), dr = fmaxf(flx + 1.f - fx - mg, 0.f);
+        const float dd = fmaxf(fy - fly - mg, 0.f), du = fmaxf(fly + 1.f - fy - mg, 0.f);
+        const float l2 = dl * dl * k2, rr2 = dr * dr * k2, d2 = dd * dd * k2, u2 = du * du * k2;
         float best = __builtin_inff();
         int bi = 0x7fffffff;
         float bx = 0, by = 0, bz = 0;
-        for (int yy = max(cy - 1, 0); yy <= min(cy + 1, gy - 1); ++yy)
-            for (int xx = max(cx - 1, 0); xx <= min(cx + 1, gx - 1); ++xx) {
-                const int c = yy * gx + xx;
-                for (int p = start[c]; p < start[c + 1]; ++p) {
-                    const float4 t4 = sorted[p];
-                    const float dx = qx - t4.x, dy = qy - t4.y, dz = qz - t4.z;
-                    const float d = (dx * dx + dy * dy) + dz * dz;
-                    const int oi = __float_as_int(t4.w);
-                    if (d < best || (d == best && oi < bi)) best = d, bi = oi, bx = t4.x, by = t4.y, bz = t4.z;
+        // five segments visited as ONE flat loop (own cell, left, right, row below, row above): a quad moves on
+        // as soon as its own segment is exhausted, so a wave costs max-over-quads of the candidates actually
+        // visited instead of the sum over nine cells of the per-cell maxima.  p, e, seg are quad-uniform.
+        int seg = 0, p = 0, e = 0;
+        for (;;) {
+            while (p >= e && seg < 5) {
+                const float bound = fminf(quad_min(best), r2);
+                if (seg == 0) {
+                    p = rs[1][1], e = rs[1][2];
+                } else if (seg == 1) {
+                    p = rs[1][0], e = l2 > bound ? p : rs[1][1];
+                } else if (seg == 2) {
+                    p = rs[1][2], e = rr2 > bound ? p : rs[1][3];
+                } else if (seg == 3) {
+                    p = (l2 + d2 > bound) ? rs[0][1] : rs[0][0];
+                    e = d2 > bound ? p : ((rr2 + d2 > bound) ? rs[0][2] : rs[0][3]);
+                } else {
+                    p = (l2 + u2 > bound) ? rs[2][1] : rs[2][0];
+                    e = u2 > bound ? p : ((rr2 + u2 > bound) ? rs[2][2] : rs[2][3]);
                 }
+                ++seg;
             }
-        if (best <= r2) {
+            if (p >= e) break;
+            const int pp = p + ql;
+            p += 4;
+            if (pp < e) {
+                const float4 t4 = sorted[pp];
+                const float dx = qx - t4.x, dy = qy - t4.y, dz = qz - t4.z;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                const int oi = __float_as_int(t4.w);
+                if (d < best || (d == best && oi < bi)) best = d, bi = oi, bx = t4.x, by = t4.y, bz = t4.z;
+            }
+        }
+        // quad-wide arg-best: (smallest distance, then smallest original index), with the winner's coordinates
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+            const float od = step ? quad_xor2(best) : quad_xor1(best);
+            const int oi = __float_as_int(step ? quad_xor2(__int_as_float(bi)) : quad_xor1(__int_as_float(bi)));
+            const float ox = step ? quad_xor2(bx) : quad_xor1(bx), oy = step ? quad_xor2(by) : quad_xor1(by);
+            const float oz = step ? quad_xor2(bz) : quad_xor1(bz);
+            if (od < best || (od == best && oi < bi)) best = od, bi = oi, bx = ox, by = oy, bz = oz;
+        }
+        if (ql == 0 && best <= r2) {
             const double X = bx, Y = by, Z = bz;
-            m[0] = 1.0, m[1] = X, m[2] = Y, m[3] = Z, m[4] = X * X, m[5] = Y * Y, m[6] = Z * Z;
-            m[7] = X * Y, m[8] = X * Z, m[9] = Y * Z;
+            m[0] += 1.0, m[1] += X, m[2] += Y, m[3] += Z, m[4] += X * X, m[5] += Y * Y, m[6] += Z * Z;
+            m[7] += X * Y, m[8] += X * Z, m[9] += Y * Z;
         }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -200,17 +314,27 @@ __global__ __launch_bounds__(256) void nn1_moments_kernel(PairArgs A, float r2) 
         if (lane == 0) sred[w][k] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 10) {
-        const double v = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
-        if (v != 0.0) atomicAdd(&hdr->sums[threadIdx.x], v);
-    }
+    // one partial per block, summed in a fixed order by the finalize kernel: no same-address fp64 atomics
+    // (256 blocks of a pair hammering one cache line was the kernel's real bottleneck) and a reproducible result
+    if (threadIdx.x < 10)
+        pair_partial(A, pair)[(size_t)blk * 10 + threadIdx.x] =
+            (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
 }
 
-__global__ void infomat_finalize_kernel(PairArgs A) {
-    if (threadIdx.x != 0) return;
-    const GridHdr *hdr = pair_hdr(A, blockIdx.x);
+__global__ __launch_bounds__(64) void infomat_finalize_kernel(PairArgs A) {
+    const double *part = pair_partial(A, blockIdx.x);
+    const int nblk = (A.N1 + 255) / 256, lane = threadIdx.x;
+    __shared__ double s[10];
+    for (int k = 0; k < 10; ++k) {
+        double v = 0.0;
+        for (int b = lane; b < nblk; b += 64) v += part[(size_t)b * 10 + k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) s[k] = v;
+    }
+    __syncthreads();
+    if (lane != 0) return;
     float *out = A.out + (size_t)blockIdx.x * A.out_stride;
-    const double *s = hdr->sums;
     const double n = s[0], x = s[1], y = s[2], z = s[3], xx = s[4], yy = s[5], zz = s[6], xy = s[7], xz = s[8],
                  yz = s[9];
     const double G[36] = {zz + yy, -xy,     -xz,     0,  -z, y,   //
@@ -224,21 +348,19 @@ __global__ void infomat_finalize_kernel(PairArgs A) {
 
 }  // namespace
 
-static size_t ws_slice_bytes(int N2) {
-    size_t b = 256 + 2 * sizeof(int) * (size_t)(GMAX * GMAX + 1) + 8 + sizeof(float4) * (size_t)N2;
+static size_t ws_slice_bytes(int N1, int N2) {
+    size_t b = 256 + sizeof(int) * (size_t)(GMAX * GMAX + 1) + 12 + sizeof(float4) * (size_t)N2 +
+               10 * sizeof(double) * (size_t)dpm_cdiv(N1, 256);
     return (b + 255) & ~(size_t)255;
 }
 
 extern "C" size_t dpm_infomat_workspace_bytes(int n_pairs, int N1, int N2) {
-    (void)N1;
-    return 256 + (size_t)n_pairs * ws_slice_bytes(N2);
+    return 256 + (size_t)n_pairs * ws_slice_bytes(N1, N2);
 }
 
 static int launch_infomat(PairArgs A, int n_pairs, double radius, hipStream_t st) {
     hipLaunchKernelGGL(grid_setup_kernel, dim3(n_pairs), dim3(1024), 0, st, A, (float)radius);
-    hipLaunchKernelGGL(grid_count_kernel, dim3(dpm_cdiv(A.N2, 256), n_pairs), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(n_pairs), dim3(1024), 0, st, A);
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3(dpm_cdiv(A.N2, 256), n_pairs), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(grid_build_kernel, dim3(SLABS, n_pairs), dim3(1024), 0, st, A);
     hipLaunchKernelGGL(nn1_moments_kernel, dim3(dpm_cdiv(A.N1, 256), n_pairs), dim3(256), 0, st, A,
                        (float)(radius * radius));
     hipLaunchKernelGGL(infomat_finalize_kernel, dim3(n_pairs), dim3(64), 0, st, A);
@@ -251,7 +373,7 @@ extern "C" int dpm_information_matrix(const float *pcd1, int N1, const float *pc
     PairArgs A{};
     A.pcd1 = pcd1, A.pcd2 = pcd2, A.f1 = nullptr, A.f2 = nullptr, A.stride1 = 0, A.stride2 = 0;
     A.Rt = Rt, A.rt_stride = 0, A.out = out6x6, A.out_stride = 0;
-    A.ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), A.ws_stride = ws_slice_bytes(N2);
+    A.ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), A.ws_stride = ws_slice_bytes(N1, N2);
     A.N1 = N1, A.N2 = N2;
     return launch_infomat(A, 1, radius, (hipStream_t)stream);
 }
@@ -265,7 +387,7 @@ extern "C" int dpm_information_matrix_batched(const float *pcd, int N, const int
     PairArgs A{};
     A.pcd1 = pcd, A.pcd2 = pcd, A.f1 = src_frame, A.f2 = dst_frame, A.stride1 = 3LL * N, A.stride2 = 3LL * N;
     A.Rt = Rt, A.rt_stride = rt_stride, A.out = out, A.out_stride = out_stride;
-    A.ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), A.ws_stride = ws_slice_bytes(N);
+    A.ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), A.ws_stride = ws_slice_bytes(N, N);
     A.N1 = N, A.N2 = N;
     return launch_infomat(A, n_pairs, radius, (hipStream_t)stream);
 }

@@ -151,6 +151,7 @@ def test_information_matrix_vs_oracle():
         got = calculate_information_matrix_from_pcd(a, b, SE3, device=DEV)
         assert got.device.type == "cpu" and got.dtype == torch.float32 and tuple(got.shape) == (6, 6)
         assert float(want[3, 3]) > 0.3 * n  # most points do find a neighbour within 1 m
+        assert float(got[3, 3]) == float(want[3, 3])  # the matched set has exactly the oracle's size
         np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * float(want.abs().max()))
     # hand case: nothing within the radius -> zero matrix; identity on a shifted copy -> counts
     a = torch.tensor([[0.0, 10, 20], [0, 0, 0], [1, 2, 3]])
@@ -178,21 +179,32 @@ def test_batched_registration_equals_per_pair_calls(dec):
 
 
 def test_batched_information_matrix_equals_single(ops):
+    """3 pairs (plain block mapping) and 8 pairs (XCD-aware mapping, one of them with the source pushed half
+    out of the target's bounding box) against the single-pair entry point."""
     from deeppointmap_amd.registration import calculate_information_matrix_from_pcd
-    pts = torch.stack([synthetic.frame(f, 8192) * 60 for f in range(3)]).to(DEV)
-    table = torch.zeros(3, 56, device=DEV)
-    poses = []
-    for p in range(3):
-        SE3 = synthetic.relative_pose(p, (p + 1) % 3).float()
-        table[p, :9] = SE3[:3, :3].reshape(9)
-        table[p, 9:12] = SE3[:3, 3]
-        poses.append(SE3)
-    src = torch.tensor([0, 1, 2], dtype=torch.int32, device=DEV)
-    dst = torch.tensor([1, 2, 0], dtype=torch.int32, device=DEV)
-    ops.information_matrix_batched(pts, src, dst, table[:, :12], table[:, 20:])
-    for p in range(3):
-        want = calculate_information_matrix_from_pcd(pts[p], pts[(p + 1) % 3], poses[p], device=DEV)
-        np.testing.assert_allclose(table[p, 20:].view(6, 6).cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-3)
+    pts = torch.stack([synthetic.frame(f, 8192) * 60 for f in range(4)]).to(DEV)
+    for pairs in ([(0, 1), (1, 2), (2, 0)], [(0, 1), (1, 2), (2, 3), (3, 0), (0, 2), (1, 3), (2, 2), (3, 1)]):
+        E = len(pairs)
+        table = torch.zeros(E, 56, device=DEV)
+        poses = []
+        for p, (a, b) in enumerate(pairs):
+            SE3 = synthetic.relative_pose(a, b).float()
+            if p == 5:
+                SE3[:3, 3] += torch.tensor([40.0, -25.0, 0.5])
+            table[p, :9] = SE3[:3, :3].reshape(9)
+            table[p, 9:12] = SE3[:3, 3]
+            poses.append(SE3)
+        src = torch.tensor([a for a, _ in pairs], dtype=torch.int32, device=DEV)
+        dst = torch.tensor([b for _, b in pairs], dtype=torch.int32, device=DEV)
+        ops.information_matrix_batched(pts, src, dst, table[:, :12], table[:, 20:])
+        for p, (a, b) in enumerate(pairs):
+            want = calculate_information_matrix_from_pcd(pts[a], pts[b], poses[p], device=DEV)
+            got = table[p, 20:].view(6, 6).cpu()
+            assert float(got[3, 3]) == float(want[3, 3]) and (p == 5 or float(got[3, 3]) > 1000)
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=1e-3)
+            ref = O.information_matrix(pts[a].cpu(), pts[b].cpu(), poses[p])
+            assert float(got[3, 3]) == float(ref[3, 3])
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()) + 1e-3)
 
 
 def test_map_vs_map_registration_vs_oracle(dec, cfg_full, sd_dec):
