@@ -24,25 +24,25 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-// 4 consecutive k of one row; zeros outside [0,rows) x [0,K)
-__device__ __forceinline__ float4 load4(const float *__restrict__ base, int ld, int row, int rows, int k, int K,
-                                        bool vec_ok) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < rows) {
-        const float *p = base + (size_t)row * ld + k;
-        if (vec_ok && k + 3 < K) {
-            v = *reinterpret_cast<const float4 *>(p);
-        } else {
-            if (k < K) v.x = p[0];
-            if (k + 1 < K) v.y = p[1];
-            if (k + 2 < K) v.z = p[2];
-            if (k + 3 < K) v.w = p[3];
-        }
+// 4 consecutive k of one row, zeros for k >= K.  Branch-free on purpose: rows beyond `rows` read the last valid
+// row (their products land in output rows / columns the epilogue never stores) and the k tail is a clamped load
+// plus a select, so the compiler issues the whole prefetch group back to back and waits for it only where the
+// values are written to LDS one K-tile later.  (With guarded loads it serialised the group behind s_waitcnt
+// vmcnt(0) and the HBM latency was exposed twice per K-tile.)
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float *__restrict__ base, int ld, int row, int rows, int k, int K) {
+    const float *p = base + (size_t)min(row, rows - 1) * ld;
+    if (VEC) {  // ld % 4 == 0, base 16-byte aligned, K % 4 == 0
+        const float4 v = *reinterpret_cast<const float4 *>(p + min(k, K - 4));
+        return k < K ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float4 v;
+    v.x = p[min(k, K - 1)], v.y = p[min(k + 1, K - 1)], v.z = p[min(k + 2, K - 1)], v.w = p[min(k + 3, K - 1)];
+    v.x = k < K ? v.x : 0.f, v.y = k + 1 < K ? v.y : 0.f, v.z = k + 2 < K ? v.z : 0.f, v.w = k + 3 < K ? v.w : 0.f;
     return v;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restrict__ X, int ldx, long long sx,
                                                            const float *__restrict__ W, int ldw, long long sw,
                                                            const float *__restrict__ bias,
@@ -56,9 +56,12 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
     const int bz = blockIdx.z;
     X += (size_t)bz * sx, W += (size_t)bz * sw, out += (size_t)bz * so;
     if (res) res += (size_t)bz * sr;
-    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
-    const bool xvec = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    const bool wvec = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+    int by = blockIdx.y, bx = blockIdx.x;
+    if ((gridDim.y & 7) == 0 && gridDim.y >= 64) {  // all column blocks of one row block on ONE XCD: its L2 serves X
+        const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, slot = L >> 3;
+        by = (int)((slot / gridDim.x) * 8 + xcd), bx = (int)(slot % gridDim.x);
+    }
+    const int row0 = by * BM, col0 = bx * BN;
     const int sr_ = t >> 3, sk = (t & 7) * 4;  // staging: row within a 32-row pass, k offset
 
     f32x4 acc[MB][NB];
@@ -69,9 +72,9 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
 
     float4 xr[PX], wr[PW];
 #pragma unroll
-    for (int p = 0; p < PX; ++p) xr[p] = load4(X, ldx, row0 + p * 32 + sr_, R, sk, Cin, xvec);
+    for (int p = 0; p < PX; ++p) xr[p] = load4<VEC>(X, ldx, row0 + p * 32 + sr_, R, sk, Cin);
 #pragma unroll
-    for (int p = 0; p < PW; ++p) wr[p] = load4(W, ldw, col0 + p * 32 + sr_, Cout, sk, Cin, wvec);
+    for (int p = 0; p < PW; ++p) wr[p] = load4<VEC>(W, ldw, col0 + p * 32 + sr_, Cout, sk, Cin);
 
     for (int k0 = 0; k0 < Cin; k0 += KT) {
         // registers -> LDS (row stride 136 B: 8-byte aligned, so two 8-byte stores per float4)
@@ -88,22 +91,29 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
         __syncthreads();
         if (k0 + KT < Cin) {  // prefetch the next K-tile while this one is consumed
 #pragma unroll
-            for (int p = 0; p < PX; ++p) xr[p] = load4(X, ldx, row0 + p * 32 + sr_, R, k0 + KT + sk, Cin, xvec);
+            for (int p = 0; p < PX; ++p) xr[p] = load4<VEC>(X, ldx, row0 + p * 32 + sr_, R, k0 + KT + sk, Cin);
 #pragma unroll
-            for (int p = 0; p < PW; ++p) wr[p] = load4(W, ldw, col0 + p * 32 + sr_, Cout, k0 + KT + sk, Cin, wvec);
+            for (int p = 0; p < PW; ++p) wr[p] = load4<VEC>(W, ldw, col0 + p * 32 + sr_, Cout, k0 + KT + sk, Cin);
         }
+        float a[2][MB], b[2][NB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) a[0][i] = Xs[wm * WM + i * 16 + (lane & 15)][lane >> 4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b[0][j] = Ws[wn * WN + j * 16 + (lane & 15)][lane >> 4];
 #pragma unroll
         for (int kk = 0; kk < KT; kk += 4) {
-            float a[MB], b[NB];
+            const int cur = (kk >> 2) & 1, nxt = cur ^ 1;
+            if (kk + 4 < KT) {  // fragments of the next k-step are in flight while this one's MFMAs issue
 #pragma unroll
-            for (int i = 0; i < MB; ++i) a[i] = Xs[wm * WM + i * 16 + (lane & 15)][kk + (lane >> 4)];
+                for (int i = 0; i < MB; ++i) a[nxt][i] = Xs[wm * WM + i * 16 + (lane & 15)][kk + 4 + (lane >> 4)];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) b[j] = Ws[wn * WN + j * 16 + (lane & 15)][kk + (lane >> 4)];
+                for (int j = 0; j < NB; ++j) b[nxt][j] = Ws[wn * WN + j * 16 + (lane & 15)][kk + 4 + (lane >> 4)];
+            }
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -135,15 +145,23 @@ extern "C" int dpm_linear_batched(const float *x, int ldx, long long sx, const f
     DPM_CHECK_ARG(ldx >= Cin && ldw >= Cin && ldo >= Cout && (!residual || ldr >= Cout));
     DPM_CHECK_ARG(act >= DPM_ACT_NONE && act <= DPM_ACT_SIGMOID);
     hipStream_t st = (hipStream_t)stream;
+    const bool vec = ldx % 4 == 0 && ldw % 4 == 0 && Cin % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 &&
+                     sx % 4 == 0 && sw % 4 == 0;
     const long long big = (long long)batch * dpm_cdiv(R, 64) * dpm_cdiv(Cout, 64);
     // 64x64 tiles measured best or tied against 128x128 / 128x64 on every shape of the path (scripts/gemm_bench.py)
-    if (big >= 192 || (R > 1024 && Cout > 32)) {
-        hipLaunchKernelGGL((gemm_nt_mfma_kernel<64, 64>), dim3(dpm_cdiv(Cout, 64), dpm_cdiv(R, 64), batch), dim3(256), 0,
-                           st, x, ldx, sx, W, ldw, sw, bias, residual, ldr, sr, out, ldo, so, R, Cin, Cout, act);
+    const bool t64 = big >= 192 || (R > 1024 && Cout > 32);
+    const dim3 grid = t64 ? dim3(dpm_cdiv(Cout, 64), dpm_cdiv(R, 64), batch) : dim3(dpm_cdiv(Cout, 32), dpm_cdiv(R, 32), batch);
+#define DPM_GEMM_LAUNCH(BM, BN, V)                                                                                  \
+    hipLaunchKernelGGL((gemm_nt_mfma_kernel<BM, BN, V>), grid, dim3(256), 0, st, x, ldx, sx, W, ldw, sw, bias, residual, \
+                       ldr, sr, out, ldo, so, R, Cin, Cout, act)
+    if (t64) {
+        if (vec) DPM_GEMM_LAUNCH(64, 64, true);
+        else DPM_GEMM_LAUNCH(64, 64, false);
     } else {
-        hipLaunchKernelGGL((gemm_nt_mfma_kernel<32, 32>), dim3(dpm_cdiv(Cout, 32), dpm_cdiv(R, 32), batch), dim3(256), 0,
-                           st, x, ldx, sx, W, ldw, sw, bias, residual, ldr, sr, out, ldo, so, R, Cin, Cout, act);
+        if (vec) DPM_GEMM_LAUNCH(32, 32, true);
+        else DPM_GEMM_LAUNCH(32, 32, false);
     }
+#undef DPM_GEMM_LAUNCH
     return dpm_launch_status();
 }
 

@@ -55,35 +55,41 @@ __global__ __launch_bounds__(256) void group_mlp_mfma_kernel(
     __syncthreads();
 
     const int sr = t >> 3, sk = (t & 7) * 4;  // staging: row within a 32-row pass, k offset
-    const bool fvec = fea && (Cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(fea) & 15) == 0);
-    const bool wvec = (C3 % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
 
-    auto load_g = [&](int row, int k) -> float4 {  // 4 consecutive input channels of gathered row `row`
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
+    // Loads are branch-free (clamped address + select) except for conditions that are uniform over the workgroup,
+    // so a prefetch group is issued back to back and only waited for when it is written to LDS one K-tile later.
+    // Cin % 4 == 0 and 16-byte aligned features are guaranteed by the dispatcher, hence the three relative
+    // coordinates start exactly at k == Cin of one float4 slot.
+    auto load_g = [&](int row, int k0) -> float4 {  // 4 consecutive input channels of gathered row `row` in tile k0
+        const int k = k0 + sk;
+        const bool body_tile = k0 < Cin, tail_tile = Cin >= k0 && Cin < k0 + KT;  // uniform over the workgroup
         const int n = s_nidx[row];
-        if (fvec && k + 3 < Cin) {
-            const float4 q = *reinterpret_cast<const float4 *>(fea + (size_t)n * Cin + k);
-            return q;
-        }
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if (!fea) px = xyz[(size_t)n * 3], py = xyz[(size_t)n * 3 + 1], pz = xyz[(size_t)n * 3 + 2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = k + j;
-            if (c < Cin) v[j] = fea ? fea[(size_t)n * Cin + c]
-                                    : fmaf(W0[3 * c + 2], pz, fmaf(W0[3 * c + 1], py, fmaf(W0[3 * c], px, b0[c])));
-            else if (c < C3) v[j] = (xyz[(size_t)n * 3 + (c - Cin)] - s_ctr[row / K][c - Cin]) * inv_r;
-        }
-        return make_float4(v[0], v[1], v[2], v[3]);
-    };
-    auto load_w = [&](int row, int k) -> float4 {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float *p = W + (size_t)row * C3 + k;
-        if (wvec && k + 3 < C3) return *reinterpret_cast<const float4 *>(p);
-        if (k < C3) v.x = p[0];
-        if (k + 1 < C3) v.y = p[1];
-        if (k + 2 < C3) v.z = p[2];
-        if (k + 3 < C3) v.w = p[3];
+        if (fea && body_tile) {
+            const float4 q = *reinterpret_cast<const float4 *>(fea + (size_t)n * Cin + min(k, Cin - 4));
+            v = k < Cin ? q : v;
+        }
+        if ((!fea && body_tile) || tail_tile) {
+            const float px = xyz[(size_t)n * 3], py = xyz[(size_t)n * 3 + 1], pz = xyz[(size_t)n * 3 + 2];
+            if (!fea && body_tile) {
+                const int c = min(k, Cin - 4);
+                float f[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    f[j] = fmaf(W0[3 * (c + j) + 2], pz, fmaf(W0[3 * (c + j) + 1], py, fmaf(W0[3 * (c + j)], px, b0[c + j])));
+                v = k < Cin ? make_float4(f[0], f[1], f[2], f[3]) : v;
+            }
+            const float *cc = s_ctr[row / K];
+            const float4 rel = make_float4((px - cc[0]) * inv_r, (py - cc[1]) * inv_r, (pz - cc[2]) * inv_r, 0.f);
+            v = k == Cin ? rel : v;
+        }
+        return v;
+    };
+    auto load_w = [&](int row, int k) -> float4 {  // rows of (Cout, Cin+3) are not 16-byte aligned: four dwords
+        const float *p = W + (size_t)row * C3;
+        float4 v;
+        v.x = p[min(k, C3 - 1)], v.y = p[min(k + 1, C3 - 1)], v.z = p[min(k + 2, C3 - 1)], v.w = p[min(k + 3, C3 - 1)];
+        v.x = k < C3 ? v.x : 0.f, v.y = k + 1 < C3 ? v.y : 0.f, v.z = k + 2 < C3 ? v.z : 0.f, v.w = k + 3 < C3 ? v.w : 0.f;
         return v;
     };
 
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256) void group_mlp_mfma_kernel(
 
     float4 gr[2], wr[PW];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) gr[p] = load_g(p * 32 + sr, sk);
+    for (int p = 0; p < 2; ++p) gr[p] = load_g(p * 32 + sr, 0);
 #pragma unroll
     for (int p = 0; p < PW; ++p) wr[p] = load_w(p * 32 + sr, sk);
 
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void group_mlp_mfma_kernel(
         __syncthreads();
         if (k0 + KT < C3) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) gr[p] = load_g(p * 32 + sr, k0 + KT + sk);
+            for (int p = 0; p < 2; ++p) gr[p] = load_g(p * 32 + sr, k0 + KT);
 #pragma unroll
             for (int p = 0; p < PW; ++p) wr[p] = load_w(p * 32 + sr, k0 + KT + sk);
         }
@@ -237,6 +243,140 @@ int launch(const float *xyz, const float *fea, const float *centers, const int32
     return dpm_launch_status();
 }
 
+// ---- wave-autonomous variant for narrow layers (Cout <= 64) ------------------------------------------------
+// One WAVE owns one centre at a time: no LDS, no barrier, no atomics.
+//   * B (the weights) lives in registers for the whole kernel: a wave walks over `cpw` consecutive centres.
+//   * A is read straight from the gathered rows.  Inside each 16-channel chunk the K index is remapped so that lane
+//     group g = lane>>4 owns channels 16c+4g .. +3: one global_load_dwordx4 per lane feeds FOUR MFMAs (an MFMA only
+//     needs A and B to agree on which k sits in which lane group).  The three relative coordinates are one more
+//     MFMA with (dx, dy, dz, 0) spread over the four lane groups.
+//   * The epilogue stays in registers: C/D rows (lane>>4)*4+q, columns lane&15, so LayerNorm's row sums are DPP
+//     reductions over the 16 lanes of a DPP row, and the max over the K rows is max over q, the row blocks and
+//     the four lane groups.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v)));   // quad_perm [1,0,3,2]
+    v += __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v)));   // quad_perm [2,3,0,1]
+    v += __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v)));  // row_half_mirror
+    v += __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v)));  // row_mirror
+    return v;
+}
+
+template <int COUT, int CIN, int KN, bool FUSED>
+__global__ __launch_bounds__(256) void group_mlp_wave_kernel(
+    const float *__restrict__ xyz_all, const float *__restrict__ fea_all, const float *__restrict__ ctr_all,
+    const int32_t *__restrict__ idx_all, const float *__restrict__ W, const float *__restrict__ bias,
+    const float *__restrict__ gamma, const float *__restrict__ beta, int N, int S, long long total, int cpw,
+    float inv_r, float *__restrict__ out_all, const float *__restrict__ W0, const float *__restrict__ b0) {
+    constexpr int MB = KN / 16, NB = COUT / 16, NC = CIN / 16, C3 = CIN + 3;
+    static_assert(!FUSED || NC == 1, "the fused point_mlp0 path has 16 input channels");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+
+    float Bf[NB][NC * 4], Bt[NB], bv[NB], gm[NB], bt[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const float *wr = W + (size_t)(j * 16 + i) * C3;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) Bf[j][c * 4 + jj] = wr[16 * c + 4 * g + jj];
+        Bt[j] = g < 3 ? wr[CIN + min(g, 2)] : 0.f;
+        bv[j] = bias[j * 16 + i], gm[j] = gamma[j * 16 + i], bt[j] = beta[j * 16 + i];
+    }
+    float w0[4][3], bb0[4];
+    if (FUSED) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            bb0[jj] = b0[4 * g + jj];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) w0[jj][d] = W0[3 * (4 * g + jj) + d];
+        }
+    }
+
+    const long long first = ((long long)blockIdx.x * 4 + w) * cpw;
+    const long long last = min(first + cpw, total);
+    for (long long cc = first; cc < last; ++cc) {
+        const int b = (int)(cc / S);
+        const float *xyz = xyz_all + (size_t)b * N * 3;
+        const float *fea = FUSED ? nullptr : fea_all + (size_t)b * N * CIN;
+        const float cx = ctr_all[cc * 3], cy = ctr_all[cc * 3 + 1], cz = ctr_all[cc * 3 + 2];
+        float mx[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) mx[j] = 0.f;  // ReLU floor
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int n = min(max(idx_all[cc * KN + m * 16 + i], 0), N - 1);
+            const float px = xyz[(size_t)n * 3], py = xyz[(size_t)n * 3 + 1], pz = xyz[(size_t)n * 3 + 2];
+            const float rel = (g == 0 ? px - cx : g == 1 ? py - cy : g == 2 ? pz - cz : 0.f) * inv_r;
+            float4 a[NC];
+            if (FUSED) {
+                float f[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    f[jj] = fmaf(w0[jj][2], pz, fmaf(w0[jj][1], py, fmaf(w0[jj][0], px, bb0[jj])));
+                a[0] = make_float4(f[0], f[1], f[2], f[3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    a[c] = *reinterpret_cast<const float4 *>(fea + (size_t)n * CIN + 16 * c + 4 * g);
+            }
+            f32x4 acc[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].x, Bf[j][c * 4 + 0], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].y, Bf[j][c * 4 + 1], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].z, Bf[j][c * 4 + 2], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].w, Bf[j][c * 4 + 3], acc[j], 0, 0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(rel, Bt[j], acc[j], 0, 0, 0);
+            // bias, two-pass LayerNorm over the COUT columns of each of this lane group's 4 rows, ReLU, max over rows
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[j][q] += bv[j], sum += acc[j][q];
+                const float mean = row16_sum(sum) * (1.0f / (float)COUT);
+                float sq = 0.f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float d = acc[j][q] - mean;
+                    sq = fmaf(d, d, sq);
+                }
+                const float rs = rsqrtf(row16_sum(sq) * (1.0f / (float)COUT) + 1e-5f);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) mx[j] = fmaxf(mx[j], fmaf((acc[j][q] - mean) * rs, gm[j], bt[j]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            float v = mx[j];
+            v = fmaxf(v, __shfl_xor(v, 16, 64));
+            v = fmaxf(v, __shfl_xor(v, 32, 64));
+            if (g == 0) out_all[cc * COUT + j * 16 + i] = v;
+        }
+    }
+}
+
+template <int COUT, int CIN, bool FUSED>
+int launch_wave(const float *xyz, const float *fea, const float *centers, const int32_t *idx, const float *W,
+                const float *bias, const float *gamma, const float *beta, int B, int N, int S, int K, float inv_r,
+                float *out, hipStream_t st, const float *W0, const float *b0) {
+    const long long total = (long long)B * S;
+    const int cpw = total >= (1 << 16) ? 8 : (total >= (1 << 13) ? 2 : 1);  // centres per wave
+    const unsigned grid = dpm_cdiv(total, 4LL * cpw);
+    if (K == 32)
+        hipLaunchKernelGGL((group_mlp_wave_kernel<COUT, CIN, 32, FUSED>), dim3(grid), dim3(256), 0, st, xyz, fea, centers,
+                           idx, W, bias, gamma, beta, N, S, total, cpw, inv_r, out, W0, b0);
+    else
+        hipLaunchKernelGGL((group_mlp_wave_kernel<COUT, CIN, 16, FUSED>), dim3(grid), dim3(256), 0, st, xyz, fea, centers,
+                           idx, W, bias, gamma, beta, N, S, total, cpw, inv_r, out, W0, b0);
+    return dpm_launch_status();
+}
+
 }  // namespace
 
 // defined in encoder_ops.hip: generic VALU kernel for shapes the MFMA kernel does not cover
@@ -253,7 +393,10 @@ extern "C" int dpm_group_mlp_max(const float *xyz, const float *fea, const float
     DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && K <= 64 && Cin >= 1 && Cout >= 1 && radius > 0.0);
     hipStream_t st = (hipStream_t)stream;
     const float inv_r = 1.0f / (float)radius;
-    if (K == 16 || K == 32) {
+    if ((K == 16 || K == 32) && Cin % 4 == 0 && ((uintptr_t)fea & 15) == 0) {
+        if (Cout == 32 && Cin == 32) return launch_wave<32, 32, false>(xyz, fea, centers, idx, W, bias, gamma, beta, B, N, S, K, inv_r, out, st, nullptr, nullptr);
+        if (Cout == 64 && Cin == 32) return launch_wave<64, 32, false>(xyz, fea, centers, idx, W, bias, gamma, beta, B, N, S, K, inv_r, out, st, nullptr, nullptr);
+        if (Cout == 64 && Cin == 64) return launch_wave<64, 64, false>(xyz, fea, centers, idx, W, bias, gamma, beta, B, N, S, K, inv_r, out, st, nullptr, nullptr);
         switch (Cout) {
             case 32: return launch<32, 4, 1>(xyz, fea, centers, idx, W, bias, gamma, beta, B, N, S, K, Cin, inv_r, out, st);
             case 64: return launch<64, 2, 2>(xyz, fea, centers, idx, W, bias, gamma, beta, B, N, S, K, Cin, inv_r, out, st);
@@ -275,9 +418,10 @@ extern "C" int dpm_group_mlp_max_from_xyz(const float *xyz, const float *W0, con
                                           double radius, float *out, dpm_stream_t stream) {
     DPM_CHECK_ARG(xyz && W0 && b0 && centers && idx && W && bias && gamma && beta && out);
     DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && Cin >= 1 && radius > 0.0);
-    if (!(K == 16 || K == 32)) return DPM_EUNSUPPORTED;
+    if (!(K == 16 || K == 32) || Cin % 4 != 0) return DPM_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const float inv_r = 1.0f / (float)radius;
+    if (Cout == 32 && Cin == 16) return launch_wave<32, 16, true>(xyz, nullptr, centers, idx, W, bias, gamma, beta, B, N, S, K, inv_r, out, st, W0, b0);
     switch (Cout) {
         case 32: return launch<32, 4, 1>(xyz, nullptr, centers, idx, W, bias, gamma, beta, B, N, S, K, Cin, inv_r, out, st, W0, b0);
         case 64: return launch<64, 2, 2>(xyz, nullptr, centers, idx, W, bias, gamma, beta, B, N, S, K, Cin, inv_r, out, st, W0, b0);
