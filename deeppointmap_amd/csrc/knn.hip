@@ -44,6 +44,11 @@ constexpr int TMPN = 128;  // scratch entries per wave (>= KMAX + 1 and >= 64)
 constexpr int GDIM = 128;  // grid cells per axis (upper bound)
 constexpr int GRID_MIN_N = 2048;
 
+// LDS scratch is handed to the helpers below as address-space-3 pointers: through generic pointers every access
+// would compile to a FLAT instruction (the address-space check plus both wait counters) instead of ds_read/ds_write.
+using LdsF = __attribute__((address_space(3))) volatile float *;
+using LdsI = __attribute__((address_space(3))) volatile int *;
+
 __device__ __forceinline__ void wave_mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -66,45 +71,79 @@ __device__ __forceinline__ int fkey(float d) {
 // Select the K smallest of the C > K candidates cd/ci[0..C) (distance, then index).  The result is written
 // UNSORTED to od/oi[0..K) (downstream is a max-pool; only slot 0 matters and is fixed up by the caller).
 // Returns the K-th smallest distance; *tie is set when the K-th and (K+1)-th distances are bit-equal.
-// Bitwise search for the K-th smallest key with ballots: 32 steps x ceil(C/64) compares per lane, instead of
-// K rounds of arg-min extraction.
-__device__ __forceinline__ float select_k(volatile float *cd, volatile int *ci, int C, int K, volatile float *od,
-                                          volatile int *oi, bool *tie) {
+// Bitwise search for the K-th smallest key with ballots instead of K rounds of arg-min extraction.  A wave64
+// VALU instruction occupies its SIMD for four cycles, so the search is trimmed to what the data needs:
+//   * it starts below the bits all keys share (distances inside one radius share sign and most of the exponent),
+//   * it only looks at the 64-candidate chunks that exist,
+//   * it stops at the first probe that has exactly K keys below it -- that probe already separates the answer
+//     (and proves there is no tie at the boundary).  Typically ~10 probes instead of 32.
+__device__ __forceinline__ float select_k(LdsF cd, LdsI ci, int C, int K, LdsF od, LdsI oi, bool *tie) {
     const int lane = lane_id();
     constexpr int R = 4;  // keys cached in registers per lane (C <= 256); the rest is re-read from LDS
+    const int nch = min((C + 63) >> 6, R);
     int kr[R];
+    int kmin = 0x7fffffff, kmax = -0x7fffffff;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int p = lane + 64 * j;
-        kr[j] = p < C ? fkey(cd[p]) : 0x7fffffff;
+        kr[j] = 0x7fffffff;
+        if (j < nch && p < C) {
+            kr[j] = fkey(cd[p]);
+            kmin = min(kmin, kr[j]), kmax = max(kmax, kr[j]);
+        }
     }
+    for (int p = lane + 64 * R; p < C; p += 64) {
+        const int k = fkey(cd[p]);
+        kmin = min(kmin, k), kmax = max(kmax, k);
+    }
+    kmin = wave_min_dpp(kmin), kmax = -wave_min_dpp(-kmax);
     auto count_lt = [&](int probe) -> int {  // wave-uniform number of candidates with key < probe
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < R; ++j) c += __popcll(__ballot(kr[j] < probe && lane + 64 * j < C));
+        int c = __popcll(__ballot(kr[0] < probe));  // padding keys are INT_MAX: never below a probe
+        if (nch > 1) c += __popcll(__ballot(kr[1] < probe));
+        if (nch > 2) c += __popcll(__ballot(kr[2] < probe));
+        if (nch > 3) c += __popcll(__ballot(kr[3] < probe));
         for (int p = lane + 64 * R; p < ((C + 63) & ~63); p += 64)
             c += __popcll(__ballot(p < C && fkey(cd[p]) < probe));
         return c;
     };
     // t = largest value with count(key < t) < K  ==  the K-th smallest key.  Keys are compared as signed ints,
-    // so search in the biased domain (key ^ 0x80000000 is unsigned-monotone).
-    unsigned tb = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const unsigned cand = tb | (1u << bit);
-        if (count_lt((int)(cand ^ 0x80000000u)) < K) tb = cand;
+    // so search in the biased domain (key ^ 0x80000000 is unsigned-monotone), below the common prefix.
+    const unsigned umin = (unsigned)kmin ^ 0x80000000u, umax = (unsigned)kmax ^ 0x80000000u;
+    const unsigned diff = umin ^ umax;
+    int t = kmin, c_lt = 0;
+    bool exact = false;  // t has exactly K keys below it (then it is a separator, not a key)
+    if (diff != 0) {
+        const int top = 31 - __clz(diff);
+        unsigned tb = top == 31 ? 0u : (umax >> (top + 1)) << (top + 1);
+        for (int bit = top; bit >= 0; --bit) {
+            const unsigned cand = tb | (1u << bit);
+            const int c = count_lt((int)(cand ^ 0x80000000u));
+            if (c == K) {
+                exact = true, tb = cand;
+                break;
+            }
+            if (c < K) tb = cand;
+        }
+        t = (int)(tb ^ 0x80000000u);
+        c_lt = exact ? K : count_lt(t);
     }
-    const int t = (int)(tb ^ 0x80000000u);
-    const int c_lt = count_lt(t);
-    const int need = K - c_lt;  // >= 1 entries equal to t are taken
+    const int need = K - c_lt;  // entries equal to t that are taken (none when t is a separator)
     int c_eq = 0;
+    if (!exact) {
+        if (diff == 0) {
+            c_eq = C;
+        } else {
 #pragma unroll
-    for (int j = 0; j < R; ++j) c_eq += __popcll(__ballot(kr[j] == t && lane + 64 * j < C));
-    for (int p = lane + 64 * R; p < ((C + 63) & ~63); p += 64) c_eq += __popcll(__ballot(p < C && fkey(cd[p]) == t));
+            for (int j = 0; j < R; ++j) c_eq += __popcll(__ballot(kr[j] == t));
+            for (int p = lane + 64 * R; p < ((C + 63) & ~63); p += 64) c_eq += __popcll(__ballot(p < C && fkey(cd[p]) == t));
+        }
+    }
     *tie = c_eq > need;
     // emit: everything below t, then `need` of the entries equal to t (smallest indices first when tied)
     const unsigned long long ltm = (1ull << lane) - 1ull;
     int base = 0, eq_taken = 0;
     int last_idx = -1;
+    float below = -__builtin_inff();  // largest emitted distance below t
     for (int p0 = 0; p0 < C; p0 += 64) {
         const int p = p0 + lane;
         const bool ok = p < C;
@@ -112,9 +151,9 @@ __device__ __forceinline__ float select_k(volatile float *cd, volatile int *ci, 
         const int k = ok ? fkey(d) : 0x7fffffff;
         const bool lt = ok && k < t;
         const unsigned long long m = __ballot(lt);
-        if (lt) od[base + __popcll(m & ltm)] = d, oi[base + __popcll(m & ltm)] = ci[p];
+        if (lt) od[base + __popcll(m & ltm)] = d, oi[base + __popcll(m & ltm)] = ci[p], below = fmaxf(below, d);
         base += __popcll(m);
-        if (!*tie) {
+        if (!exact && !*tie) {
             const bool eq = ok && k == t;
             const unsigned long long me = __ballot(eq);
             if (eq) od[c_lt + eq_taken + __popcll(me & ltm)] = d, oi[c_lt + eq_taken + __popcll(me & ltm)] = ci[p];
@@ -134,9 +173,11 @@ __device__ __forceinline__ float select_k(volatile float *cd, volatile int *ci, 
         }
     }
     wave_mem_sync();
-    // the K-th smallest distance itself (value of key t): read it back from any entry equal to t
-    float kth = 0.f;
-    {
+    // the K-th smallest distance itself: the largest one below a separator, else the value of key t
+    float kth;
+    if (exact) {
+        kth = wave_max_dpp(below);
+    } else {
         float v = -__builtin_inff();
         for (int p = lane; p < C; p += 64)
             if (fkey(cd[p]) == t) v = cd[p];
@@ -148,7 +189,7 @@ __device__ __forceinline__ float select_k(volatile float *cd, volatile int *ci, 
 }
 
 // libstdc++ __adjust_heap + __push_heap on (value, index) pairs ordered by value only
-__device__ void heap_adjust(volatile float *hv, volatile int *hi, int hole, int len, float val, int vi) {
+__device__ void heap_adjust(LdsF hv, LdsI hi, int hole, int len, float val, int vi) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
@@ -173,7 +214,7 @@ __device__ void heap_adjust(volatile float *hv, volatile int *hi, int hole, int 
 // Sequential emulation of std::partial_sort's heap-select over the whole row in ORIGINAL index order.
 // hv/hi: K-entry heap in LDS; tv: 64-entry staging.  On return hv/hi hold the K survivors.
 __device__ void heap_select_exact(const float *__restrict__ pts, int len, int K, float cx, float cy, float cz,
-                                  float caa, volatile float *hv, volatile int *hi, volatile float *tv) {
+                                  float caa, LdsF hv, LdsI hi, LdsF tv) {
     const int lane = lane_id();
     auto dist = [&](int i) -> float {
         if (i >= len) return __builtin_inff();
@@ -211,6 +252,32 @@ __device__ void heap_select_exact(const float *__restrict__ pts, int len, int K,
     }
 }
 
+// K survivors of the heap-select in hv/hi -> the K output slots (executed by one full wave): slots beyond the
+// radius are replaced by the nearest point (utils.py:85-87) and the nearest point itself goes to slot 0.
+__device__ __forceinline__ void emit_heap_result(LdsF hv, LdsI hi, int K, float r2, int32_t *__restrict__ out) {
+    const int lane = lane_id();
+    float mv = (lane < K) ? hv[lane] : __builtin_inff();
+    int mi = (lane < K) ? hi[lane] : 0x7fffffff;
+    const float myv = mv;
+    const int myi = mi;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(mv, off, 64);
+        const int oi = __shfl_xor(mi, off, 64);
+        if (ov < mv || (ov == mv && oi < mi)) mv = ov, mi = oi;
+    }
+    int outv = (myv > r2) ? mi : myi;
+    // slot 0 must be the nearest point: swap it (in registers) with whoever holds it
+    const unsigned long long hm = __ballot(lane < K && myi == mi);
+    const int L = hm ? __builtin_ctzll(hm) : 0;
+    const int v0 = __shfl(outv, 0, 64);
+    if (lane == L) outv = v0;
+    if (lane == 0) outv = mi;
+    if (lane < K) out[lane] = outv;
+}
+
+constexpr int TIE_CAP = 4096;  // queued boundary-tie rows per call (beyond that they are resolved in place)
+
 // Per-centre running state (all fields wave-uniform except gd/gi which are per lane).
 struct Ctr {
     float x, y, z, aa, thr, gd;
@@ -226,7 +293,7 @@ __device__ __forceinline__ void ctr_init(Ctr &c, const float *p, float r2) {
 
 // Offer one point per lane (ok = lane holds a valid point with original index i) to centre c.
 __device__ __forceinline__ void offer(Ctr &c, bool ok, float x, float y, float z, float bb, int i, int K,
-                                      volatile float *cd, volatile int *ci, volatile float *td, volatile int *ti) {
+                                      LdsF cd, LdsI ci, LdsF td, LdsI ti) {
     const int lane = lane_id();
     const float d = ok ? exp_dist(c.x, c.y, c.z, c.aa, x, y, z, bb) : __builtin_inff();
     if (d < c.gd || (d == c.gd && i < c.gi)) c.gd = d, c.gi = i;
@@ -254,8 +321,9 @@ __device__ __forceinline__ void offer(Ctr &c, bool ok, float x, float y, float z
 
 // Turn the candidate list of centre c into the K output slots.
 __device__ __forceinline__ void finish(Ctr &c, const float *__restrict__ pts, int len, int N, int K, float r2,
-                                       volatile float *cd, volatile int *ci, volatile float *td, volatile int *ti,
-                                       int32_t *__restrict__ out) {
+                                       LdsF cd, LdsI ci, LdsF td, LdsI ti,
+                                       int32_t *__restrict__ out, int *tie_count = nullptr,
+                                       int32_t *tie_rows = nullptr, int row = 0) {
     const int lane = lane_id();
     wave_mem_sync();
     // global nearest among the points examined (slot 0 when nothing lies within the radius)
@@ -289,28 +357,24 @@ __device__ __forceinline__ void finish(Ctr &c, const float *__restrict__ pts, in
         wave_mem_sync();
     }
     const bool heap_regime = (long long)K * 64 <= (long long)N;  // torch.topk: partial_sort vs nth_element
-    if (c.tie && heap_regime && len >= K) {
+    bool exact_here = c.tie && heap_regime && len >= K;
+    if (exact_here && tie_count) {
+        // Grid path: the sequential emulation streams the whole frame and would leave this wave running long after
+        // the rest of the kernel has drained, so the row is queued for knn_tie_kernel (one workgroup
+        // per row) and gets the plain selection for now.  A full queue falls back to doing it here.
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(tie_count, 1);
+        slot = __shfl(slot, 0, 64);
+        if (slot < TIE_CAP) {
+            if (lane == 0) tie_rows[slot] = row;
+            exact_here = false;
+        }
+    }
+    if (exact_here) {
         // boundary tie: reproduce the reference's choice exactly (rare, sequential)
         wave_mem_sync();
         heap_select_exact(pts, len, K, c.x, c.y, c.z, c.aa, cd, ci, td);
-        float mv = (lane < K) ? cd[lane] : __builtin_inff();
-        int mi = (lane < K) ? ci[lane] : 0x7fffffff;
-        const float myv = mv;
-        const int myi = mi;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(mv, off, 64);
-            const int oi = __shfl_xor(mi, off, 64);
-            if (ov < mv || (ov == mv && oi < mi)) mv = ov, mi = oi;
-        }
-        int outv = (myv > r2) ? mi : myi;  // radius mask -> nearest (utils.py:85-87)
-        // slot 0 must be the nearest point: swap it (in registers) with whoever holds it
-        const unsigned long long hm = __ballot(lane < K && myi == mi);
-        const int L = hm ? __builtin_ctzll(hm) : 0;
-        const int v0 = __shfl(outv, 0, 64);
-        if (lane == L) outv = v0;
-        if (lane == 0) outv = mi;
-        if (lane < K) out[lane] = outv;
+        emit_heap_result(cd, ci, K, r2, out);
     } else {
         // unsorted selection: put the nearest point into slot 0 by swapping it with whatever sits there
         int outv = (lane < k) ? ti[lane] : first;
@@ -367,12 +431,12 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
         if (ok) x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
         const float bb = sq3(x, y, z);
 #pragma unroll
-        for (int j = 0; j < CPW; ++j) offer(c[j], ok, x, y, z, bb, i, K, s_d[w][j], s_i[w][j], s_td[w], s_ti[w]);
+        for (int j = 0; j < CPW; ++j) offer(c[j], ok, x, y, z, bb, i, K, (LdsF)s_d[w][j], (LdsI)s_i[w][j], (LdsF)s_td[w], (LdsI)s_ti[w]);
     }
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
         if (s0 + j >= S) break;
-        finish(c[j], pts, len, N, K, r2, s_d[w][j], s_i[w][j], s_td[w], s_ti[w],
+        finish(c[j], pts, len, N, K, r2, (LdsF)s_d[w][j], (LdsI)s_i[w][j], (LdsF)s_td[w], (LdsI)s_ti[w],
                idx_all + ((size_t)b * S + (s0 + j)) * K);
     }
 }
@@ -389,7 +453,9 @@ __global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float *__res
                                                               const int32_t *__restrict__ lengths, int N,
                                                               float cs_min, KnnGrid *__restrict__ hdr_all,
                                                               int *__restrict__ start_all,
-                                                              float4 *__restrict__ sorted_all) {
+                                                              float4 *__restrict__ sorted_all,
+                                                              int *__restrict__ tie_count) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *tie_count = 0;
     __shared__ int s_hist[GDIM * GDIM];
     __shared__ float s_red[4][16];
     __shared__ int s_wsum[16];
@@ -469,7 +535,9 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
                                                             const float4 *__restrict__ sorted_all,
                                                             int32_t *__restrict__ idx_all,
                                                             const int32_t *__restrict__ reuse_idx,
-                                                            const int32_t *__restrict__ center_src) {
+                                                            const int32_t *__restrict__ center_src,
+                                                            int *__restrict__ tie_count,
+                                                            int32_t *__restrict__ tie_rows) {
     __shared__ float s_d[WPB][CAP];
     __shared__ int s_i[WPB][CAP];
     __shared__ float s_td[WPB][TMPN];
@@ -501,8 +569,8 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
                 const bool ok = q < hi;
                 float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ok) p = sorted[q];
-                offer(c, ok, p.x, p.y, p.z, sq3(p.x, p.y, p.z), ok ? __float_as_int(p.w) : 0x7fffffff, K, s_d[w],
-                      s_i[w], s_td[w], s_ti[w]);
+                offer(c, ok, p.x, p.y, p.z, sq3(p.x, p.y, p.z), ok ? __float_as_int(p.w) : 0x7fffffff, K, (LdsF)s_d[w],
+                      (LdsI)s_i[w], (LdsF)s_td[w], (LdsI)s_ti[w]);
             }
         }
     }
@@ -518,7 +586,132 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
             }
         }
     }
-    finish(c, pts, len, N, K, r2, s_d[w], s_i[w], s_td[w], s_ti[w], idx_all + ((size_t)b * S + s) * K);
+    finish(c, pts, len, N, K, r2, (LdsF)s_d[w], (LdsI)s_i[w], (LdsF)s_td[w], (LdsI)s_ti[w], idx_all + ((size_t)b * S + s) * K,
+           tie_count, tie_rows, b * S + s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Boundary-tie rows of the grid search: exact emulation of torch.topk's heap-select, one workgroup
+// per queued row.  The whole workgroup evaluates TIE_U * TIE_T distances per step (in index order: chunk (u, wave) covers
+// 64 consecutive points) and flags the ones below the heap top; only those are replayed sequentially by thread 0,
+// re-checked against the moving top -- exactly the elements std::__heap_select would have touched, in its order.
+// The next batch of points is fetched while the replay runs.
+// ---------------------------------------------------------------------------------------------
+constexpr int TIE_U = 4;    // points per thread per step
+constexpr int TIE_T = 256;  // threads per row: the sequential replay bounds a row, so many small workgroups beat few large ones
+
+__device__ __forceinline__ float rlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int rlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+// "write lane l": a select on the lane id (this toolchain has no v_writelane builtin; two VALU ops are as cheap)
+__device__ __forceinline__ void wlane(int &v, int l, int x) { v = lane_id() == l ? x : v; }
+__device__ __forceinline__ void wlane(float &v, int l, float x) { v = lane_id() == l ? x : v; }
+
+// heap_adjust with the heap held in registers: lane j of the wave owns entry j, every index is wave-uniform,
+// so the walk is v_readlane plus lane-id selects with scalar indices -- no LDS round trips on the serial path.
+__device__ __forceinline__ void heap_adjust_reg(float &hv, int &hi, int hole, int len, float val, int vi) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (rlane(hv, child) < rlane(hv, child - 1)) child--;
+        wlane(hv, hole, rlane(hv, child)), wlane(hi, hole, rlane(hi, child));
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        wlane(hv, hole, rlane(hv, child - 1)), wlane(hi, hole, rlane(hi, child - 1));
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && rlane(hv, parent) < val) {
+        wlane(hv, hole, rlane(hv, parent)), wlane(hi, hole, rlane(hi, parent));
+        hole = parent, parent = (hole - 1) / 2;
+    }
+    wlane(hv, hole, val), wlane(hi, hole, vi);
+}
+
+__global__ __launch_bounds__(TIE_T) void knn_tie_kernel(const float *__restrict__ points_all,
+                                                       const int32_t *__restrict__ lengths,
+                                                       const float *__restrict__ centers_all, int N, int S, int K,
+                                                       float r2, const int *__restrict__ tie_count,
+                                                       const int32_t *__restrict__ tie_rows,
+                                                       int32_t *__restrict__ idx_all) {
+    __shared__ float s_hv[KMAX];
+    __shared__ int s_hi[KMAX];
+    __shared__ float s_dist[TIE_U * TIE_T];
+    __shared__ unsigned long long s_mask[TIE_U * (TIE_T / 64)];
+    __shared__ float s_top;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int n_rows = min(*tie_count, TIE_CAP);
+    for (int r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const int row = tie_rows[r], b = row / S;
+        const float *pts = points_all + (size_t)b * N * 3;
+        const int len = min(max(lengths[b], 0), N);
+        const float *cp = centers_all + (size_t)row * 3;
+        const float cx = cp[0], cy = cp[1], cz = cp[2], caa = sq3(cx, cy, cz);
+        auto dist = [&](float x, float y, float z) -> float { return exp_dist(cx, cy, cz, caa, x, y, z, sq3(x, y, z)); };
+        // wave 0 owns the heap: entry j in lane j
+        float hv = __builtin_inff();
+        int hi = 0x7fffffff;
+        if (w == 0) {
+            if (lane < K) {
+                const int i = min(lane, len - 1);
+                hv = dist(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), hi = lane;
+            }
+            if (K >= 2) {  // std::__make_heap
+                for (int parent = (K - 2) / 2;; --parent) {
+                    heap_adjust_reg(hv, hi, parent, K, rlane(hv, parent), rlane(hi, parent));
+                    if (parent == 0) break;
+                }
+            }
+            if (lane == 0) s_top = hv;
+        }
+        float px[TIE_U], py[TIE_U], pz[TIE_U];
+        auto fetch = [&](int base) {
+#pragma unroll
+            for (int u = 0; u < TIE_U; ++u) {
+                const int i = min(base + u * TIE_T + t, len - 1);
+                px[u] = pts[3 * i], py[u] = pts[3 * i + 1], pz[u] = pts[3 * i + 2];
+            }
+        };
+        fetch(K);
+        for (int base = K; base < len; base += TIE_U * TIE_T) {
+            __syncthreads();  // s_top is final for this step; s_dist / s_mask are free again
+            const float top = s_top;
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < TIE_U; ++u) {
+                const int i = base + u * TIE_T + t;
+                const float d = i < len ? dist(px[u], py[u], pz[u]) : __builtin_inff();
+                s_dist[u * TIE_T + t] = d;
+                const unsigned long long m = __ballot(d < top);
+                if (lane == 0) s_mask[u * (TIE_T / 64) + w] = m;
+                any |= m != 0;
+            }
+            if (base + TIE_U * TIE_T < len) fetch(base + TIE_U * TIE_T);
+            if (__syncthreads_or(any) && w == 0) {
+                // replay, in index order, of the 64-point chunks that had anything below the step's starting top
+                for (int c = 0; c < TIE_U * (TIE_T / 64); ++c) {
+                    if (s_mask[c] == 0) continue;
+                    const float d = s_dist[c * 64 + lane];
+                    unsigned long long mm = __ballot(d < rlane(hv, 0));
+                    while (mm) {
+                        const int l = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        const float dl = rlane(d, l);
+                        if (dl < rlane(hv, 0)) heap_adjust_reg(hv, hi, 0, K, dl, base + c * 64 + l);  // std::__pop_heap
+                    }
+                }
+                if (lane == 0) s_top = hv;
+            }
+        }
+        if (w == 0) {
+            if (lane < K) s_hv[lane] = hv, s_hi[lane] = hi;
+            wave_mem_sync();
+            emit_heap_result((LdsF)s_hv, (LdsI)s_hi, K, r2, idx_all + (size_t)row * K);
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -572,7 +765,7 @@ extern "C" int dpm_ball_query(const float *points, const int32_t *lengths, const
 extern "C" size_t dpm_knn_workspace_bytes(int B, int N) {
     if (N < GRID_MIN_N) return 0;
     return 1024 + sizeof(KnnGrid) * (size_t)B + sizeof(int) * (size_t)B * (GDIM * GDIM + 1) +
-           (size_t)B * (size_t)N * sizeof(float4);
+           (size_t)B * (size_t)N * sizeof(float4) + 256 + sizeof(int32_t) * (size_t)TIE_CAP;
 }
 
 extern "C" int dpm_knn_hybrid_reuse(const float *points, const int32_t *lengths, const float *centers, int B, int N,
@@ -591,12 +784,18 @@ extern "C" int dpm_knn_hybrid_reuse(const float *points, const int32_t *lengths,
         int *start = (int *)p;
         p = (p + sizeof(int) * (size_t)B * (GDIM * GDIM + 1) + 255) & ~(uintptr_t)255;
         float4 *sorted = (float4 *)p;
+        p = (p + sizeof(float4) * (size_t)B * (size_t)N + 255) & ~(uintptr_t)255;
+        int *tie_count = (int *)p;  // [0] = queued rows; the list follows
+        int32_t *tie_rows = (int32_t *)(p + 64);
         // cell edge > sqrt(r^2 + 2e-5): the expanded-form distance can undershoot the true one by ~1.5e-6
         const float cs_min = (float)(sqrt(radius * radius + 2e-5) * 1.002);
         hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, st, points, lengths, N, cs_min, hdr, start,
-                           sorted);
+                           sorted, tie_count);
         hipLaunchKernelGGL(knn_grid_kernel, dim3(dpm_cdiv(S, WPB), B), dim3(WPB * 64), 0, st, points, lengths, centers, N,
-                           S, K, r2, hdr, start, sorted, idx, reuse_idx, center_src);
+                           S, K, r2, hdr, start, sorted, idx, reuse_idx, center_src, tie_count, tie_rows);
+        if ((long long)K * 64 <= (long long)N)  // the only regime with an order-dependent tie rule
+            hipLaunchKernelGGL(knn_tie_kernel, dim3(2048), dim3(TIE_T), 0, st, points, lengths, centers, N, S, K, r2,
+                               tie_count, tie_rows, idx);
         return dpm_launch_status();
     }
     hipLaunchKernelGGL(knn_hybrid_kernel, dim3(dpm_cdiv(S, WPB * CPW), B), dim3(WPB * 64), 0, st, points, lengths, centers,

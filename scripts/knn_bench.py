@@ -1,0 +1,29 @@
+"""Isolated timing of the two grid-search neighbour queries of the first encoder stage (64 frames)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from deeppointmap_amd import ops, synthetic
+
+F, N = 64, 65536
+dev = torch.device("cuda:0")
+pts, pad = synthetic.frames(F, N)
+xyz, lengths = ops.prepare_points(pts.to(dev), pad.to(dev))
+fidx, new_xyz, new_len = ops.fps(xyz, lengths, 4096)
+torch.cuda.synchronize()
+
+
+def timed(name, fn, reps=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{name}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us")
+
+
+timed("SA0  N=65536 S=4096 r=0.05 K=32", lambda: ops.knn_hybrid(xyz, lengths, new_xyz, 32, 0.05))
+timed("LA0  N=4096  S=4096 r=0.10 K=32", lambda: ops.knn_hybrid(new_xyz, new_len, new_xyz, 32, 0.1))
