@@ -15,8 +15,6 @@
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-constexpr int KT = 32;
-constexpr int LDS_LD = KT + 2;
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == DPM_ACT_RELU) return fmaxf(v, 0.f);
@@ -42,14 +40,15 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ base, int ld, 
     return v;
 }
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, int KT = 32>
 __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restrict__ X, int ldx, long long sx,
                                                            const float *__restrict__ W, int ldw, long long sw,
                                                            const float *__restrict__ bias,
                                                            const float *__restrict__ res, int ldr, long long sr,
                                                            float *__restrict__ out, int ldo, long long so, int R,
                                                            int Cin, int Cout, int act) {
-    constexpr int WM = BM / 2, WN = BN / 2, MB = WM / 16, NB = WN / 16, PX = BM / 32, PW = BN / 32;
+    constexpr int LDS_LD = KT == 32 ? 34 : KT + 4, LPR = KT / 4, RPP = 256 / LPR;  // lanes per staged row, rows per staging pass
+    constexpr int WM = BM / 2, WN = BN / 2, MB = WM / 16, NB = WN / 16, PX = BM / RPP, PW = BN / RPP;
     __shared__ float Xs[BM][LDS_LD];
     __shared__ float Ws[BN][LDS_LD];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
@@ -62,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
         by = (int)((slot / gridDim.x) * 8 + xcd), bx = (int)(slot % gridDim.x);
     }
     const int row0 = by * BM, col0 = bx * BN;
-    const int sr_ = t >> 3, sk = (t & 7) * 4;  // staging: row within a 32-row pass, k offset
+    const int sr_ = t / LPR, sk = (t % LPR) * 4;  // staging: row within a pass, k offset
 
     f32x4 acc[MB][NB];
 #pragma unroll
@@ -72,28 +71,28 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
 
     float4 xr[PX], wr[PW];
 #pragma unroll
-    for (int p = 0; p < PX; ++p) xr[p] = load4<VEC>(X, ldx, row0 + p * 32 + sr_, R, sk, Cin);
+    for (int p = 0; p < PX; ++p) xr[p] = load4<VEC>(X, ldx, row0 + p * RPP + sr_, R, sk, Cin);
 #pragma unroll
-    for (int p = 0; p < PW; ++p) wr[p] = load4<VEC>(W, ldw, col0 + p * 32 + sr_, Cout, sk, Cin);
+    for (int p = 0; p < PW; ++p) wr[p] = load4<VEC>(W, ldw, col0 + p * RPP + sr_, Cout, sk, Cin);
 
     for (int k0 = 0; k0 < Cin; k0 += KT) {
         // registers -> LDS (row stride 136 B: 8-byte aligned, so two 8-byte stores per float4)
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
-            float2 *d = reinterpret_cast<float2 *>(&Xs[p * 32 + sr_][sk]);
+            float2 *d = reinterpret_cast<float2 *>(&Xs[p * RPP + sr_][sk]);
             d[0] = make_float2(xr[p].x, xr[p].y), d[1] = make_float2(xr[p].z, xr[p].w);
         }
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
-            float2 *d = reinterpret_cast<float2 *>(&Ws[p * 32 + sr_][sk]);
+            float2 *d = reinterpret_cast<float2 *>(&Ws[p * RPP + sr_][sk]);
             d[0] = make_float2(wr[p].x, wr[p].y), d[1] = make_float2(wr[p].z, wr[p].w);
         }
         __syncthreads();
         if (k0 + KT < Cin) {  // prefetch the next K-tile while this one is consumed
 #pragma unroll
-            for (int p = 0; p < PX; ++p) xr[p] = load4<VEC>(X, ldx, row0 + p * 32 + sr_, R, k0 + KT + sk, Cin);
+            for (int p = 0; p < PX; ++p) xr[p] = load4<VEC>(X, ldx, row0 + p * RPP + sr_, R, k0 + KT + sk, Cin);
 #pragma unroll
-            for (int p = 0; p < PW; ++p) wr[p] = load4<VEC>(W, ldw, col0 + p * 32 + sr_, Cout, k0 + KT + sk, Cin);
+            for (int p = 0; p < PW; ++p) wr[p] = load4<VEC>(W, ldw, col0 + p * RPP + sr_, Cout, k0 + KT + sk, Cin);
         }
         float a[2][MB], b[2][NB];
 #pragma unroll

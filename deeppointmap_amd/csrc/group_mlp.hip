@@ -64,26 +64,29 @@ __global__ __launch_bounds__(256) void group_mlp_mfma_kernel(
         const int k = k0 + sk;
         const bool body_tile = k0 < Cin, tail_tile = Cin >= k0 && Cin < k0 + KT;  // uniform over the workgroup
         const int n = s_nidx[row];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool in = k < Cin;
+        // selects are written per component: a select between two float4 objects is lowered through scratch memory
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
         if (fea && body_tile) {
             const float4 q = *reinterpret_cast<const float4 *>(fea + (size_t)n * Cin + min(k, Cin - 4));
-            v = k < Cin ? q : v;
+            v0 = in ? q.x : 0.f, v1 = in ? q.y : 0.f, v2 = in ? q.z : 0.f, v3 = in ? q.w : 0.f;
         }
         if ((!fea && body_tile) || tail_tile) {
             const float px = xyz[(size_t)n * 3], py = xyz[(size_t)n * 3 + 1], pz = xyz[(size_t)n * 3 + 2];
             if (!fea && body_tile) {
                 const int c = min(k, Cin - 4);
-                float f[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    f[j] = fmaf(W0[3 * (c + j) + 2], pz, fmaf(W0[3 * (c + j) + 1], py, fmaf(W0[3 * (c + j)], px, b0[c + j])));
-                v = k < Cin ? make_float4(f[0], f[1], f[2], f[3]) : v;
+                const float f0 = fmaf(W0[3 * c + 2], pz, fmaf(W0[3 * c + 1], py, fmaf(W0[3 * c], px, b0[c])));
+                const float f1 = fmaf(W0[3 * c + 5], pz, fmaf(W0[3 * c + 4], py, fmaf(W0[3 * c + 3], px, b0[c + 1])));
+                const float f2 = fmaf(W0[3 * c + 8], pz, fmaf(W0[3 * c + 7], py, fmaf(W0[3 * c + 6], px, b0[c + 2])));
+                const float f3 = fmaf(W0[3 * c + 11], pz, fmaf(W0[3 * c + 10], py, fmaf(W0[3 * c + 9], px, b0[c + 3])));
+                v0 = in ? f0 : 0.f, v1 = in ? f1 : 0.f, v2 = in ? f2 : 0.f, v3 = in ? f3 : 0.f;
             }
-            const float *cc = s_ctr[row / K];
-            const float4 rel = make_float4((px - cc[0]) * inv_r, (py - cc[1]) * inv_r, (pz - cc[2]) * inv_r, 0.f);
-            v = k == Cin ? rel : v;
+            const int ci = row / K;
+            const bool rel = k == Cin;
+            const float r0 = (px - s_ctr[ci][0]) * inv_r, r1 = (py - s_ctr[ci][1]) * inv_r, r2_ = (pz - s_ctr[ci][2]) * inv_r;
+            v0 = rel ? r0 : v0, v1 = rel ? r1 : v1, v2 = rel ? r2_ : v2, v3 = rel ? 0.f : v3;
         }
-        return v;
+        return make_float4(v0, v1, v2, v3);
     };
     auto load_w = [&](int row, int k) -> float4 {  // rows of (Cout, Cin+3) are not 16-byte aligned: four dwords
         const float *p = W + (size_t)row * C3;

@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 tile = os.environ.get('DPM_GEMM_V', '0')
 from deeppointmap_amd import ops
 torch.manual_seed(0)
-shapes = [(16384, 256, 256), (32768, 256, 256), (16384, 256, 768), (16384, 256, 512), (262144, 32, 128), (262144, 128, 32), (65536, 64, 256), (65536, 256, 64), (16384, 128, 512), (16384, 512, 128), (4096, 1024, 256), (1024, 2048, 512), (32768, 512, 256)]
+shapes = [(16384, 256, 256), (32768, 256, 256), (65536, 256, 256), (262144, 256, 256), (16384, 256, 768), (16384, 256, 512), (262144, 32, 128), (262144, 128, 32), (65536, 64, 256), (65536, 256, 64), (16384, 128, 512), (16384, 512, 128), (4096, 1024, 256), (1024, 2048, 512), (32768, 512, 256)]
 for R, K, N in shapes:
     x = torch.randn(R, K, device='cuda'); W = torch.randn(N, K, device='cuda'); b = torch.randn(N, device='cuda')
     out = torch.empty(R, N, device='cuda')
