@@ -54,14 +54,15 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
                                                         const float *__restrict__ Kp, int ldk, long long sk,
                                                         const float *__restrict__ V, int ldv, long long sv,
                                                         float *__restrict__ O, int ldo, long long so, int M,
                                                         int N, float scale) {
     constexpr int TK = 64;                 // keys per tile
-    __shared__ float Ks[TK][HD + 2];       // B operand of S = Q K^T: B[k=d][j=key] = Ks[key][d]
-    __shared__ float Vs[TK][HD + 16];      // B operand of O = P V:   B[k=key][j=d] = Vs[key][d]
+    __shared__ __attribute__((aligned(16))) float Ks[TK][HD + 2];   // B operand of S = Q K^T: B[k=d][j=key] = Ks[key][d]
+    __shared__ __attribute__((aligned(16))) float Vs[TK][HD + 16];  // B operand of O = P V: B[k=key][j=d] = Vs[key][d]
     __shared__ float Ps[4][16][TK + 2];    // per wave: P in row-major, re-read in the A-operand layout
     const int b = blockIdx.z, h = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int q0 = blockIdx.x * 64 + w * 16;
@@ -81,24 +82,34 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 #pragma unroll
     for (int q = 0; q < 4; ++q) mrow[q] = -__builtin_inff(), lrow[q] = 0.f;
 
+    // K / V tiles: 64 rows x 32 floats each = 512 float4 per matrix, 2 per thread.  The next tile is fetched into
+    // registers (branch-free: rows beyond N re-read the last key; their scores are masked to -inf below, so the
+    // probabilities that multiply those V rows are exactly 0) while the current one feeds the MFMAs.
+    float4 kreg[2], vreg[2];
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int e = t + p * 256, kr = min(n0 + (e >> 3), N - 1), c4 = (e & 7) * 4;
+            const float *kp = Kb + (size_t)kr * ldk + c4, *vp = Vb + (size_t)kr * ldv + c4;
+            if (VEC) {
+                kreg[p] = *reinterpret_cast<const float4 *>(kp), vreg[p] = *reinterpret_cast<const float4 *>(vp);
+            } else {
+                kreg[p] = make_float4(kp[0], kp[1], kp[2], kp[3]), vreg[p] = make_float4(vp[0], vp[1], vp[2], vp[3]);
+            }
+        }
+    };
+    fetch(0);
     for (int n0 = 0; n0 < N; n0 += TK) {
         __syncthreads();
-        // stage K and V tiles: 64 rows x 32 floats each = 512 float4 per matrix, 2 per thread
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int e = t + p * 256, kr = e >> 3, c4 = (e & 7) * 4;
-            float kv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (n0 + kr < N) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    kv[j] = Kb[(size_t)(n0 + kr) * ldk + c4 + j];
-                    vv[j] = Vb[(size_t)(n0 + kr) * ldv + c4 + j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Ks[kr][c4 + j] = kv[j], Vs[kr][c4 + j] = vv[j];
+            float2 *kd = reinterpret_cast<float2 *>(&Ks[kr][c4]);  // row stride 136 B: 8-byte aligned
+            kd[0] = make_float2(kreg[p].x, kreg[p].y), kd[1] = make_float2(kreg[p].z, kreg[p].w);
+            *reinterpret_cast<float4 *>(&Vs[kr][c4]) = vreg[p];     // row stride 192 B: 16-byte aligned
         }
         __syncthreads();
+        if (n0 + TK < N) fetch(n0 + TK);
         // S tile: 16 queries x 64 keys = 4 MFMA blocks, 8 k-steps each
         f32x4 sacc[4];
 #pragma unroll
@@ -904,8 +915,14 @@ extern "C" int dpm_attention(const float *Q, int ldq, long long sq, const float 
                              int N, int heads, int head_dim, dpm_stream_t stream) {
     DPM_CHECK_ARG(Q && K && V && out && B >= 1 && M >= 1 && N >= 1 && heads >= 1);
     if (head_dim != HD) return DPM_EUNSUPPORTED;
-    hipLaunchKernelGGL(attention_kernel, dim3(dpm_cdiv(M, 64), heads, B), dim3(256), 0, (hipStream_t)stream, Q, ldq, sq,
-                       K, ldk, sk, V, ldv, sv, out, ldo, so, M, N, (float)(1.0 / sqrt((double)head_dim)));
+    const bool vec = ldk % 4 == 0 && ldv % 4 == 0 && sk % 4 == 0 && sv % 4 == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0;
+    const float scale = (float)(1.0 / sqrt((double)head_dim));
+    if (vec)
+        hipLaunchKernelGGL(attention_kernel<true>, dim3(dpm_cdiv(M, 64), heads, B), dim3(256), 0, (hipStream_t)stream, Q, ldq,
+                           sq, K, ldk, sk, V, ldv, sv, out, ldo, so, M, N, scale);
+    else
+        hipLaunchKernelGGL(attention_kernel<false>, dim3(dpm_cdiv(M, 64), heads, B), dim3(256), 0, (hipStream_t)stream, Q, ldq,
+                           sq, K, ldk, sk, V, ldv, sv, out, ldo, so, M, N, scale);
     return dpm_launch_status();
 }
 

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
                                                            const float *__restrict__ res, int ldr, long long sr,
                                                            float *__restrict__ out, int ldo, long long so, int R,
                                                            int Cin, int Cout, int act) {
-    constexpr int LDS_LD = KT == 32 ? 34 : KT + 4, LPR = KT / 4, RPP = 256 / LPR;  // lanes per staged row, rows per staging pass
+    constexpr int LDS_LD = KT + 2, LPR = KT / 4, RPP = 256 / LPR;  // lanes per staged row, rows per staging pass
     constexpr int WM = BM / 2, WN = BN / 2, MB = WM / 16, NB = WN / 16, PX = BM / RPP, PW = BN / RPP;
     __shared__ float Xs[BM][LDS_LD];
     __shared__ float Ws[BN][LDS_LD];
