@@ -149,6 +149,66 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     }
 }
 
+// Vectorised variant for the widths of the path (C = 4 * G * V): G lanes share a row (64 / G rows per wave), every
+// lane keeps its V float4 in registers, so x (+ pre) is read exactly once, and the two row sums are DPP / shuffle
+// reductions inside the lane group.  Same two-pass arithmetic as the generic kernel above.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    if (G >= 2) v += __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v)));   // quad_perm [1,0,3,2]
+    if (G >= 4) v += __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v)));   // quad_perm [2,3,0,1]
+    if (G >= 8) v += __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v)));  // row_half_mirror
+    if (G >= 16) v += __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v)));  // row_mirror
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int G, int V>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float *__restrict__ X, int ldx,
+                                                            const float *__restrict__ pre,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta,
+                                                            const float *__restrict__ post,
+                                                            float *__restrict__ out, int ldo, int R, int act) {
+    constexpr int C = 4 * G * V, RPW = 64 / G;
+    const int lane = threadIdx.x & 63, gl = lane % G;
+    const int r = min((blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G, R - 1);  // surplus lanes redo the last row
+    const float *x = X + (size_t)r * ldx;
+    float4 v[V];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = 4 * (gl + G * j);
+        v[j] = *reinterpret_cast<const float4 *>(x + c);
+        if (pre) {
+            const float4 p = *reinterpret_cast<const float4 *>(pre + (size_t)r * C + c);
+            v[j].x += p.x, v[j].y += p.y, v[j].z += p.z, v[j].w += p.w;
+        }
+        sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mu = group_sum<G>(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        v[j].x -= mu, v[j].y -= mu, v[j].z -= mu, v[j].w -= mu;
+        sq = fmaf(v[j].x, v[j].x, fmaf(v[j].y, v[j].y, fmaf(v[j].z, v[j].z, fmaf(v[j].w, v[j].w, sq))));
+    }
+    const float rs = rsqrtf(group_sum<G>(sq) / (float)C + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = 4 * (gl + G * j);
+        const float4 g4 = *reinterpret_cast<const float4 *>(gamma + c), b4 = *reinterpret_cast<const float4 *>(beta + c);
+        float4 o = make_float4(fmaf(v[j].x * rs, g4.x, b4.x), fmaf(v[j].y * rs, g4.y, b4.y), fmaf(v[j].z * rs, g4.z, b4.z),
+                               fmaf(v[j].w * rs, g4.w, b4.w));
+        if (post) {
+            const float4 p = *reinterpret_cast<const float4 *>(post + (size_t)r * C + c);
+            o.x += p.x, o.y += p.y, o.z += p.z, o.w += p.w;
+        }
+        o.x = apply_act(o.x, act), o.y = apply_act(o.y, act), o.z = apply_act(o.z, act), o.w = apply_act(o.w, act);
+        *reinterpret_cast<float4 *>(out + (size_t)r * ldo + c) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // 3-NN inverse-distance interpolation + concat [skip | interpolated]; one workgroup per fine point
 // ------------------------------------------------------------------------------------------
@@ -239,8 +299,23 @@ extern "C" int dpm_layernorm(const float *x, int ldx, const float *pre, const fl
                              const float *post, float *out, int ldo, int R, int C, int act, dpm_stream_t stream) {
     DPM_CHECK_ARG(x && gamma && beta && out && R >= 1 && C >= 1 && ldx >= C && ldo >= C);
     DPM_CHECK_ARG(act >= DPM_ACT_NONE && act <= DPM_ACT_SIGMOID);
-    hipLaunchKernelGGL(layernorm_kernel, dim3(dpm_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, pre, gamma,
-                       beta, post, out, ldo, R, C, act);
+    hipStream_t st = (hipStream_t)stream;
+    auto al = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+    const bool vec = ldx % 4 == 0 && ldo % 4 == 0 && al(x) && al(out) && al(gamma) && al(beta) && al(pre) && al(post);
+#define DPM_LN(G, V)                                                                                              \
+    hipLaunchKernelGGL((layernorm_vec_kernel<G, V>), dim3(dpm_cdiv(R, 4 * (64 / G))), dim3(256), 0, st, x, ldx, pre, gamma, \
+                       beta, post, out, ldo, R, act)
+    if (vec && C == 32) DPM_LN(8, 1);
+    else if (vec && C == 64) DPM_LN(16, 1);
+    else if (vec && C == 128) DPM_LN(32, 1);
+    else if (vec && C == 256) DPM_LN(64, 1);
+    else if (vec && C == 512) DPM_LN(64, 2);
+    else if (vec && C == 1024) DPM_LN(64, 4);
+    else if (vec && C == 2048) DPM_LN(64, 8);
+    else
+        hipLaunchKernelGGL(layernorm_kernel, dim3(dpm_cdiv(R, 4)), dim3(256), 0, st, x, ldx, pre, gamma, beta, post, out, ldo,
+                           R, C, act);
+#undef DPM_LN
     return dpm_launch_status();
 }
 

@@ -194,7 +194,7 @@ def test_linear_layernorm_interp_vs_torch(ops):
     ops.linear(x.to(DEV), W.to(DEV), None, out=buf[:, 20:32])
     torch.testing.assert_close(buf[:, 20:32].cpu(), x @ W.t(), rtol=1e-5, atol=1e-5)
     assert float(buf[:, :20].abs().sum()) == 0 and float(buf[:, 32:].abs().sum()) == 0
-    for R, C in [(300, 32), (17, 2048), (256, 256)]:
+    for R, C in [(300, 32), (301, 64), (1001, 128), (256, 256), (77, 512), (33, 1024), (17, 2048), (19, 96), (5, 131)]:
         x, pre, post = (torch.randn(R, C, generator=gen) * 3 for _ in range(3))
         gm, bt = torch.randn(C, generator=gen), torch.randn(C, generator=gen)
         y = ops.layernorm(x.to(DEV), gm.to(DEV), bt.to(DEV), act=ops.ACT_RELU, pre=pre.to(DEV), post=post.to(DEV)).cpu()
