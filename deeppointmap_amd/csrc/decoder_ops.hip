@@ -64,8 +64,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     __shared__ __attribute__((aligned(16))) float Ks[TK][HD + 2];   // B operand of S = Q K^T: B[k=d][j=key] = Ks[key][d]
     __shared__ __attribute__((aligned(16))) float Vs[TK][HD + 16];  // B operand of O = P V: B[k=key][j=d] = Vs[key][d]
     __shared__ float Ps[4][16][TK + 2];    // per wave: P in row-major, re-read in the A-operand layout
-    const int b = blockIdx.z, h = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int q0 = blockIdx.x * 64 + w * 16;
+    // all query tiles and heads of one batch element on one XCD: its K / V rows are fetched into that L2 once
+    const unsigned bid = xcd_chunked_id((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
+                                        gridDim.x * gridDim.y * gridDim.z);
+    const int b = bid / (gridDim.x * gridDim.y), h = (bid / gridDim.x) % gridDim.y;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int q0 = (bid % gridDim.x) * 64 + w * 16;
     const float *Qb = Q + (size_t)b * sq + h * HD;
     const float *Kb = Kp + (size_t)b * sk + h * HD;
     const float *Vb = V + (size_t)b * sv + h * HD;

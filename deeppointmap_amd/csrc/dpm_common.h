@@ -31,6 +31,14 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// XCD-aware workgroup order.  Workgroups are dealt round-robin to the 8 XCDs by linear id and every XCD has its own
+// 4 MB L2; with the plain order all XCDs walk through all frames at once and every L2 holds a slice of everything.
+// This maps the hardware id to a logical id such that XCD x processes the contiguous chunk [x*n/8, (x+1)*n/8) in
+// order, i.e. whole frames / pairs stay on one XCD and their gather sources stay L2-resident.
+__device__ __forceinline__ unsigned xcd_chunked_id(unsigned linear, unsigned total) {
+    return (total & 7u) == 0u ? (linear & 7u) * (total >> 3) + (linear >> 3) : linear;
+}
+
 // ---- wave64 reductions on DPP (no LDS crossbar round trips).  After the call every lane holds the result.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }

@@ -38,10 +38,11 @@ __global__ __launch_bounds__(256) void group_mlp_mfma_kernel(
     __shared__ int s_nidx[TM];
     __shared__ float s_ctr[TM / 16][3];
 
-    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w / WN, wn = w % WN;
+    const unsigned bid = xcd_chunked_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int b = bid / gridDim.x, t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w / WN, wn = w % WN;
     const int C3 = Cin + 3;
     const int cpb = TM / K;                       // centres per workgroup (2 or 4)
-    const int s0 = blockIdx.x * cpb;              // first centre
+    const int s0 = (bid % gridDim.x) * cpb;       // first centre
     const float *xyz = xyz_all + (size_t)b * N * 3;
     const float *fea = fea_all ? fea_all + (size_t)b * N * Cin : nullptr;
 
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void group_mlp_wave_kernel(
         }
     }
 
-    const long long first = ((long long)blockIdx.x * 4 + w) * cpw;
+    const long long first = ((long long)xcd_chunked_id(blockIdx.x, gridDim.x) * 4 + w) * cpw;
     const long long last = min(first + cpw, total);
     for (long long cc = first; cc < last; ++cc) {
         const int b = (int)(cc / S);

@@ -542,8 +542,9 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
     __shared__ int s_i[WPB][CAP];
     __shared__ float s_td[WPB][TMPN];
     __shared__ int s_ti[WPB][TMPN];
-    const int b = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = blockIdx.x * WPB + w;
+    const unsigned bid = xcd_chunked_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int b = bid / gridDim.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = (bid % gridDim.x) * WPB + w;
     if (s >= S) return;
     if (reuse_idx) {
         const int src = center_src[(size_t)b * S + s];
