@@ -296,53 +296,71 @@ __global__ __launch_bounds__(256) void group_mlp_wave_kernel(
         }
     }
 
-    const long long first = ((long long)xcd_chunked_id(blockIdx.x, gridDim.x) * 4 + w) * cpw;
-    const long long last = min(first + cpw, total);
-    for (long long cc = first; cc < last; ++cc) {
-        const int b = (int)(cc / S);
+    // centre ids fit 32 bits (dispatcher checks); the frame index is carried along instead of divided out per centre
+    const int first = (int)((xcd_chunked_id(blockIdx.x, gridDim.x) * 4 + w) * (unsigned)cpw);
+    const int last = (int)min((long long)first + cpw, total);
+    const int gc = min(g, 2);  // lane group g carries relative coordinate g (group 3 carries the zero padding)
+    struct Rows {  // the gathered A operand of one centre
+        float4 a[MB][NC];
+        float rel[MB];
+    };
+    auto load_idx = [&](int cc, int (&n)[MB]) {
+        const int c = min(cc, last - 1);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) n[m] = idx_all[(size_t)c * KN + m * 16 + i];
+    };
+    auto gather = [&](int cc, const int (&n)[MB], Rows &r) {
+        const int c = min(cc, last - 1), b = c / S;
         const float *xyz = xyz_all + (size_t)b * N * 3;
         const float *fea = FUSED ? nullptr : fea_all + (size_t)b * N * CIN;
-        const float cx = ctr_all[cc * 3], cy = ctr_all[cc * 3 + 1], cz = ctr_all[cc * 3 + 2];
+        const float cg = ctr_all[(size_t)c * 3 + gc];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int nm = min(max(n[m], 0), N - 1);
+            if (FUSED) {
+                // features from the point itself: three loads per lane; the relative coordinate falls out of them
+                const float px = xyz[(size_t)nm * 3], py = xyz[(size_t)nm * 3 + 1], pz = xyz[(size_t)nm * 3 + 2];
+                float f[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    f[jj] = fmaf(w0[jj][2], pz, fmaf(w0[jj][1], py, fmaf(w0[jj][0], px, bb0[jj])));
+                r.a[m][0] = make_float4(f[0], f[1], f[2], f[3]);
+                r.rel[m] = ((g == 0 ? px : (g == 1 ? py : pz)) - cg) * inv_r;
+            } else {
+#pragma unroll
+                for (int c4 = 0; c4 < NC; ++c4)
+                    r.a[m][c4] = *reinterpret_cast<const float4 *>(fea + (size_t)nm * CIN + 16 * c4 + 4 * g);
+                r.rel[m] = (xyz[(size_t)nm * 3 + gc] - cg) * inv_r;  // one load per lane, no divergence
+            }
+            r.rel[m] = g == 3 ? 0.f : r.rel[m];
+        }
+    };
+    auto compute = [&](int cc, const Rows &r) {
         float mx[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) mx[j] = 0.f;  // ReLU floor
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            const int n = min(max(idx_all[cc * KN + m * 16 + i], 0), N - 1);
-            const float px = xyz[(size_t)n * 3], py = xyz[(size_t)n * 3 + 1], pz = xyz[(size_t)n * 3 + 2];
-            const float rel = (g == 0 ? px - cx : g == 1 ? py - cy : g == 2 ? pz - cz : 0.f) * inv_r;
-            float4 a[NC];
-            if (FUSED) {
-                float f[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    f[jj] = fmaf(w0[jj][2], pz, fmaf(w0[jj][1], py, fmaf(w0[jj][0], px, bb0[jj])));
-                a[0] = make_float4(f[0], f[1], f[2], f[3]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    a[c] = *reinterpret_cast<const float4 *>(fea + (size_t)n * CIN + 16 * c + 4 * g);
-            }
             f32x4 acc[NB];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NB; ++j) acc[j] = f32x4{bv[j], bv[j], bv[j], bv[j]};  // bias folded into the accumulator
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].x, Bf[j][c * 4 + 0], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].y, Bf[j][c * 4 + 1], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].z, Bf[j][c * 4 + 2], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].w, Bf[j][c * 4 + 3], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[m][c].x, Bf[j][c * 4 + 0], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[m][c].y, Bf[j][c * 4 + 1], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[m][c].z, Bf[j][c * 4 + 2], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[m][c].w, Bf[j][c * 4 + 3], acc[j], 0, 0, 0);
                 }
 #pragma unroll
-            for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(rel, Bt[j], acc[j], 0, 0, 0);
-            // bias, two-pass LayerNorm over the COUT columns of each of this lane group's 4 rows, ReLU, max over rows
+            for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.rel[m], Bt[j], acc[j], 0, 0, 0);
+            // two-pass LayerNorm over the COUT columns of each of this lane group's 4 rows, ReLU, max over rows
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float sum = 0.f;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) acc[j][q] += bv[j], sum += acc[j][q];
+                for (int j = 0; j < NB; ++j) sum += acc[j][q];
                 const float mean = row16_sum(sum) * (1.0f / (float)COUT);
                 float sq = 0.f;
 #pragma unroll
@@ -360,8 +378,20 @@ __global__ __launch_bounds__(256) void group_mlp_wave_kernel(
             float v = mx[j];
             v = fmaxf(v, __shfl_xor(v, 16, 64));
             v = fmaxf(v, __shfl_xor(v, 32, 64));
-            if (g == 0) out_all[cc * COUT + j * 16 + i] = v;
+            if (g == 0) out_all[(size_t)cc * COUT + j * 16 + i] = v;
         }
+    };
+    // All gathers of a centre are issued before its first MFMA and the neighbour indices of the next centre are
+    // fetched meanwhile.  (Keeping two centres in flight per wave measured slower: the kernel is bound by VALU issue
+    // in the LayerNorm epilogue, not by load latency, and the extra registers cost occupancy.)
+    if (first >= last) return;
+    int n[MB];
+    Rows A;
+    load_idx(first, n);
+    for (int cc = first; cc < last; ++cc) {
+        gather(cc, n, A);
+        load_idx(cc + 1, n);
+        compute(cc, A);
     }
 }
 
@@ -370,6 +400,7 @@ int launch_wave(const float *xyz, const float *fea, const float *centers, const 
                 const float *bias, const float *gamma, const float *beta, int B, int N, int S, int K, float inv_r,
                 float *out, hipStream_t st, const float *W0, const float *b0) {
     const long long total = (long long)B * S;
+    if (total * 32 >= (1LL << 31)) return DPM_EUNSUPPORTED;
     const int cpw = total >= (1 << 16) ? 8 : (total >= (1 << 13) ? 2 : 1);  // centres per wave
     const unsigned grid = dpm_cdiv(total, 4LL * cpw);
     if (K == 32)
