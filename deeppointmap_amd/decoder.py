@@ -93,6 +93,9 @@ class Decoder(ParamTree):
             raise ValueError("src and dst batch sizes differ")
         C, E = self.in_channel, self.model_channel
         xyz_s, xyz_d = ts[:, C:C + 3], td[:, C:C + 3]
+        if M == N:
+            x, y = self._attention_layers_joint(ts, td, B, M)
+            return x, xyz_s, y, xyz_d, B, M, N
         ps, pd = ops.posemb(xyz_s, self._dimt(dev), E), ops.posemb(xyz_d, self._dimt(dev), E)
         # x + pos enters every layer: fold the addition into the producing kernel's epilogue
         xp = ops.linear(ts[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=ps)
@@ -112,6 +115,32 @@ class Decoder(ParamTree):
             yp = self._ln(pre + ".norm3", self._lin(pre + ".mlp.2", self._lin(pre + ".mlp.0", y2, ops.ACT_RELU),
                                                     residual=y2), post=None if last else pd)
         return xp, xyz_s, yp, xyz_d, B, M, N
+
+    def _attention_layers_joint(self, ts, td, B, M):
+        """Same arithmetic as the two-sided loop above for M == N, with the source and target tokens stacked into one
+        (2*B*M)-row matrix: the layers share their weights between the two sides (descriptor_attention.py:31-48), so
+        every projection / LayerNorm / MLP is ONE launch over all rows, self attention is one launch over 2B
+        sequences, and only cross attention needs one launch per direction (queries of one half, keys/values of the
+        other).  Row-wise kernels give bit-identical rows whatever the row count, so the results equal the split path."""
+        C, E, R = self.in_channel, self.model_channel, B * M
+        dev = ts.device
+        z_in = torch.cat([ts, td], dim=0)                       # (2R, 131): [src tokens ; dst tokens]
+        pos = ops.posemb(z_in[:, C:C + 3], self._dimt(dev), E)
+        zp = ops.linear(z_in[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=pos)
+        for l in range(self.attention_layers):
+            pre = f"descriptor_attention.{l}"
+            last = l == self.attention_layers - 1
+            z1 = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", zp, 2 * B, M), post=pos)
+            ca = pre + ".cross_attn"
+            qkv = ops.linear(z1, self.p(ca + ".in_proj_weight"), self.p(ca + ".in_proj_bias"))  # q | k | v of every token
+            a = torch.empty(2 * R, E, device=dev, dtype=torch.float32)
+            ops.attention(qkv[:R, :E], qkv[R:, E:2 * E], qkv[R:, 2 * E:], B, M, M, HEADS, out=a[:R])   # src <- dst
+            ops.attention(qkv[R:, :E], qkv[:R, E:2 * E], qkv[:R, 2 * E:], B, M, M, HEADS, out=a[R:])   # dst <- src
+            z2 = self._ln(pre + ".norm2", ops.linear(a, self.p(ca + ".out_proj.weight"), self.p(ca + ".out_proj.bias"),
+                                                     residual=z1))
+            zp = self._ln(pre + ".norm3", self._lin(pre + ".mlp.2", self._lin(pre + ".mlp.0", z2, ops.ACT_RELU),
+                                                    residual=z2), post=None if last else pos)
+        return zp[:R], zp[R:]
 
     # -- public API ----------------------------------------------------------------------------
     def forward(self, *a, **k):
