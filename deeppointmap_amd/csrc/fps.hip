@@ -490,8 +490,10 @@ extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N
     float *ws = (float *)workspace;
     if (N <= 64) return launch<64, 1, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
     if (N <= 256) return launch<256, 1, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
-    if (N <= 1024) return launch<1024, 1, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
-    if (N <= 4096) return launch<1024, 4, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
+    // block shapes measured per level (scripts/fps_small_bench.py): fewer waves = cheaper barrier and second-level
+    // reduction, more points per thread = more independent work per round
+    if (N <= 1024) return launch<256, 4, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
+    if (N <= 4096) return launch<512, 8, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
     if (N <= 16384) return launch<1024, 16, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
     DPM_CHECK_ARG(workspace != nullptr);
     return launch<1024, 1, false>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
