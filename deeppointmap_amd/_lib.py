@@ -48,6 +48,11 @@ SIGNATURES = {
     "dpm_corr_kabsch": (I, [P, P, I, LL, P, I, LL, P, P, P, I, I, D, I, D, P, P, P, I, P]),
     "dpm_preprocess_workspace_bytes": (c_size_t, [LL]),
     "dpm_preprocess_scan": (I, [P, I, I, D, D, D, D, LL, P, P, I, P, P, P]),
+    "dpm_knn_self_workspace_bytes": (c_size_t, [I]),
+    "dpm_knn_self": (I, [P, I, I, D, P, P, P, P, P]),
+    "dpm_point_normals": (I, [P, I, D, P, P, P]),
+    "dpm_lowpass_similarity": (I, [P, P, I, I, I, P, P]),
+    "dpm_stat_filter": (I, [P, I, D, I, D, P, P, P, P, P, P]),
     "dpm_map_tile": (I, [P, P, P, P, I, I, I, P, P]),
     "dpm_infomat_workspace_bytes": (c_size_t, [I, I, I]),
     "dpm_information_matrix": (I, [P, I, P, I, P, D, P, P, P]),

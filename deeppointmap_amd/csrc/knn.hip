@@ -292,10 +292,16 @@ __device__ __forceinline__ void ctr_init(Ctr &c, const float *p, float r2) {
 }
 
 // Offer one point per lane (ok = lane holds a valid point with original index i) to centre c.
+// Offer one candidate per lane with a precomputed squared distance d (inf for lanes without a point).
+__device__ __forceinline__ void offer_d(Ctr &c, float d, int i, int K, LdsF cd, LdsI ci, LdsF td, LdsI ti);
+
 __device__ __forceinline__ void offer(Ctr &c, bool ok, float x, float y, float z, float bb, int i, int K,
                                       LdsF cd, LdsI ci, LdsF td, LdsI ti) {
+    offer_d(c, ok ? exp_dist(c.x, c.y, c.z, c.aa, x, y, z, bb) : __builtin_inff(), i, K, cd, ci, td, ti);
+}
+
+__device__ __forceinline__ void offer_d(Ctr &c, float d, int i, int K, LdsF cd, LdsI ci, LdsF td, LdsI ti) {
     const int lane = lane_id();
-    const float d = ok ? exp_dist(c.x, c.y, c.z, c.aa, x, y, z, bb) : __builtin_inff();
     if (d < c.gd || (d == c.gd && i < c.gi)) c.gd = d, c.gi = i;
     const bool in = d <= c.thr;
     const unsigned long long m = __ballot(in);
@@ -716,6 +722,184 @@ __global__ __launch_bounds__(TIE_T) void knn_tie_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Self kNN of one cloud (pre-processing filters: OutlierFilter / LowPassFilter, reference
+// dataloader/transforms.py:230-289, which call pytorch3d.knn_points(p, p, K+1) and drop the first column).
+// Exact, no radius: one wave per point searches the (2R+1)^2 cell block around it and accepts the result when
+// the K-th distance is within R cells (every point outside the block is farther than that); otherwise R doubles
+// (sparse far-range points) until the block covers the grid.  Distances are the direct form (dx^2+dy^2)+dz^2;
+// the K+1 nearest (the point itself first) are ordered by (distance, index) and column 0 is dropped.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WPB * 64) void knn_self_kernel(const float *__restrict__ pts, int N, int K,
+                                                            const KnnGrid *__restrict__ hdr,
+                                                            const int *__restrict__ start,
+                                                            const float4 *__restrict__ sorted,
+                                                            int32_t *__restrict__ idx_out,
+                                                            float *__restrict__ dist2_out,
+                                                            float *__restrict__ mean_dist_out) {
+    __shared__ float s_d[WPB][CAP];
+    __shared__ int s_i[WPB][CAP];
+    __shared__ float s_td[WPB][TMPN];
+    __shared__ int s_ti[WPB][TMPN];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * WPB + w;
+    if (q >= N) return;
+    LdsF cd = (LdsF)s_d[w], td = (LdsF)s_td[w];
+    LdsI ci = (LdsI)s_i[w], ti = (LdsI)s_ti[w];
+    const KnnGrid G = hdr[0];
+    const float cs = 1.0f / G.inv_cs;
+    const int K1 = K + 1;
+    const float qx = pts[3 * q], qy = pts[3 * q + 1], qz = pts[3 * q + 2];
+    const int cx = min(max((int)floorf((qx - G.lox) * G.inv_cs), 0), G.g - 1);
+    const int cy = min(max((int)floorf((qy - G.loy) * G.inv_cs), 0), G.g - 1);
+    Ctr c;
+    int cnt = 0;
+    for (int R = 1;; R *= 2) {
+        c.x = qx, c.y = qy, c.z = qz, c.aa = 0.f;
+        c.thr = __builtin_inff(), c.gd = __builtin_inff(), c.gi = 0x7fffffff, c.cnt = 0, c.tie = false;
+        const int x0 = max(cx - R, 0), x1 = min(cx + R, G.g - 1);
+        for (int yy = max(cy - R, 0); yy <= min(cy + R, G.g - 1); ++yy) {
+            const int lo = start[yy * G.g + x0], hi = start[yy * G.g + x1 + 1];
+            for (int base = lo; base < hi; base += 64) {
+                const int p = base + lane;
+                float d = __builtin_inff();
+                int i = 0x7fffffff;
+                if (p < hi) {
+                    const float4 t4 = sorted[p];
+                    const float dx = qx - t4.x, dy = qy - t4.y, dz = qz - t4.z;
+                    d = (dx * dx + dy * dy) + dz * dz;
+                    i = __float_as_int(t4.w);
+                }
+                offer_d(c, d, i, K1, cd, ci, td, ti);
+            }
+        }
+        wave_mem_sync();
+        const bool whole = x0 == 0 && x1 == G.g - 1 && cy - R <= 0 && cy + R >= G.g - 1;
+        cnt = min(c.cnt, K1);
+        float kth = __builtin_inff();
+        if (c.cnt > K1) {
+            bool tie = false;
+            kth = select_k(cd, ci, c.cnt, K1, td, ti, &tie);
+        } else {
+            for (int p = lane; p < c.cnt; p += 64) td[p] = cd[p], ti[p] = ci[p];
+            wave_mem_sync();
+            if (c.cnt == K1) {
+                float v = lane < K1 ? td[lane] : -__builtin_inff();
+                kth = wave_max_dpp(v);
+            }
+        }
+        const float reach = (float)R * cs;
+        if (whole || kth <= reach * reach * (1.f - 1e-5f)) break;
+    }
+    // order the (<= K+1) survivors by (distance, index): lane j ranks its own entry against the others
+    const float dj = lane < cnt ? td[lane] : __builtin_inff();
+    const int ij = lane < cnt ? ti[lane] : 0x7fffffff;
+    int rank = 0;
+    for (int o = 0; o < cnt; ++o) {
+        const float dv = rlane(dj, o);
+        const int iv = rlane(ij, o);
+        rank += (dv < dj || (dv == dj && iv < ij)) ? 1 : 0;
+    }
+    // column 0 (the point itself) is dropped; missing neighbours (cloud smaller than K+1) repeat index q at d = 0
+    if (lane < cnt && rank >= 1) {
+        if (idx_out) idx_out[(size_t)q * K + rank - 1] = ij;
+        if (dist2_out) dist2_out[(size_t)q * K + rank - 1] = dj;
+    }
+    if (lane >= cnt && lane < K1 && lane >= 1) {
+        if (idx_out) idx_out[(size_t)q * K + lane - 1] = q;
+        if (dist2_out) dist2_out[(size_t)q * K + lane - 1] = 0.f;
+    }
+    if (mean_dist_out) {  // mean over the K columns of sqrt(d^2), summed in column order
+        float acc = 0.f;
+        const float sd = (lane < cnt && rank >= 1) ? sqrtf(dj) : 0.f;
+        for (int r = 1; r < K1; ++r) {
+            const unsigned long long m = __ballot(lane < cnt && rank == r);
+            acc += m ? rlane(sd, (int)__builtin_ctzll(m)) : 0.f;
+        }
+        if (lane == 0) mean_dist_out[q] = acc / (float)K;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Point normals for LowPassFilter (reference dataloader/transforms.py:268-271: open3d 0.16
+// PointCloud.estimate_normals(KDTreeSearchParamRadius(r))): covariance of the points within r of the point
+// (itself included) from fp64 cumulants, normal = unit eigenvector of its smallest eigenvalue (cyclic Jacobi in
+// fp64; the sign is arbitrary -- the caller only uses |n_i . n_j|); fewer than 3 points in range -> (0,0,1).
+// One wave per point over the 3x3 cells of a grid with cell edge >= r.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(WPB * 64) void point_normals_kernel(const float *__restrict__ pts, int N, float r2,
+                                                                 const KnnGrid *__restrict__ hdr,
+                                                                 const int *__restrict__ start,
+                                                                 const float4 *__restrict__ sorted,
+                                                                 float *__restrict__ normals) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * WPB + w;
+    if (q >= N) return;
+    const KnnGrid G = hdr[0];
+    const float qx = pts[3 * q], qy = pts[3 * q + 1], qz = pts[3 * q + 2];
+    const int cx = min(max((int)floorf((qx - G.lox) * G.inv_cs), 0), G.g - 1);
+    const int cy = min(max((int)floorf((qy - G.loy) * G.inv_cs), 0), G.g - 1);
+    double m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // n, x, y, z, xx, xy, xz, yy, yz, zz
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.g - 1);
+    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, G.g - 1); ++yy) {
+        const int lo = start[yy * G.g + x0], hi = start[yy * G.g + x1 + 1];
+        for (int p = lo + lane; p < hi; p += 64) {
+            const float4 t4 = sorted[p];
+            const float dx = qx - t4.x, dy = qy - t4.y, dz = qz - t4.z;
+            if ((dx * dx + dy * dy) + dz * dz < r2) {
+                const double X = t4.x, Y = t4.y, Z = t4.z;
+                m[0] += 1.0, m[1] += X, m[2] += Y, m[3] += Z;
+                m[4] += X * X, m[5] += X * Y, m[6] += X * Z, m[7] += Y * Y, m[8] += Y * Z, m[9] += Z * Z;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) m[k] = wave_sum_f64(m[k]);
+    if (lane != 0) return;
+    float nx = 0.f, ny = 0.f, nz = 1.f;
+    if (m[0] >= 3.0) {
+        const double n = m[0], mx = m[1] / n, my = m[2] / n, mz = m[3] / n;
+        double A[3][3] = {{m[4] / n - mx * mx, m[5] / n - mx * my, m[6] / n - mx * mz},
+                          {0, m[7] / n - my * my, m[8] / n - my * mz},
+                          {0, 0, m[9] / n - mz * mz}};
+        A[1][0] = A[0][1], A[2][0] = A[0][2], A[2][1] = A[1][2];
+        double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int sweep = 0; sweep < 12; ++sweep) {
+            const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+            if (off <= 1e-300 || off <= 1e-18 * (fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]))) break;
+            for (int p = 0; p < 2; ++p)
+                for (int r = p + 1; r < 3; ++r) {
+                    if (A[p][r] == 0.0) continue;
+                    const double theta = (A[r][r] - A[p][p]) / (2.0 * A[p][r]);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double cs_ = 1.0 / sqrt(t * t + 1.0), sn = t * cs_;
+                    for (int k = 0; k < 3; ++k) {  // A <- A J
+                        const double akp = A[k][p], akr = A[k][r];
+                        A[k][p] = cs_ * akp - sn * akr, A[k][r] = sn * akp + cs_ * akr;
+                    }
+                    for (int k = 0; k < 3; ++k) {  // A <- J^T A,  V <- V J
+                        const double apk = A[p][k], ark = A[r][k];
+                        A[p][k] = cs_ * apk - sn * ark, A[r][k] = sn * apk + cs_ * ark;
+                        const double vkp = V[k][p], vkr = V[k][r];
+                        V[k][p] = cs_ * vkp - sn * vkr, V[k][r] = sn * vkp + cs_ * vkr;
+                    }
+                }
+        }
+        int e = 0;
+        if (A[1][1] < A[e][e]) e = 1;
+        if (A[2][2] < A[e][e]) e = 2;
+        const double vx = V[0][e], vy = V[1][e], vz = V[2][e], nr = sqrt(vx * vx + vy * vy + vz * vz);
+        if (nr > 0.0) nx = (float)(vx / nr), ny = (float)(vy / nr), nz = (float)(vz / nr);
+    }
+    normals[3 * (size_t)q] = nx, normals[3 * (size_t)q + 1] = ny, normals[3 * (size_t)q + 2] = nz;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Querier.ball_query (utils.py:57-73): the K smallest INDICES among the points within the radius, ascending,
 // padded with the first of them.  One wave per centre scans the frame in index order and stops at K hits.
 // (A centre with no point in range gets index N in every slot in the reference -- an out-of-range gather
@@ -807,4 +991,54 @@ extern "C" int dpm_knn_hybrid_reuse(const float *points, const int32_t *lengths,
 extern "C" int dpm_knn_hybrid(const float *points, const int32_t *lengths, const float *centers, int B, int N,
                               int S, int K, double radius, int32_t *idx, void *workspace, dpm_stream_t stream) {
     return dpm_knn_hybrid_reuse(points, lengths, centers, B, N, S, K, radius, idx, workspace, nullptr, nullptr, stream);
+}
+
+// ---- self kNN (pre-processing filters) ------------------------------------------------------------------
+extern "C" size_t dpm_knn_self_workspace_bytes(int N) { return dpm_knn_workspace_bytes(1, N > GRID_MIN_N ? N : GRID_MIN_N); }
+
+extern "C" int dpm_knn_self(const float *xyz, int N, int K, double cell, int32_t *idx, float *dist2, float *mean_dist,
+                            void *workspace, dpm_stream_t stream) {
+    DPM_CHECK_ARG(xyz && workspace && N >= 1 && K >= 1 && cell > 0.0 && (idx || dist2 || mean_dist));
+    if (K + 1 > KMAX) return DPM_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    KnnGrid *hdr = (KnnGrid *)p;
+    p = (p + sizeof(KnnGrid) + 255) & ~(uintptr_t)255;
+    int *start = (int *)p;
+    p = (p + sizeof(int) * (size_t)(GDIM * GDIM + 1) + 255) & ~(uintptr_t)255;
+    float4 *sorted = (float4 *)p;
+    p = (p + sizeof(float4) * (size_t)N + 255) & ~(uintptr_t)255;
+    int *tie_count = (int *)p;
+    // one "frame" of N points, all valid: the length lives in the workspace header area
+    int32_t *len_dev = (int32_t *)(tie_count + 8);
+    hipError_t e = hipMemcpyAsync(len_dev, &N, sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(1), dim3(1024), 0, st, xyz, len_dev, N, (float)cell, hdr, start, sorted,
+                       tie_count);
+    hipLaunchKernelGGL(knn_self_kernel, dim3(dpm_cdiv(N, WPB)), dim3(WPB * 64), 0, st, xyz, N, K, hdr, start, sorted, idx,
+                       dist2, mean_dist);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_point_normals(const float *xyz, int N, double radius, float *normals, void *workspace,
+                                 dpm_stream_t stream) {
+    DPM_CHECK_ARG(xyz && normals && workspace && N >= 1 && radius > 0.0);
+    hipStream_t st = (hipStream_t)stream;
+    uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    KnnGrid *hdr = (KnnGrid *)p;
+    p = (p + sizeof(KnnGrid) + 255) & ~(uintptr_t)255;
+    int *start = (int *)p;
+    p = (p + sizeof(int) * (size_t)(GDIM * GDIM + 1) + 255) & ~(uintptr_t)255;
+    float4 *sorted = (float4 *)p;
+    p = (p + sizeof(float4) * (size_t)N + 255) & ~(uintptr_t)255;
+    int *tie_count = (int *)p;
+    int32_t *len_dev = (int32_t *)(tie_count + 8);
+    hipError_t e = hipMemcpyAsync(len_dev, &N, sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    // cell edge slightly above the radius: the 3x3 block then contains every point strictly within it
+    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(1), dim3(1024), 0, st, xyz, len_dev, N, (float)(radius * 1.001), hdr, start,
+                       sorted, tie_count);
+    hipLaunchKernelGGL(point_normals_kernel, dim3(dpm_cdiv(N, WPB)), dim3(WPB * 64), 0, st, xyz, N,
+                       (float)(radius * radius), hdr, start, sorted, normals);
+    return dpm_launch_status();
 }

@@ -167,6 +167,107 @@ __global__ __launch_bounds__(256) void pre_write_kernel(const float *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// LowPassFilter similarity (transforms.py:279-281): sim[i] = sum of the `flux` largest |n_i . n_j| over the K
+// nearest neighbours j of i.  One thread per point.
+// ------------------------------------------------------------------------------------------
+constexpr int FLUX_MAX = 8;
+
+__global__ __launch_bounds__(256) void lowpass_sim_kernel(const float *__restrict__ normals,
+                                                          const int32_t *__restrict__ idx, int N, int K, int flux,
+                                                          float *__restrict__ sim) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float nx = normals[3 * (size_t)i], ny = normals[3 * (size_t)i + 1], nz = normals[3 * (size_t)i + 2];
+    float top[FLUX_MAX];
+#pragma unroll
+    for (int f = 0; f < FLUX_MAX; ++f) top[f] = -1.f;  // similarities are >= 0
+    for (int k = 0; k < K; ++k) {
+        const int j = idx[(size_t)i * K + k];
+        // (grouped_normals @ normals.unsqueeze(-1)): a K=3 dot product accumulated in index order
+        float v = fabsf(fmaf(normals[3 * (size_t)j + 2], nz, fmaf(normals[3 * (size_t)j + 1], ny, normals[3 * (size_t)j] * nx)));
+#pragma unroll
+        for (int f = 0; f < FLUX_MAX; ++f) {  // insertion into the descending list
+            if (f < flux && v > top[f]) {
+                const float t = top[f];
+                top[f] = v, v = t;
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < FLUX_MAX; ++f)
+        if (f < flux) s += fmaxf(top[f], 0.f);
+    sim[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Statistical cut + stable compaction shared by OutlierFilter and LowPassFilter (transforms.py:241-246,
+// 282-287): mean and unbiased std of stat[0..N) (fp64 accumulation, rounded to fp32 like the torch scalars),
+// mode 0 keeps stat <= mean + k*std, mode 1 keeps stat > mean - k*std; survivors keep their order.
+// One 1024-thread workgroup (scans after voxel sampling have a few 10^4 points).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void stat_filter_kernel(const float *__restrict__ stat, int N, float k_std, int mode,
+                                                           float ratio,
+                                                           const float *__restrict__ xyz_in,
+                                                           const int32_t *__restrict__ idx_in,
+                                                           float *__restrict__ xyz_out, int32_t *__restrict__ idx_out,
+                                                           int32_t *__restrict__ n_out) {
+    __shared__ double s_red[16];
+    __shared__ int s_cnt[16];
+    __shared__ double s_bcast;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    auto block_sum = [&](double v) -> double {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        __syncthreads();
+        if (lane == 0) s_red[w] = v;
+        __syncthreads();
+        if (t == 0) {
+            double a = 0.0;
+            for (int k = 0; k < 16; ++k) a += s_red[k];
+            s_bcast = a;
+        }
+        __syncthreads();
+        return s_bcast;
+    };
+    double a = 0.0;
+    for (int i = t; i < N; i += 1024) a += (double)stat[i];
+    const double mean = block_sum(a) / (double)N;
+    double q = 0.0;
+    for (int i = t; i < N; i += 1024) {
+        const double d = (double)stat[i] - mean;
+        q += d * d;
+    }
+    const double var = N > 1 ? block_sum(q) / (double)(N - 1) : 0.0;
+    const float mean_f = (float)mean, std_f = (float)sqrt(var);
+    const float thr = mode == 0 ? mean_f + k_std * std_f : mean_f - k_std * std_f;
+    auto keep = [&](int i) -> bool { return i < N && (mode == 0 ? stat[i] <= thr : stat[i] > thr); };
+    // stable compaction: wave w owns the contiguous range [w*per, (w+1)*per) and walks it 64 points at a time
+    const int per = ((N + 15) / 16 + 63) & ~63, i0 = min(w * per, N), i1 = min(i0 + per, N);
+    int c = 0;
+    for (int i = i0; i < i1; i += 64) c += __popcll(__ballot(keep(i + lane)));
+    if (lane == 0) s_cnt[w] = c;
+    __syncthreads();
+    int pos = 0;
+    for (int k = 0; k < w; ++k) pos += s_cnt[k];
+    const unsigned long long ltm = (1ull << lane) - 1ull;
+    for (int i = i0; i < i1; i += 64) {
+        const int j = i + lane;
+        const bool kp = keep(j);
+        const unsigned long long m = __ballot(kp);
+        if (kp) {
+            const size_t o = (size_t)(pos + __popcll(m & ltm));
+            // CoordinatesNormalization folded into the last filter: a true division (x / 1 is exact)
+            xyz_out[3 * o] = xyz_in[3 * (size_t)j] / ratio, xyz_out[3 * o + 1] = xyz_in[3 * (size_t)j + 1] / ratio;
+            xyz_out[3 * o + 2] = xyz_in[3 * (size_t)j + 2] / ratio;
+            if (idx_out) idx_out[o] = idx_in ? idx_in[j] : j;
+        }
+        pos += __popcll(m);
+    }
+    if (t == 1023) *n_out = pos;
+}
+
 }  // namespace
 
 extern "C" size_t dpm_preprocess_workspace_bytes(long long max_cells) {
@@ -196,5 +297,24 @@ extern "C" int dpm_preprocess_scan(const float *xyz, int N, int stride, double v
     // status = [n_out, overflow]: two ints copied device-to-device so the caller reads them with its own sync
     hipError_t e = hipMemcpyAsync(status, &hdr->n_out, 2 * sizeof(int), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return (int)e;
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_lowpass_similarity(const float *normals, const int32_t *idx, int N, int K, int flux, float *sim,
+                                      dpm_stream_t stream) {
+    DPM_CHECK_ARG(normals && idx && sim && N >= 1 && K >= 1 && flux >= 1 && flux <= K);
+    if (flux > FLUX_MAX) return DPM_EUNSUPPORTED;
+    hipLaunchKernelGGL(lowpass_sim_kernel, dim3(dpm_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, normals, idx, N, K, flux,
+                       sim);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_stat_filter(const float *stat, int N, double k_std, int mode, double ratio, const float *xyz_in,
+                               const int32_t *idx_in, float *xyz_out, int32_t *idx_out, int32_t *n_out,
+                               dpm_stream_t stream) {
+    DPM_CHECK_ARG(stat && xyz_in && xyz_out && n_out && N >= 1 && (mode == 0 || mode == 1) && ratio != 0.0);
+    hipLaunchKernelGGL(stat_filter_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stat, N, (float)k_std, mode,
+                       (float)ratio, xyz_in,
+                       idx_in, xyz_out, idx_out, n_out);
     return dpm_launch_status();
 }

@@ -206,6 +206,31 @@ int dpm_preprocess_scan(const float *xyz, int N, int stride, double voxel_size, 
                         double ratio, long long max_cells, float *out_xyz, int32_t *out_idx, int out_capacity,
                         int32_t *status, void *workspace, dpm_stream_t stream);
 
+/* Building blocks of OutlierFilter / LowPassFilter (dataloader/transforms.py:230-289), which the reference runs
+ * through pytorch3d.knn_points and open3d.estimate_normals between DistanceSample and CoordinatesNormalization:
+ *
+ * dpm_knn_self: exact K nearest OTHER points of every point of one cloud xyz (N,3) (== knn_points(p, p, K+1)
+ *   with column 0 dropped; rows ordered by (distance, index); direct-form squared distances).  Any of idx (N,K),
+ *   dist2 (N,K), mean_dist (N) [mean over the K columns of sqrt(dist2), transforms.py:240-241] may be NULL.
+ *   `cell` = edge of the search grid in the units of xyz (a few times the typical neighbour spacing).
+ * dpm_point_normals: unit normal of every point = eigenvector of the smallest eigenvalue of the covariance of
+ *   the points within `radius` (itself included), (0,0,1) when fewer than 3 are in range (transforms.py:268-271).
+ * dpm_lowpass_similarity: sim[i] = sum of the `flux` largest |n_i . n_j| over the K neighbours idx[i,:]
+ *   (transforms.py:279-281).
+ * dpm_stat_filter: mean / unbiased std of stat (N); mode 0 keeps stat <= mean + k_std*std (OutlierFilter,
+ *   transforms.py:242-246), mode 1 keeps stat > mean - k_std*std (LowPassFilter, transforms.py:282); survivors
+ *   are compacted in order into xyz_out (coordinates divided by `ratio`: CoordinatesNormalization folded into the
+ *   last filter, 1.0 = untouched) / idx_out (idx_in NULL: positions), their number into n_out[0].
+ * workspace for the first two: dpm_knn_self_workspace_bytes(N). */
+size_t dpm_knn_self_workspace_bytes(int N);
+int dpm_knn_self(const float *xyz, int N, int K, double cell, int32_t *idx, float *dist2, float *mean_dist,
+                 void *workspace, dpm_stream_t stream);
+int dpm_point_normals(const float *xyz, int N, double radius, float *normals, void *workspace, dpm_stream_t stream);
+int dpm_lowpass_similarity(const float *normals, const int32_t *idx, int N, int K, int flux, float *sim,
+                           dpm_stream_t stream);
+int dpm_stat_filter(const float *stat, int N, double k_std, int mode, double ratio, const float *xyz_in,
+                    const int32_t *idx_in, float *xyz_out, int32_t *idx_out, int32_t *n_out, dpm_stream_t stream);
+
 /* ---------------------------------------------------------------- map tiles ------------- */
 
 /* PoseGraph.__global_mapping + centring of global_map_query_graph (system/modules/pose_graph.py:373-409,

@@ -518,3 +518,65 @@ def preprocess_scan(xyz: Tensor, voxel_size: float = 0.3, min_dis: float = 1.0, 
     d = torch.norm(q, p=2, dim=1)
     keep = (min_dis <= d) & (d <= max_dis)
     return q[keep] / ratio, torch.from_numpy(first)[keep]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# OutlierFilter / LowPassFilter (reference dataloader/transforms.py:230-289).  The reference computes them with
+# pytorch3d.knn_points (pinned 0.7.4) and open3d.estimate_normals (pinned 0.16.0), both absent here, so these
+# restatements follow the in-file arithmetic (transforms.py:236-246, 268-287) with scipy's exact cKDTree as the
+# neighbour search and numpy's symmetric eigensolver for the normals: PARITY UNPINNED by the reference itself.
+# ---------------------------------------------------------------------------------------------------------
+def knn_self(xyz: Tensor, K: int) -> Tuple[Tensor, Tensor]:
+    """xyz (N,3) f32 -> (idx (N,K) int64, dist2 (N,K) f32) of the K nearest OTHER points, rows ordered by
+    (fp32 direct-form squared distance, index)  == knn_points(p, p, K+1, return_sorted=True)[..., 1:]."""
+    from scipy.spatial import cKDTree
+    p = xyz.numpy().astype(np.float32)
+    n = p.shape[0]
+    kq = min(n, K + 1 + 4)  # a few extra candidates so that fp32 re-ranking near the K-th place is exact
+    _, cand = cKDTree(p.astype(np.float64)).query(p.astype(np.float64), k=kq)
+    d = p[:, None, :] - p[cand]                                 # fp32
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    order = np.lexsort((cand, d2), axis=1)[:, :K + 1]
+    idx = np.take_along_axis(cand, order, axis=1)
+    d2 = np.take_along_axis(d2, order, axis=1)
+    return torch.from_numpy(idx[:, 1:].astype(np.int64)), torch.from_numpy(d2[:, 1:].astype(np.float32))
+
+
+def outlier_filter(xyz: Tensor, nb_neighbors: int = 10, std_ratio: float = 3.0) -> Tensor:
+    """-> bool mask (N,) of the points OutlierFilter keeps (transforms.py:236-246)."""
+    _, d2 = knn_self(xyz, nb_neighbors)
+    points_dist = torch.sqrt(d2).mean(1)
+    outlier_dist = points_dist.mean() + std_ratio * points_dist.std()
+    return points_dist <= outlier_dist
+
+
+def point_normals(xyz: Tensor, radius: float) -> Tensor:
+    """open3d estimate_normals(KDTreeSearchParamRadius(radius)) restated: covariance of the points within the radius
+    (the point included) from fp64 cumulants, eigenvector of the smallest eigenvalue; < 3 points -> (0,0,1)."""
+    from scipy.spatial import cKDTree
+    p = xyz.numpy().astype(np.float64)
+    tree = cKDTree(p)
+    out = np.zeros((p.shape[0], 3), dtype=np.float32)
+    for i, nb in enumerate(tree.query_ball_point(p, r=radius)):
+        if len(nb) < 3:
+            out[i] = (0.0, 0.0, 1.0)
+            continue
+        q = p[nb]
+        m = q.mean(0)
+        cov = (q[:, :, None] * q[:, None, :]).mean(0) - m[:, None] * m[None, :]
+        w, v = np.linalg.eigh(cov)
+        out[i] = v[:, 0] / np.linalg.norm(v[:, 0])
+    return torch.from_numpy(out)
+
+
+def lowpass_filter(xyz: Tensor, normals_radius: float = 0.5, normals_num: int = 16, filter_std: float = 2.0,
+                   flux: int = 2, normals: Tensor = None) -> Tuple[Tensor, Tensor]:
+    """-> (bool mask (N,) of the points LowPassFilter keeps, sim (N,))   (transforms.py:268-287, max_remain = -1)."""
+    if normals is None:
+        normals = point_normals(xyz, normals_radius)
+    idx, _ = knn_self(xyz, normals_num)
+    grouped = normals[idx]                                           # (N, K, 3)
+    similarity = (grouped @ normals.unsqueeze(-1)).squeeze(-1).abs()
+    sim, _ = torch.topk(similarity, k=flux, dim=-1)
+    sim = sim.sum(1)
+    return sim > (sim.mean() - filter_std * sim.std()), sim
