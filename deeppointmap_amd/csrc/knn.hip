@@ -25,8 +25,8 @@
 // keep the smaller index (none occur on the shipped shapes).
 //
 // Two search strategies, same candidate logic:
-//  * BRUTE (N < 2048): one wave handles 4 centres and streams all points of the frame.
-//  * GRID  (N >= 2048): the frame's points are counting-sorted into a 2-D xy grid whose cell edge
+//  * BRUTE (N < 1024): one wave handles 4 centres and streams all points of the frame.
+//  * GRID  (N >= 1024): the frame's points are counting-sorted into a 2-D xy grid whose cell edge
 //    exceeds sqrt(r^2 + 2e-5) (the 2e-5 covers the rounding of the expanded form), so every
 //    admissible point lies in the 3x3 cells around the centre; cells of one grid row are contiguous
 //    in the sorted array, so a centre reads three short ranges.  65 536 x 4096 pair evaluations
@@ -42,7 +42,7 @@ constexpr int CAP = 512;  // candidate slots per centre
 constexpr int KMAX = 64;
 constexpr int TMPN = 128;  // scratch entries per wave (>= KMAX + 1 and >= 64)
 constexpr int GDIM = 128;  // grid cells per axis (upper bound)
-constexpr int GRID_MIN_N = 2048;
+constexpr int GRID_MIN_N = 1024;
 
 // LDS scratch is handed to the helpers below as address-space-3 pointers: through generic pointers every access
 // would compile to a FLAT instruction (the address-space check plus both wait counters) instead of ds_read/ds_write.

@@ -39,6 +39,7 @@ class HotPath:
         self.coor_scale, self.num_sample = float(coor_scale), num_sample
         self.geometry_levels = None  # FPS levels run by the geometry stage (None = all; measured best on MI355X)
         self.geometry_depth = 2      # batches whose geometry pass is in flight ahead of the feature stage
+        self.feature_streams = 1     # >1: consecutive batches' feature stages alternate between side streams
         self._side = None      # side HIP streams for the software pipeline (submit / flush)
         self._pending = None
 
@@ -102,8 +103,10 @@ class HotPath:
         main = torch.cuda.current_stream(dev)
         if self._side is None:
             self._side = dict(geo=[torch.cuda.Stream(device=dev) for _ in range(max(1, self.geometry_depth))],
-                              reg=torch.cuda.Stream(device=dev))
-            self._pending = dict(geo=[], reg=None, n=0)
+                              reg=torch.cuda.Stream(device=dev),
+                              feat=[torch.cuda.Stream(device=dev) for _ in range(self.feature_streams)]
+                              if self.feature_streams > 1 else [])
+            self._pending = dict(geo=[], reg=None, n=0, nf=0)
         sa = self._side["geo"][self._pending["n"] % len(self._side["geo"])]
         self._pending["n"] += 1
         with torch.cuda.stream(sa):
@@ -123,9 +126,19 @@ class HotPath:
         main = torch.cuda.current_stream(dev)
         sb = self._side["reg"]
         pre, ready, points, padding, pcd_m = geo
-        main.wait_event(ready)
-        desc = self.extract(points, padding, presampled=pre)
-        desc_ready = main.record_event()
+        if self._side["feat"]:
+            sf = self._side["feat"][self._pending["nf"] % len(self._side["feat"])]
+            self._pending["nf"] += 1
+            with torch.cuda.stream(sf):
+                sf.wait_event(ready)
+                for t in pre.values():
+                    t.record_stream(sf)
+                desc = self.extract(points, padding, presampled=pre)
+                desc_ready = sf.record_event()
+        else:
+            main.wait_event(ready)
+            desc = self.extract(points, padding, presampled=pre)
+            desc_ready = main.record_event()
         desc.record_stream(sb)
         reg, self._pending["reg"] = self._pending["reg"], (desc, desc_ready, pcd_m)
         return self._register_on_b(reg) if reg is not None else None
