@@ -154,6 +154,24 @@ def main():
     import deeppointmap_amd.encoder as enc_mod
     enc_mod.ops.fps = timed_fps
 
+    # ... and around the widest dense contraction of the path (the decoder's 256 -> 768 attention projections over
+    # all tokens of the batch), the MFMA-bound representative reported as `roofline_mfma`
+    gemm_events, gemm_flops = [], [0]
+    orig_linear = ops.linear
+
+    def timed_linear(x, W, *a, **k):
+        if W.shape[0] != 768 or x.shape[0] < 8192:
+            return orig_linear(x, W, *a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_linear(x, W, *a, **k)
+        e1.record()
+        gemm_events.append((e0, e1))
+        gemm_flops[0] = 2 * x.shape[0] * W.shape[0] * W.shape[1]
+        return out
+
+    ops.linear = timed_linear
+
     def step():
         # Streaming mode (HotPath.submit): this batch's input staging + first-level FPS start on a side HIP
         # stream and overlap with the previous batch's remaining stages on the main stream.  Edges stay on the
@@ -180,6 +198,7 @@ def main():
         step()
     drain()
     fps_events.clear()
+    gemm_events.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -192,6 +211,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     fps_ms = sum(a.elapsed_time(b) for a, b in fps_events) / max(len(fps_events), 1)
+    gemm_ms = sum(a.elapsed_time(b) for a, b in gemm_events) / max(len(gemm_events), 1)
 
     if args.stages and rank == 0:
         def tm(fn, n=3):
@@ -234,6 +254,15 @@ def main():
                                  "bound by construction (us_per_round is the figure that matters); traffic > algorithmic "
                                  "bytes because each round re-reads the ~12 buckets the new point can change; see DESIGN.md"},
         }
+        if gemm_ms > 0:
+            tf = gemm_flops[0] / (gemm_ms * 1e-3) / 1e12
+            line["roofline_mfma"] = {
+                "kernel": "gemm_nt_mfma_kernel<64,64> on the decoder's 256->768 attention projections "
+                          f"({gemm_flops[0] // (2 * 768 * 256)} token rows per launch)",
+                "bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                "avg_launch_ms": round(gemm_ms, 4), "flops_per_launch": gemm_flops[0],
+                "note": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak); timed with HIP events on its "
+                        "launch stream while the other pipeline stages share the chip"}
         if world == 1 and args.cpu_frames > 0:
             # torch's intra-op pool stops scaling (and then collapses) well below the box's core count on
             # these small ops: 16 threads measured fastest on the 256-core GPU host (8: 0.83, 16: 0.63,
