@@ -116,21 +116,41 @@ class Decoder(ParamTree):
                                                     residual=y2), post=None if last else pd)
         return xp, xyz_s, yp, xyz_d, B, M, N
 
-    def _attention_layers_joint(self, ts, td, B, M):
+    def _attention_layers_joint(self, ts, td, B, M, frames=None):
         """Same arithmetic as the two-sided loop above for M == N, with the source and target tokens stacked into one
         (2*B*M)-row matrix: the layers share their weights between the two sides (descriptor_attention.py:31-48), so
         every projection / LayerNorm / MLP is ONE launch over all rows, self attention is one launch over 2B
         sequences, and only cross attention needs one launch per direction (queries of one half, keys/values of the
-        other).  Row-wise kernels give bit-identical rows whatever the row count, so the results equal the split path."""
+        other).  Row-wise kernels give bit-identical rows whatever the row count, so the results equal the split path.
+
+        frames = (tu (U*M,131), sidx, didx): the pairs are (frame sidx[p], frame didx[p]) of U distinct frames.
+        Everything up to and including the FIRST self-attention block depends on a frame alone, so it runs once per
+        frame (consecutive-frame odometry uses every frame twice) and its rows are then gathered per pair."""
         C, E, R = self.in_channel, self.model_channel, B * M
-        dev = ts.device
-        z_in = torch.cat([ts, td], dim=0)                       # (2R, 131): [src tokens ; dst tokens]
-        pos = ops.posemb(z_in[:, C:C + 3], self._dimt(dev), E)
-        zp = ops.linear(z_in[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=pos)
+        dev = self.device
+        if frames is not None:
+            tu, sidx, didx = frames
+            U = tu.shape[0] // M
+            pos_u = ops.posemb(tu[:, C:C + 3], self._dimt(dev), E)
+            zu = ops.linear(tu[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=pos_u)
+            pre = "descriptor_attention.0"
+            z1u = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", zu, U, M), post=pos_u)
+            order = torch.cat([sidx, didx]).long()
+            pos = pos_u.view(U, M * E).index_select(0, order).view(2 * R, E)
+            z1_first = z1u.view(U, M * E).index_select(0, order).view(2 * R, E)
+            zp = None
+        else:
+            z_in = torch.cat([ts, td], dim=0)                       # (2R, 131): [src tokens ; dst tokens]
+            pos = ops.posemb(z_in[:, C:C + 3], self._dimt(dev), E)
+            zp = ops.linear(z_in[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=pos)
+            z1_first = None
         for l in range(self.attention_layers):
             pre = f"descriptor_attention.{l}"
             last = l == self.attention_layers - 1
-            z1 = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", zp, 2 * B, M), post=pos)
+            if l == 0 and z1_first is not None:
+                z1 = z1_first
+            else:
+                z1 = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", zp, 2 * B, M), post=pos)
             ca = pre + ".cross_attn"
             qkv = ops.linear(z1, self.p(ca + ".in_proj_weight"), self.p(ca + ".in_proj_bias"))  # q | k | v of every token
             a = torch.empty(2 * R, E, device=dev, dtype=torch.float32)
@@ -159,10 +179,20 @@ class Decoder(ParamTree):
             raise ValueError(f"Argument `num_sample` with value {num_sample} is not supported")
         return k // 2
 
-    def _register(self, src_descriptor, dst_descriptor, num_sample, header_out=None, trace: dict = None):
+    def _register(self, src_descriptor, dst_descriptor, num_sample, header_out=None, trace: dict = None, pairs=None):
         """Batched core: (B,131,M), (B,131,N) -> result (B, 20+2k) on the device, nothing synchronises.
         Pairs are independent, so every kernel runs all B of them at once."""
-        x, xyz_s, y, xyz_d, B, M, N = self._descriptor_attention_forward(src_descriptor, dst_descriptor)
+        if pairs is not None:   # src_descriptor holds the U distinct frames, pairs = (sidx, didx) int32 on the device
+            dev = self.device
+            sidx, didx = pairs
+            tu, U, M = self._stage(src_descriptor, dev)
+            N, B, C = M, sidx.numel(), self.in_channel
+            x, y = self._attention_layers_joint(None, None, B, M, frames=(tu, sidx, didx))
+            xyz_u = tu.view(U, M, C + 3)[:, :, C:C + 3]
+            xyz_s = xyz_u.index_select(0, sidx.long()).reshape(B * M, 3)
+            xyz_d = xyz_u.index_select(0, didx.long()).reshape(B * M, 3)
+        else:
+            x, xyz_s, y, xyz_d, B, M, N = self._descriptor_attention_forward(src_descriptor, dst_descriptor)
         E = self.model_channel
         k = self._num_pairs(num_sample, M, N)
         # similarity head -> L2 normalise -> M x N similarity -> dual softmax -> top-k   (decoder.py:181-191)
@@ -192,6 +222,19 @@ class Decoder(ParamTree):
             raise RuntimeError("deeppointmap_amd.Decoder runs on the GPU only (there is no CPU fallback)")
         with torch.cuda.device(dev):
             return self._register(src_descriptor, dst_descriptor, num_sample, header_out)
+
+    @torch.no_grad()
+    def registration_forward_pairs(self, descriptors: torch.Tensor, src_frame: torch.Tensor, dst_frame: torch.Tensor,
+                                   num_sample: Union[int, float] = 0.5, header_out: torch.Tensor = None) -> torch.Tensor:
+        """Like registration_forward_batch for pairs drawn from ONE set of frames: descriptors (F,131,M), pair p =
+        (src_frame[p], dst_frame[p]) (int32 device tensors).  The per-frame part of the decoder (projection, position
+        embedding, first self-attention block) runs once per frame instead of once per pair side; results are
+        bit-identical to registration_forward_batch(descriptors[src_frame], descriptors[dst_frame])."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("deeppointmap_amd.Decoder runs on the GPU only (there is no CPU fallback)")
+        with torch.cuda.device(dev):
+            return self._register(descriptors, None, num_sample, header_out, pairs=(src_frame, dst_frame))
 
     @torch.no_grad()
     def registration_forward(self, src_descriptor: torch.Tensor, dst_descriptor: torch.Tensor,

@@ -63,8 +63,8 @@ class HotPath:
             table = torch.zeros(len(pairs), EDGE_FLOATS, device=dev, dtype=torch.float32)
         sidx = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev)
         didx = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev)
-        res = self.decoder.registration_forward_batch(desc.index_select(0, sidx.long()), desc.index_select(0, didx.long()),
-                                                      num_sample=self.num_sample, header_out=table[:, :ops.RES_HDR])
+        res = self.decoder.registration_forward_pairs(desc, sidx, didx, num_sample=self.num_sample,
+                                                      header_out=table[:, :ops.RES_HDR])
         if pcd_m is not None:
             ops.information_matrix_batched(pcd_m, sidx, didx, table[:, :12], table[:, ops.RES_HDR:])
         edges = []

@@ -178,6 +178,23 @@ def test_batched_registration_equals_per_pair_calls(dec):
         assert torch.equal(table[b, :20], res[b, :20])
 
 
+def test_pairs_entry_equals_batched_entry(dec):
+    """registration_forward_pairs shares the per-frame decoder prefix between the pairs a frame takes part in; rows
+    are computed by row-wise kernels, so the result must equal the gathered-batch entry point bit for bit."""
+    g = load_golden("decoder.npz")
+    frames = torch.stack([T(g["synthetic01.src_desc"]), T(g["synthetic01.dst_desc"]), T(g["kitti01.src_desc"]),
+                          T(g["kitti01.dst_desc"])]).to(DEV)
+    src = torch.tensor([0, 1, 2, 3, 0], dtype=torch.int32, device=DEV)
+    dst = torch.tensor([1, 2, 3, 0, 2], dtype=torch.int32, device=DEV)
+    t1, t2 = torch.zeros(5, 56, device=DEV), torch.zeros(5, 56, device=DEV)
+    r1 = dec.registration_forward_pairs(frames, src, dst, 0.5, header_out=t1[:, :20])
+    r2 = dec.registration_forward_batch(frames[src.long()], frames[dst.long()], 0.5, header_out=t2[:, :20])
+    assert torch.equal(t1, t2) and torch.equal(r1[:, :20], r2[:, :20])
+    for b in range(5):  # entries past the inlier count are unspecified
+        n_in = int(r1[b, 14])
+        assert n_in > 0 and torch.equal(r1[b, 20:20 + n_in], r2[b, 20:20 + n_in])
+
+
 def test_batched_information_matrix_equals_single(ops):
     """3 pairs (plain block mapping) and 8 pairs (XCD-aware mapping, one of them with the source pushed half
     out of the target's bounding box) against the single-pair entry point."""
