@@ -414,6 +414,175 @@ int launch_wave(const float *xyz, const float *fea, const float *centers, const 
 
 }  // namespace
 
+namespace {
+
+// ---- "project before gather" (the default path of the encoder) ---------------------------------------------
+// The layer is linear before its LayerNorm:  W [fea_n ; rel] + b  =  (W_f fea_n + b) + W_r rel.  The first term
+// depends on the neighbour point alone, so it is computed ONCE PER POINT by a dense GEMM (P = fea W_f^T + b,
+// dpm_linear with ldw = Cin+3) instead of once per (centre, neighbour) pair -- K times fewer multiply-adds -- and
+// the per-pair work left is: gather the Cout-vector P[n], add the three relative-coordinate terms as an fma chain
+// (same k order as the full dot product), two-pass LayerNorm, ReLU, max over the K neighbours.  For the first
+// stage P itself is affine in the point (P = A xyz + c, A = W_f W0, c = W_f b0 + b) and is evaluated on the fly,
+// so neither the level-0 features nor their projection ever exist in memory.
+// One wave per centre; G = Cout/(4V) lanes share a row (float4 per lane, V float4 for Cout = 512), 64/G rows per
+// wave pass, LayerNorm sums are DPP / shuffle reductions inside the lane group.
+template <int G>
+__device__ __forceinline__ float lane_group_sum(float v) {
+    if (G >= 2) v += __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v)));   // quad_perm [1,0,3,2]
+    if (G >= 4) v += __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v)));   // quad_perm [2,3,0,1]
+    if (G >= 8) v += __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v)));  // row_half_mirror
+    if (G >= 16) v += __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v)));  // row_mirror
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int COUT, int V, bool AFFINE>
+__global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
+    const float *__restrict__ P_all, const float *__restrict__ A, const float *__restrict__ cvec,
+    const float *__restrict__ xyz_all, const float *__restrict__ ctr_all, const int32_t *__restrict__ idx_all,
+    const float *__restrict__ Wr, int ldwr, const float *__restrict__ gamma, const float *__restrict__ beta, int N,
+    int S, int K, long long total, int cpw, float inv_r, float *__restrict__ out_all) {
+    constexpr int G = COUT / (4 * V), RPW = 64 / G;  // lanes per row, rows per wave pass
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gl = lane % G, gr = lane / G;
+    // per-lane constants for its 4*V channels: relative-coordinate weights, LayerNorm affine, (AFFINE) the point map
+    float wr[V][4][3], gm[V][4], bt[V][4], am[AFFINE ? V : 1][4][3], cv[AFFINE ? V : 1][4];
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (gl + G * v) + e;
+            gm[v][e] = gamma[c], bt[v][e] = beta[c];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) wr[v][e][d] = Wr[(size_t)c * ldwr + d];
+            if (AFFINE) {
+                cv[v][e] = cvec[c];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) am[v][e][d] = A[3 * c + d];
+            }
+        }
+    const int first = (int)((xcd_chunked_id(blockIdx.x, gridDim.x) * 4 + w) * (unsigned)cpw);
+    const int last = (int)min((long long)first + cpw, total);
+    for (int cc = first; cc < last; ++cc) {
+        const int b = cc / S;
+        const float *xyz = xyz_all + (size_t)b * N * 3;
+        const float *P = AFFINE ? nullptr : P_all + (size_t)b * N * COUT;
+        const float cx = ctr_all[(size_t)cc * 3], cy = ctr_all[(size_t)cc * 3 + 1], cz = ctr_all[(size_t)cc * 3 + 2];
+        float mx[V][4];
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx[v][e] = 0.f;  // ReLU floor
+#pragma unroll 4
+        for (int r0 = 0; r0 < K; r0 += RPW) {
+            const int r = min(r0 + gr, K - 1);  // K is a multiple of RPW on every shipped layer; clamped rows repeat
+            const int n = min(max(idx_all[(size_t)cc * K + r], 0), N - 1);
+            const float px = xyz[(size_t)n * 3], py = xyz[(size_t)n * 3 + 1], pz = xyz[(size_t)n * 3 + 2];
+            const float rx = (px - cx) * inv_r, ry = (py - cy) * inv_r, rz = (pz - cz) * inv_r;
+            float y[V][4], sum = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                float4 p4;
+                if (AFFINE) {
+                    p4.x = fmaf(am[v][0][2], pz, fmaf(am[v][0][1], py, fmaf(am[v][0][0], px, cv[v][0])));
+                    p4.y = fmaf(am[v][1][2], pz, fmaf(am[v][1][1], py, fmaf(am[v][1][0], px, cv[v][1])));
+                    p4.z = fmaf(am[v][2][2], pz, fmaf(am[v][2][1], py, fmaf(am[v][2][0], px, cv[v][2])));
+                    p4.w = fmaf(am[v][3][2], pz, fmaf(am[v][3][1], py, fmaf(am[v][3][0], px, cv[v][3])));
+                } else {
+                    p4 = *reinterpret_cast<const float4 *>(P + (size_t)n * COUT + 4 * (gl + G * v));
+                }
+                y[v][0] = fmaf(wr[v][0][2], rz, fmaf(wr[v][0][1], ry, fmaf(wr[v][0][0], rx, p4.x)));
+                y[v][1] = fmaf(wr[v][1][2], rz, fmaf(wr[v][1][1], ry, fmaf(wr[v][1][0], rx, p4.y)));
+                y[v][2] = fmaf(wr[v][2][2], rz, fmaf(wr[v][2][1], ry, fmaf(wr[v][2][0], rx, p4.z)));
+                y[v][3] = fmaf(wr[v][3][2], rz, fmaf(wr[v][3][1], ry, fmaf(wr[v][3][0], rx, p4.w)));
+                sum += (y[v][0] + y[v][1]) + (y[v][2] + y[v][3]);
+            }
+            const float mean = lane_group_sum<G>(sum) * (1.0f / (float)COUT);
+            float sq = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[v][e] -= mean;
+                    sq = fmaf(y[v][e], y[v][e], sq);
+                }
+            const float rs = rsqrtf(lane_group_sum<G>(sq) * (1.0f / (float)COUT) + 1e-5f);
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mx[v][e] = fmaxf(mx[v][e], fmaf(y[v][e] * rs, gm[v][e], bt[v][e]));
+        }
+        // max over the row groups of the wave (lanes with equal gl), then the first group stores
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float m = mx[v][e];
+#pragma unroll
+                for (int off = G; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                mx[v][e] = m;
+            }
+        if (gr == 0) {
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                *reinterpret_cast<float4 *>(out_all + (size_t)cc * COUT + 4 * (gl + G * v)) =
+                    make_float4(mx[v][0], mx[v][1], mx[v][2], mx[v][3]);
+        }
+    }
+}
+
+template <int COUT, int V, bool AFFINE>
+int launch_gather(const float *P, const float *A, const float *cvec, const float *xyz, const float *centers,
+                  const int32_t *idx, const float *Wr, int ldwr, const float *gamma, const float *beta, int B, int N,
+                  int S, int K, float inv_r, float *out, hipStream_t st) {
+    const long long total = (long long)B * S;
+    if (total >= (1LL << 30)) return DPM_EUNSUPPORTED;
+    const int cpw = total >= (1 << 16) ? 8 : (total >= (1 << 13) ? 2 : 1);  // centres per wave
+    hipLaunchKernelGGL((group_gather_ln_max_kernel<COUT, V, AFFINE>), dim3(dpm_cdiv(total, 4LL * cpw)), dim3(256), 0, st, P,
+                       A, cvec, xyz, centers, idx, Wr, ldwr, gamma, beta, N, S, K, total, cpw, inv_r, out);
+    return dpm_launch_status();
+}
+
+}  // namespace
+
+extern "C" int dpm_group_gather_ln_max(const float *P, const float *xyz, const float *centers, const int32_t *idx,
+                                       const float *W_rel, int ldw_rel, const float *gamma, const float *beta, int B,
+                                       int N, int S, int K, int Cout, double radius, float *out, dpm_stream_t stream) {
+    DPM_CHECK_ARG(P && xyz && centers && idx && W_rel && gamma && beta && out);
+    DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && ldw_rel >= 3 && radius > 0.0);
+    DPM_CHECK_ARG(((uintptr_t)P & 15) == 0 && ((uintptr_t)out & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_r = 1.0f / (float)radius;
+#define DPM_GG(C, V) return launch_gather<C, V, false>(P, nullptr, nullptr, xyz, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, inv_r, out, st)
+    switch (Cout) {
+        case 32: DPM_GG(32, 1);
+        case 64: DPM_GG(64, 1);
+        case 128: DPM_GG(128, 1);
+        case 256: DPM_GG(256, 1);
+        case 512: DPM_GG(512, 2);
+        default: return DPM_EUNSUPPORTED;
+    }
+#undef DPM_GG
+}
+
+extern "C" int dpm_group_affine_ln_max(const float *A, const float *cvec, const float *xyz, const float *centers,
+                                       const int32_t *idx, const float *W_rel, int ldw_rel, const float *gamma,
+                                       const float *beta, int B, int N, int S, int K, int Cout, double radius,
+                                       float *out, dpm_stream_t stream) {
+    DPM_CHECK_ARG(A && cvec && xyz && centers && idx && W_rel && gamma && beta && out);
+    DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && ldw_rel >= 3 && radius > 0.0 && ((uintptr_t)out & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_r = 1.0f / (float)radius;
+#define DPM_GA(C, V) return launch_gather<C, V, true>(nullptr, A, cvec, xyz, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, inv_r, out, st)
+    switch (Cout) {
+        case 32: DPM_GA(32, 1);
+        case 64: DPM_GA(64, 1);
+        case 128: DPM_GA(128, 1);
+        default: return DPM_EUNSUPPORTED;
+    }
+#undef DPM_GA
+}
+
 // defined in encoder_ops.hip: generic VALU kernel for shapes the MFMA kernel does not cover
 extern "C" int dpm_group_mlp_max_generic(const float *xyz, const float *fea, const float *centers, const int32_t *idx,
                                          const float *W, const float *bias, const float *gamma, const float *beta,

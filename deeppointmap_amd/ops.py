@@ -105,9 +105,15 @@ def ball_query(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tenso
     return idx
 
 
-def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, generic: bool = False) -> torch.Tensor:
+PROJECTED_COUT = (32, 64, 128, 256, 512)
+
+
+def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, generic: bool = False,
+                  fused: bool = False) -> torch.Tensor:
     """xyz (B,N,3), fea (B,N,Cin), centers (B,S,3), idx (B,S,K), W (Cout,Cin+3[,1,1]) -> (B,S,Cout).
-    generic=True forces the plain-VALU kernel (cross-check path)."""
+    Default: project before gather (P = fea W_f^T + b once per point with the MFMA GEMM, then gather + relative
+    coordinates + LayerNorm + max).  fused=True: the one-kernel gather-GEMM path; generic=True: the plain-VALU
+    kernel (cross-check paths, and the fallback for layer widths the projected path does not cover)."""
     for n, t in (("xyz", xyz), ("fea", fea), ("centers", centers), ("W", W), ("bias", bias),
                  ("gamma", gamma), ("beta", beta)):
         _chk(t, torch.float32, n)
@@ -119,16 +125,28 @@ def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, g
         raise ValueError(f"W must be (Cout, Cin+3) = ({Cout}, {Cin + 3}), got {tuple(W.shape)}")
     out = torch.empty(B, S, Cout, device=fea.device, dtype=torch.float32)
     lib = _lib.load()
+    if not generic and not fused and Cout in PROJECTED_COUT:
+        W2 = W.reshape(Cout, Cin + 3)
+        # a packed copy of the feature columns (rows of the Conv2d weight are Cin+3 floats: not 16-byte aligned)
+        P = linear(fea.reshape(B * N, Cin), W2[:, :Cin].contiguous(), bias)
+        _lib.check(lib.dpm_group_gather_ln_max(_ptr(P), _ptr(xyz), _ptr(centers), _ptr(idx), W2.data_ptr() + 4 * Cin,
+                                               Cin + 3, _ptr(gamma), _ptr(beta), B, N, S, K, Cout, float(radius),
+                                               _ptr(out), _stream(fea)), "dpm_group_gather_ln_max")
+        return out
     fn = lib.dpm_group_mlp_max_generic if generic else lib.dpm_group_mlp_max
     _lib.check(fn(_ptr(xyz), _ptr(fea), _ptr(centers), _ptr(idx), _ptr(W), _ptr(bias), _ptr(gamma), _ptr(beta),
                   B, N, S, K, Cin, Cout, float(radius), _ptr(out), _stream(fea)), "dpm_group_mlp_max")
     return out
 
 
-def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radius: float) -> torch.Tensor:
+def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radius: float,
+                           fused: bool = False) -> torch.Tensor:
     """First-stage SetAbstraction with the per-point input MLP (W0 (Cin,3[,1]), b0 (Cin)) folded into the gather:
     xyz (B,N,3), centers (B,S,3), idx (B,S,K), W (Cout,Cin+3[,1,1]) -> (B,S,Cout).  Raises ValueError for
-    shapes the fused kernel does not cover (callers fall back to linear + group_mlp_max)."""
+    shapes the kernels do not cover (callers fall back to linear + group_mlp_max).
+    Default: the projected point feature is affine in the point, P = (W_f W0) xyz + (W_f b0 + b); the two small
+    weight products are made with the GEMM and the kernel evaluates P on the fly.  fused=True: the gather-GEMM kernel
+    that evaluates the 16 input features per neighbour."""
     for n, t in (("xyz", xyz), ("W0", W0), ("b0", b0), ("centers", centers), ("W", W), ("bias", bias),
                  ("gamma", gamma), ("beta", beta)):
         _chk(t, torch.float32, n)
@@ -139,6 +157,15 @@ def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radi
     if W0.shape[1] != 3 or W.shape[1] != Cin + 3:
         raise ValueError("W0 must be (Cin,3) and W (Cout,Cin+3)")
     out = torch.empty(B, S, Cout, device=xyz.device, dtype=torch.float32)
+    if not fused and Cout in (32, 64, 128):
+        W2 = W.reshape(Cout, Cin + 3)
+        A = linear(W2[:, :Cin], W0.reshape(Cin, 3).t().contiguous())                       # (Cout,3) = W_f W0
+        cvec = linear(W2[:, :Cin], b0.reshape(1, Cin), residual=bias.reshape(Cout, 1))    # (Cout,1) = W_f b0 + b
+        _lib.check(_lib.load().dpm_group_affine_ln_max(_ptr(A), _ptr(cvec), _ptr(xyz), _ptr(centers), _ptr(idx),
+                                                       W2.data_ptr() + 4 * Cin, Cin + 3, _ptr(gamma), _ptr(beta), B, N, S,
+                                                       K, Cout, float(radius), _ptr(out), _stream(xyz)),
+                   "dpm_group_affine_ln_max")
+        return out
     _lib.check(_lib.load().dpm_group_mlp_max_from_xyz(_ptr(xyz), _ptr(W0), _ptr(b0), _ptr(centers), _ptr(idx), _ptr(W),
                                                       _ptr(bias), _ptr(gamma), _ptr(beta), B, N, S, K, Cin, Cout,
                                                       float(radius), _ptr(out), _stream(xyz)),
@@ -151,8 +178,14 @@ def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     """x (..., Cin) (last dim contiguous rows), W (Cout, Cin[,1[,1]]) -> (..., Cout).
 
     `out` may be a column slice of a wider row-major buffer (its row stride is honoured)."""
-    _chk(W, torch.float32, "W")
+    if W.dtype != torch.float32 or not W.is_cuda:
+        raise ValueError("W must be an fp32 GPU tensor")
     Cout, Cin = W.shape[0], W.shape[1]
+    if W.dim() == 2 and W.stride(1) == 1 and W.stride(0) >= Cin:
+        ldw = W.stride(0)      # a column range of a wider weight matrix (e.g. the feature columns of a Conv2d weight)
+    else:
+        _chk(W, torch.float32, "W")
+        ldw = Cin
     if x.dtype != torch.float32 or not x.is_cuda or x.stride(-1) != 1:
         raise ValueError("x must be an fp32 GPU tensor with unit stride in the last dimension")
     x2 = x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x
@@ -168,7 +201,7 @@ def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     if residual is not None:
         r2 = residual.reshape(-1, Cout)
         _chk(r2, torch.float32, "residual")
-    _lib.check(_lib.load().dpm_linear(_ptr(x2), x2.stride(0), _ptr(W), Cin, _ptr(bias), _ptr(r2),
+    _lib.check(_lib.load().dpm_linear(_ptr(x2), x2.stride(0), _ptr(W), ldw, _ptr(bias), _ptr(r2),
                                       Cout if r2 is not None else 0, _ptr(o2), o2.stride(0), R, Cin, Cout, act,
                                       _stream(x)), "dpm_linear")
     return out

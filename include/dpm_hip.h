@@ -111,6 +111,21 @@ int dpm_group_mlp_max_from_xyz(const float *xyz, const float *W0, const float *b
                                const float *beta, int B, int N, int S, int K, int Cin, int Cout,
                                double radius, float *out, dpm_stream_t stream);
 
+/* The same layer with the projection hoisted out of the gather ("project before gather", the encoder's default):
+ * W [fea_n ; rel] + b = (W_f fea_n + b) + W_r rel, so P = fea W_f^T + b (B,N,Cout) is computed once per POINT with
+ * dpm_linear (x = fea, W = the first Cin columns, ldw = Cin+3) and this kernel does the per-(centre, neighbour) rest:
+ * out[b,s,:] = max_k relu(LN(P[idx[b,s,k]] + W_rel (xyz[idx]-center)/radius)).  W_rel points at column Cin of the
+ * Conv2d weight, ldw_rel = Cin+3.  Cout in {32,64,128,256,512}; P and out 16-byte aligned.
+ * dpm_group_affine_ln_max: first-stage variant, P is affine in the point itself (P = A xyz + c with A (Cout,3) =
+ * W_f W0 and c (Cout) = W_f b0 + b, both produced with dpm_linear) and is evaluated on the fly; Cout in {32,64,128}. */
+int dpm_group_gather_ln_max(const float *P, const float *xyz, const float *centers, const int32_t *idx,
+                            const float *W_rel, int ldw_rel, const float *gamma, const float *beta, int B, int N,
+                            int S, int K, int Cout, double radius, float *out, dpm_stream_t stream);
+int dpm_group_affine_ln_max(const float *A, const float *cvec, const float *xyz, const float *centers,
+                            const int32_t *idx, const float *W_rel, int ldw_rel, const float *gamma,
+                            const float *beta, int B, int N, int S, int K, int Cout, double radius, float *out,
+                            dpm_stream_t stream);
+
 /* 1x1 Conv1d / nn.Linear (build_mlp, network/encoder/utils.py:358-389; decoder heads):
  * out[r, :Cout] = act(x[r,:Cin] W^T + bias + residual[r]); W (Cout,Cin) row-major with leading
  * dimension ldw; x/out/residual have leading dimensions ldx/ldo/ldr (rows R). bias, residual

@@ -229,10 +229,11 @@ def test_group_mlp_max_vs_oracle(ops):
               "m.0.bias": torch.randn(Cout, generator=gen) * 0.1,
               "m.1.ln.weight": 1 + 0.1 * torch.randn(Cout, generator=gen), "m.1.ln.bias": 0.1 * torch.randn(Cout, generator=gen)}
         want = O.grouped_mlp_max(sd, "m", 0.3, xyz, fea, ctr, idx)
-        for generic in (False, True):
+        # the three implementations: project-before-gather (default), one-kernel gather-GEMM, plain VALU
+        for kw in ({}, {"fused": True}, {"generic": True}):
             got = ops.group_mlp_max(xyz.to(DEV), fea.to(DEV), ctr.to(DEV), idx.int().to(DEV), sd["m.0.weight"].to(DEV),
                                     sd["m.0.bias"].to(DEV), sd["m.1.ln.weight"].to(DEV), sd["m.1.ln.bias"].to(DEV), 0.3,
-                                    generic=generic).cpu()
+                                    **kw).cpu()
             torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
 
 
@@ -248,8 +249,9 @@ def test_group_mlp_from_xyz_equals_materialised_features(ops):
     d = lambda t: t.to(DEV)
     fea = ops.linear(d(xyz), d(W0), d(b0))
     want = ops.group_mlp_max(d(xyz), fea, d(ctr), d(idx), d(W), d(bias), d(gm), d(bt), 0.3)
-    got = ops.group_mlp_max_from_xyz(d(xyz), d(W0), d(b0), d(ctr), d(idx), d(W), d(bias), d(gm), d(bt), 0.3)
-    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    for kw in ({}, {"fused": True}):  # affine-on-the-fly (default) and the per-neighbour feature evaluation
+        got = ops.group_mlp_max_from_xyz(d(xyz), d(W0), d(b0), d(ctr), d(idx), d(W), d(bias), d(gm), d(bt), 0.3, **kw)
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
 def test_prepare_and_channel_first(ops):
