@@ -58,8 +58,8 @@ int dpm_to_channel_first(const float *x, int B, int R, int C, float *out, dpm_st
 size_t dpm_fps_workspace_bytes(int B, int N, int K);
 int dpm_fps(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
             float *new_xyz, int32_t *new_lengths, void *workspace, dpm_stream_t stream);
-/* same, with the algorithm forced: 0 = auto, 1 = register/brute force, 2 = bucket-pruned
- * (both give identical bits; tests run both). */
+/* same, with the algorithm forced: 0 = auto, 1 = register/brute force, 2 = bucket-pruned, 3 = bucket-pruned with
+ * speculative two-picks-per-round (experimental; all give identical bits; tests run all). */
 int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
                float *new_xyz, int32_t *new_lengths, void *workspace, int algo, dpm_stream_t stream);
 

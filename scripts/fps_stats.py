@@ -13,11 +13,12 @@ lens = torch.full((B,), N, dtype=torch.int32, device='cuda')
 idx = torch.empty(B, K, dtype=torch.int32, device='cuda'); new = torch.empty(B, K, 3, device='cuda'); nl = torch.empty(B, dtype=torch.int32, device='cuda')
 ws = torch.zeros(lib.dpm_fps_workspace_bytes(B, N, K), dtype=torch.uint8, device='cuda')
 P = ctypes.c_void_p
+ALGO = int(os.environ.get('ALGO', '2'))
 for rep in range(2):
-    torch.cuda.synchronize()
+    ws.zero_(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    rc = lib.dpm_fps_ex(P(pts.data_ptr()), P(lens.data_ptr()), B, N, K, P(idx.data_ptr()), P(new.data_ptr()), P(nl.data_ptr()), P(ws.data_ptr()), 2, P(torch.cuda.current_stream().cuda_stream))
+    rc = lib.dpm_fps_ex(P(pts.data_ptr()), P(lens.data_ptr()), B, N, K, P(idx.data_ptr()), P(new.data_ptr()), P(nl.data_ptr()), P(ws.data_ptr()), ALGO, P(torch.cuda.current_stream().cuda_stream))
     e1.record(); torch.cuda.synchronize()
     base = (ws.data_ptr() + 255) & ~255
     off = base - ws.data_ptr()

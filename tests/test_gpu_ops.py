@@ -44,7 +44,7 @@ def knn_rows_ok(idx_gpu, points, centers, radius, tol=4e-6):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 def test_fps_bit_exact_vs_reference_fixtures(ops, algo):
     g = load_golden("fps.npz")
     names = sorted({k.rsplit(".", 1)[0] for k in g if k.endswith(".points")})
@@ -56,7 +56,7 @@ def test_fps_bit_exact_vs_reference_fixtures(ops, algo):
         assert int(nl[0]) == min(length, K)
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3])
 def test_fps_full_size_synthetic_bit_exact(ops, algo):
     g = load_golden("fps.npz")
     pts = synthetic.frame(0).t().contiguous()
@@ -72,13 +72,35 @@ def test_fps_batched_ragged_and_ties(ops):
     pts = torch.rand(B, N, 3, generator=gen)
     pts[1] = torch.round(pts[1] * 8) / 8  # heavy ties: first-index rule must hold
     lens = [20000, 20000, 17001, 300, 1]
-    for algo in (1, 2):
+    for algo in (1, 2, 3):
         idx, new, nl = ops.fps(pts.to(DEV), _lengths(lens), K, algo=algo)
         for b in range(B):
             want = O.fps_indices_fast(pts[b], lens[b], K)
             assert torch.equal(idx[b].cpu().long(), want), (algo, b)
             assert torch.equal(new[b].cpu(), O.gather_masked(pts[b], want))
         assert nl.cpu().tolist() == [min(l, K) for l in lens]
+
+
+def test_fps_speculative_rounds_on_adversarial_clouds(ops):
+    """algo 3 takes several picks per round and proves them afterwards; clouds built to break the proof's premises:
+    a lattice (every distance tied many times over), two far clusters with duplicates (equal maxima in different
+    buckets), points on a line (candidates that change each other), and a K close to the cloud size."""
+    gen = torch.Generator().manual_seed(9)
+    N = 30000
+    g = torch.stack(torch.meshgrid(torch.arange(31.0), torch.arange(31.0), torch.arange(32.0), indexing="ij"), -1).reshape(-1, 3)
+    lattice = g[torch.randperm(g.shape[0], generator=gen)][:N] * 0.25
+    a = torch.rand(N // 2, 3, generator=gen)
+    clusters = torch.cat([a, a + torch.tensor([50.0, 0.0, 0.0])])[torch.randperm(N, generator=gen)]
+    line = torch.zeros(N, 3)
+    line[:, 0] = torch.rand(N, generator=gen) * 100
+    uniform = torch.rand(N, 3, generator=gen) * torch.tensor([60.0, 60.0, 2.0])
+    pts = torch.stack([lattice, clusters, line, uniform])
+    for K, lens in ((2500, [N, N, N, N]), (20000, [N, 25000, N, 20001])):
+        idx, new, nl = ops.fps(pts.to(DEV), _lengths(lens), K, algo=3)
+        for b in range(4):
+            want = O.fps_indices_fast(pts[b], lens[b], K)
+            assert torch.equal(idx[b].cpu().long(), want), (K, b)
+            assert torch.equal(new[b].cpu(), O.gather_masked(pts[b], want))
 
 
 def test_fps_all_levels_sizes(ops):
