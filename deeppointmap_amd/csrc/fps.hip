@@ -468,6 +468,10 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
 // 2.1x (KC = 2) to 2.8x (KC = 3) fewer rounds on the 65 536-point scans -- but a round costs ~9 000 cycles against
 // ~4 100 (top-KC reductions, the second exchange), so it is 20 % SLOWER today and is opt-in (algo = 3).  The
 // measured phase split (scripts/fps_stats.py with ALGO=3) says where a tuned version has to save.
+// (A second variant, one pick per round with the runner-up's buckets prefetched global -> LDS, was measured too:
+// 92 % of the rounds hit, 82 % of the bucket updates found their data on chip -- and the kernel got slower, 9.6 ms
+// against 6.2: a round ends at the barrier, so ONE wave with a miss makes it as long as before, and with ~12
+// buckets per round a fully served round is the exception.)
 // ------------------------------------------------------------------------------------------
 template <int KC, int MAXA>
 __global__ __launch_bounds__(FB) void fps_bucket_spec_kernel(const float *__restrict__ xyz_all,
@@ -774,7 +778,7 @@ extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N
     DPM_CHECK_ARG(algo >= 0 && algo <= 3);
     hipStream_t st = (hipStream_t)stream;
     if (algo == 0) algo = (N > 16384) ? 2 : 1;
-    if (algo == 2 || algo == 3) {
+    if (algo >= 2) {
         if (N > 64 * MAXBUCKETS) return DPM_EUNSUPPORTED;
         DPM_CHECK_ARG(workspace != nullptr);
         uintptr_t p = (((uintptr_t)workspace + 255) & ~(uintptr_t)255) + 256;  // 256 B of debug counters in front

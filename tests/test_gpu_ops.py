@@ -96,11 +96,12 @@ def test_fps_speculative_rounds_on_adversarial_clouds(ops):
     uniform = torch.rand(N, 3, generator=gen) * torch.tensor([60.0, 60.0, 2.0])
     pts = torch.stack([lattice, clusters, line, uniform])
     for K, lens in ((2500, [N, N, N, N]), (20000, [N, 25000, N, 20001])):
-        idx, new, nl = ops.fps(pts.to(DEV), _lengths(lens), K, algo=3)
-        for b in range(4):
-            want = O.fps_indices_fast(pts[b], lens[b], K)
-            assert torch.equal(idx[b].cpu().long(), want), (K, b)
-            assert torch.equal(new[b].cpu(), O.gather_masked(pts[b], want))
+        wants = [O.fps_indices_fast(pts[b], lens[b], K) for b in range(4)]
+        for algo in (3,):  # multi-pick rounds
+            idx, new, nl = ops.fps(pts.to(DEV), _lengths(lens), K, algo=algo)
+            for b in range(4):
+                assert torch.equal(idx[b].cpu().long(), wants[b]), (algo, K, b)
+                assert torch.equal(new[b].cpu(), O.gather_masked(pts[b], wants[b]))
 
 
 def test_fps_all_levels_sizes(ops):
