@@ -33,6 +33,13 @@ class Encoder(ParamTree):
             if s["type"] not in ("fps", "fps-t3d"):
                 raise NotImplementedError(f"sampler {s['type']!r}: only farthest point sampling is implemented "
                                           "(all shipped configs use fps-t3d)")
+        # Farthest point sampling is nested: level i+1 samples the level-i picks starting from the same first point,
+        # and the k-th level-i pick is the farthest of ALL level-(i-1) points from the picks before it -- in
+        # particular the farthest among the level-i picks themselves -- so level i+1 reproduces the level-i pick
+        # ORDER: its result is the first npoint[i+1] picks of level i (ties included: the first-index rule on
+        # positions agrees with the pick order).  Only the first level is computed; False runs every level
+        # (tests assert both give identical tensors).
+        self.nested_fps = all(b <= a for a, b in zip(self.encoder_cfg.npoint, self.encoder_cfg.npoint[1:]))
         self.eval()
 
     # -- helpers -------------------------------------------------------------------------------
@@ -69,7 +76,13 @@ class Encoder(ParamTree):
             cur, cur_len = xyz, lengths
             n_levels = len(self.encoder_cfg.npoint) if levels is None else levels
             for i, npoint in enumerate(self.encoder_cfg.npoint[:n_levels]):
-                fidx, cur, cur_len = ops.fps(cur, cur_len, npoint)
+                if i == 0 or not self.nested_fps:
+                    fidx, cur, cur_len = ops.fps(cur, cur_len, npoint)
+                else:  # prefix of the previous level (index bookkeeping only; rows past a short frame are zero already)
+                    cur_len = torch.clamp(cur_len, max=npoint)
+                    ar = torch.arange(npoint, device=dev, dtype=torch.int32).unsqueeze(0)
+                    fidx = torch.where(ar < cur_len.unsqueeze(1), ar, torch.full_like(ar, -1))
+                    cur = cur[:, :npoint].contiguous()
                 out[f"fidx{i}"], out[f"xyz{i}"], out[f"len{i}"] = fidx, cur, cur_len
         return out
 

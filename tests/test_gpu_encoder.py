@@ -69,3 +69,32 @@ def test_encoder_rejects_cpu_module(cfg_reduced):
     from deeppointmap_amd.encoder import Encoder
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Encoder(cfg_reduced)(torch.zeros(1, 3, 64), torch.zeros(1, 64, dtype=torch.bool))
+
+
+def test_nested_fps_prefix_equals_explicit_chain(cfg_full):
+    """Levels 1.. of the sampling chain are taken as prefixes of level 0 (Encoder.nested_fps); running every level
+    explicitly must give the very same tensors -- on regular scans, on a lattice (every distance tied), with fewer
+    distinct points than picks at the lower levels, and on ragged frames."""
+    from deeppointmap_amd.encoder import Encoder
+    from deeppointmap_amd.weights import init_procedural
+    enc = init_procedural(Encoder(cfg_full)).to(DEV)
+    gen = torch.Generator().manual_seed(31)
+    N = 20000
+    pts = torch.rand(4, 3, N, generator=gen)
+    g = torch.stack(torch.meshgrid(torch.arange(28.0), torch.arange(28.0), torch.arange(28.0), indexing="ij"), -1).reshape(-1, 3)
+    pts[1] = (g[torch.randperm(g.shape[0], generator=gen)][:N] * 0.03).t()
+    pts[2, :, 2000:] = pts[2, :, torch.randint(0, 2000, (N - 2000,), generator=gen)]   # 2000 distinct points only
+    pad = torch.arange(N).unsqueeze(0) >= torch.tensor([[N], [N], [N], [3000]])
+    assert enc.nested_fps
+    a = enc.presample(pts, pad)
+    enc.nested_fps = False
+    b = enc.presample(pts, pad)
+    assert a.keys() == b.keys()
+    for k in a:
+        if k.startswith("fidx") and k != "fidx0":
+            # a frame with fewer distinct points than picks repeats its first point; the explicit chain then reports
+            # position 0 for the repeats, the prefix their own position -- same coordinates either way
+            same = (a[k] == b[k]) | (b[k] == 0)
+            assert bool(same.all()), k
+        else:
+            assert torch.equal(a[k], b[k]), k
