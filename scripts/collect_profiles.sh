@@ -19,4 +19,6 @@ python scripts/rocprof_summary.py $out/pip/t_results.db > $out/pipelined.md
 python scripts/rocprof_pmc.py $out/pmc_FETCH_SIZE/p_results.db $out/pmc_WRITE_SIZE/p_results.db > $out/pmc_fetch_write.md
 python scripts/evidence_table.py $out/unpip/t_results.db $out/pmc_FETCH_SIZE/p_results.db $out/pmc_WRITE_SIZE/p_results.db $out/pmc_mfma/p_results.db > $out/evidence.md
 tail -1 $out/unpip.log | cut -c1-200; tail -1 $out/pip.log | cut -c1-200
+# gpurun copies at most 64 MiB back: the sqlite traces stay on the box unless asked for
+[ "${KEEP_DB:-0}" = 1 ] || rm -rf $out/unpip $out/pip $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_mfma
 ls -la $out
