@@ -328,6 +328,8 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
     int bidx = 0x7fffffff;
     float wx = 0.f, wy = 0.f, wz = 0.f;  // coordinates of this bucket's current best point
     float sx = xyz[0], sy = xyz[1], sz = xyz[2];
+    float wv = -1.f, wbx = 0.f, wby = 0.f, wbz = 0.f;  // this wave's best over ALL its buckets, valid across rounds
+    int wi = 0x7fffffff;
 
 #ifdef DPM_FPS_STATS
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = clock64();
@@ -347,12 +349,11 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
 #ifdef DPM_FPS_STATS
         if (lane == 0 && m) atomicAdd(&((unsigned long long *)pts_all)[-1 - (b & 0)], (unsigned long long)__popcll(m)), atomicMax(&((int *)pts_all)[-4], __popcll(m));
 #endif
-        // wave-level best so far, all values wave-uniform: (value, original index, coordinates)
-        float wv;
-        int wi;
-        float wbx, wby, wbz;
+        // wave-level best so far, all values wave-uniform: (value, original index, coordinates).  It is carried over
+        // from the previous round: a wave none of whose buckets can change this round (almost half of the
+        // wave-rounds) has nothing to recompute and goes straight to the exchange.
         bool first = true;
-        do {
+        if (m != 0) do {
             // up to two active buckets per pass; their global loads are issued first ...
             const int l0 = m ? __builtin_ctzll(m) : 0;
             const bool one = m != 0;
