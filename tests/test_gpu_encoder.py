@@ -98,3 +98,26 @@ def test_nested_fps_prefix_equals_explicit_chain(cfg_full):
             assert bool(same.all()), k
         else:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_encoder_extra_input_channels_vs_oracle(cfg_reduced):
+    """in_channel > 3 (e.g. intensity as a fourth point channel; no shipped config uses it): point_mlp0 is then a
+    real GEMM over the input channels and the first set abstraction reads materialised features.  Checked against
+    the oracle (the reference module is identical up to its state-dict shapes, which the procedural weights fill)."""
+    import copy
+    cfg = copy.deepcopy(cfg_reduced)
+    cfg.encoder.in_channel = 4
+    enc = make_encoder(cfg)
+    sd = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    assert tuple(sd["point_mlp0.weight"].shape[:2]) == (cfg.encoder.width, 4)
+    gen = torch.Generator().manual_seed(41)
+    pts = torch.cat([synthetic.frames(2, 4096)[0], torch.rand(2, 1, 4096, generator=gen)], dim=1)   # x, y, z, intensity
+    pad = torch.zeros(2, 4096, dtype=torch.bool)
+    coor, fea, mask = enc(pts, pad)
+    wc, wf, wm = O.encoder_forward(sd, cfg, pts, pad)
+    assert torch.equal(coor.cpu(), wc) and torch.equal(mask.cpu(), wm)
+    np.testing.assert_allclose(fea.cpu().numpy(), wf.numpy(), rtol=0, atol=3e-4)
+    # the extra channel really reaches the descriptors
+    pts2 = pts.clone()
+    pts2[:, 3] = 1.0 - pts2[:, 3]
+    assert float((enc(pts2, pad)[1] - fea).abs().max()) > 1e-3
