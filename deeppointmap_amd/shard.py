@@ -46,5 +46,17 @@ def gather_to_root(t: torch.Tensor, root: int = 0) -> Optional[torch.Tensor]:
 
 
 def gather_step_results(desc: torch.Tensor, edges_packed: torch.Tensor, root: int = 0):
-    """One step's exchange: descriptors (F,131,S) and packed edges (F,EDGE_FLOATS) -> rank 0."""
-    return gather_to_root(desc, root), gather_to_root(edges_packed, root)
+    """One step's exchange: descriptors (F,131,S) and packed edges (E,EDGE_FLOATS) -> rank 0, as ONE collective:
+    the two tensors travel as one flat fp32 row block per rank (a collective costs a launch and a stream hand-over
+    on every rank whatever its size; the edge rows are 14 KB next to 8.6 MB of descriptors)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return desc, edges_packed
+    nd, ne = desc.numel(), edges_packed.numel()
+    flat = torch.cat([desc.reshape(-1), edges_packed.reshape(-1).to(desc.dtype)]).unsqueeze(0)   # (1, nd + ne)
+    out = gather_to_root(flat, root)
+    if out is None:
+        return None, None
+    world = out.shape[0]
+    d = out[:, :nd].reshape((world * desc.shape[0],) + tuple(desc.shape[1:]))
+    e = out[:, nd:].reshape((world * edges_packed.shape[0],) + tuple(edges_packed.shape[1:]))
+    return d, e
