@@ -59,6 +59,8 @@ SIGNATURES = {
     "dpm_infomat_workspace_bytes": (c_size_t, [I, I, I]),
     "dpm_information_matrix": (I, [P, I, P, I, P, D, P, P, P]),
     "dpm_information_matrix_batched": (I, [P, I, P, P, I, P, I, D, P, I, P, P]),
+    "dpm_infomat_build_grids": (I, [P, I, P, I, D, P, P]),
+    "dpm_infomat_search_grids": (I, [P, I, P, P, I, P, I, D, P, I, P, P]),
 }
 
 

@@ -49,8 +49,11 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
                                                            int Cin, int Cout, int act) {
     constexpr int LDS_LD = KT + 2, LPR = KT / 4, RPP = 256 / LPR;  // lanes per staged row, rows per staging pass
     constexpr int WM = BM / 2, WN = BN / 2, MB = WM / 16, NB = WN / 16, PX = BM / RPP, PW = BN / RPP;
-    __shared__ float Xs[BM][LDS_LD];
-    __shared__ float Ws[BN][LDS_LD];
+    constexpr int LDC = BN + 4;  // row stride of the output tile when it is staged for the epilogue
+    static_assert(BM * LDC <= (BM + BN) * LDS_LD, "the staged output tile reuses the operand tiles' LDS");
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    float (*Xs)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(smem);
+    float (*Ws)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(smem + BM * LDS_LD);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
     const int bz = blockIdx.z;
     X += (size_t)bz * sx, W += (size_t)bz * sw, out += (size_t)bz * so;
@@ -112,27 +115,190 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[cur][j], a[cur][i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
-    // C/D layout of the 16x16 block: col = lane & 15, row = (lane >> 4) * 4 + reg
+    // W is the instruction's A operand and X its B operand, so the 16x16 result block is the TRANSPOSED output
+    // block: D[m][n] with n = lane & 15 -> output row, m = (lane >> 4) * 4 + reg -> output column: a lane owns
+    // four consecutive columns of one row.
+    const bool vec_out = VEC && (ldo & 3) == 0 && (((uintptr_t)out) & 15) == 0 && (Cout & 3) == 0 &&
+                         (!bias || (((uintptr_t)bias) & 15) == 0) &&
+                         (!res || ((ldr & 3) == 0 && (((uintptr_t)res) & 15) == 0));
+    if (vec_out) {
+        // The tile goes through LDS once more (the operand tiles are dead after the loop's last barrier) so that
+        // every store instruction writes whole rows of the tile: 256-byte runs instead of 64-byte pieces.
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                *reinterpret_cast<float4 *>(&smem[(wm * WM + i * 16 + (lane & 15)) * LDC + wn * WN + j * 16 + (lane >> 4) * 4]) =
+                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        __syncthreads();
+        constexpr int TPR = BN / 4, RPS = 256 / TPR;  // threads per tile row, rows per store pass
+        const int cr = t / TPR, cc = (t % TPR) * 4, c = col0 + cc;
+        if (c < Cout) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) bv = *reinterpret_cast<const float4 *>(bias + c);
+#pragma unroll
+            for (int p = 0; p < BM / RPS; ++p) {
+                const int r = row0 + p * RPS + cr;
+                if (r >= R) continue;
+                float4 v = *reinterpret_cast<const float4 *>(&smem[(p * RPS + cr) * LDC + cc]);
+                v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                if (res) {
+                    const float4 rv = *reinterpret_cast<const float4 *>(res + (size_t)r * ldr + c);
+                    v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
+                }
+                v.x = apply_act(v.x, act), v.y = apply_act(v.y, act), v.z = apply_act(v.z, act), v.w = apply_act(v.w, act);
+                *reinterpret_cast<float4 *>(out + (size_t)r * ldo + c) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int c = col0 + wn * WN + j * 16 + (lane & 15);
-            if (c >= Cout) continue;
-            const float bv = bias ? bias[c] : 0.f;
+            const int r = row0 + wm * WM + i * 16 + (lane & 15);
+            const int c = col0 + wn * WN + j * 16 + (lane >> 4) * 4;
+            if (r >= R) continue;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = row0 + wm * WM + i * 16 + (lane >> 4) * 4 + q;
-                if (r >= R) continue;
-                float v = acc[i][j][q] + bv;
-                if (res) v += res[(size_t)r * ldr + c];
-                out[(size_t)r * ldo + c] = apply_act(v, act);
+                if (c + q >= Cout) continue;
+                float v = acc[i][j][q] + (bias ? bias[c + q] : 0.f);
+                if (res) v += res[(size_t)r * ldr + c + q];
+                out[(size_t)r * ldo + c + q] = apply_act(v, act);
             }
         }
+}
+
+// Large-shape variant: block tile 128x128, 4 waves as 2x2, wave tile 64x64 = 2x2 blocks of
+// v_mfma_f32_32x32x2_f32 (64 accumulator registers; half the LDS fragment traffic and half the
+// global->LDS staging per flop of the 64x64 kernel).  K-tile 32, LDS row stride 36 floats: 16-byte
+// aligned rows for ds_write_b128 / ds_read_b128, and rows r..r+7 start 4 banks apart, so a
+// quarter-wave's b128 reads cover all banks once.
+// One float4 per lane feeds FOUR MFMAs: the instruction wants A[i = l & 31][k = l >> 5] (two k per
+// issue); lanes < 32 read k = 8g..8g+3 and lanes >= 32 read k = 8g+4..8g+7 of their row, and MFMA c
+// takes component c of both operands -- it contracts k in {8g+c, 8g+4+c}.  A and B use the same
+// map, so the four issues together contract k = 8g..8g+7 exactly once.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int KT = 32>
+__global__ __launch_bounds__(256, 2) void gemm_nt_mfma128_kernel(const float *__restrict__ X0, int ldx, long long sx,
+                                                                 const float *__restrict__ W0, int ldw, long long sw,
+                                                                 const float *__restrict__ bias,
+                                                                 const float *__restrict__ res0, int ldr, long long sr,
+                                                                 float *__restrict__ out0, int ldo, long long so, int R,
+                                                                 int Cin, int Cout, int act, int gx, int gy, int ntiles) {
+    constexpr int BM = 128, BN = 128, LD = KT + 4, LPR = KT / 4, RPP = 256 / LPR, PX = BM / RPP, PW = BN / RPP;
+    __shared__ __attribute__((aligned(16))) float Xs[BM][LD];
+    __shared__ __attribute__((aligned(16))) float Ws[BN][LD];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+    const int sr_ = t / LPR, sk = (t % LPR) * 4;
+    const int fr = lane & 31, fk = (lane >> 5) * 4;
+    const bool swz = (gy & 7) == 0 && gy >= 64 && (gridDim.x & 7) == 0;
+    const int per = gx * gy;
+
+    // Persistent blocks: block b walks tiles b, b + G, ...  (G % 8 == 0 keeps a block's tiles on the XCD-chunk
+    // its first tile mapped to).  The first K-tile of the NEXT output tile is requested before the current
+    // tile's epilogue, so neither the load latency nor the stores sit between two MFMA phases.
+    int bz, row0, col0;
+    auto place = [&](int L) {
+        bz = L / per;
+        const int l = L - bz * per;
+        int by = l / gx, bx = l - by * gx;
+        if (swz) {  // all column blocks of one row block on ONE XCD: its L2 serves X
+            const int xcd = l & 7, slot = l >> 3;
+            by = (slot / gx) * 8 + xcd, bx = slot % gx;
+        }
+        row0 = by * BM, col0 = bx * BN;
+    };
+    float4 xr[PX], wr[PW];
+    auto request = [&](int k) {
+        const float *X = X0 + (size_t)bz * sx, *W = W0 + (size_t)bz * sw;
+#pragma unroll
+        for (int p = 0; p < PX; ++p) xr[p] = load4<true>(X, ldx, row0 + p * RPP + sr_, R, k + sk, Cin);
+#pragma unroll
+        for (int p = 0; p < PW; ++p) wr[p] = load4<true>(W, ldw, col0 + p * RPP + sr_, Cout, k + sk, Cin);
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) place(tile), request(0);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int my_bz = bz, my_row0 = row0, my_col0 = col0;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        for (int k0 = 0; k0 < Cin; k0 += KT) {
+#pragma unroll
+            for (int p = 0; p < PX; ++p) *reinterpret_cast<float4 *>(&Xs[p * RPP + sr_][sk]) = xr[p];
+#pragma unroll
+            for (int p = 0; p < PW; ++p) *reinterpret_cast<float4 *>(&Ws[p * RPP + sr_][sk]) = wr[p];
+            __syncthreads();
+            if (k0 + KT < Cin) {
+                request(k0 + KT);
+            } else if (tile + (int)gridDim.x < ntiles) {
+                place(tile + gridDim.x), request(0);
+            }
+            float4 a[2][2], b[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[0][i] = *reinterpret_cast<const float4 *>(&Xs[wm * 64 + i * 32 + fr][fk]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[0][j] = *reinterpret_cast<const float4 *>(&Ws[wn * 64 + j * 32 + fr][fk]);
+#pragma unroll
+            for (int g = 0; g < KT / 8; ++g) {
+                const int cur = g & 1, nxt = cur ^ 1;
+                if (g + 1 < KT / 8) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        a[nxt][i] = *reinterpret_cast<const float4 *>(&Xs[wm * 64 + i * 32 + fr][(g + 1) * 8 + fk]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        b[nxt][j] = *reinterpret_cast<const float4 *>(&Ws[wn * 64 + j * 32 + fr][(g + 1) * 8 + fk]);
+                }
+#define DPM_MFMA4(c)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =        \
+        __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].c, a[cur][i].c, acc[i][j], 0, 0, 0)
+                DPM_MFMA4(x);
+                DPM_MFMA4(y);
+                DPM_MFMA4(z);
+                DPM_MFMA4(w);
+#undef DPM_MFMA4
+            }
+            __syncthreads();
+        }
+        // Transposed result blocks (W is the A operand): D[m][n], n = lane & 31 -> output row,
+        // m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) -> output column: four 16-byte stores per block.
+        float *out = out0 + (size_t)my_bz * so;
+        const float *res = res0 ? res0 + (size_t)my_bz * sr : nullptr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = my_row0 + wm * 64 + i * 32 + (lane & 31);
+                if (r >= R) continue;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = my_col0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+                    if (c >= Cout) continue;  // Cout % 4 == 0 (dispatch): all four columns exist
+                    float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    if (bias) {
+                        const float4 bv = *reinterpret_cast<const float4 *>(bias + c);
+                        v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                    }
+                    if (res) {
+                        const float4 rv = *reinterpret_cast<const float4 *>(res + (size_t)r * ldr + c);
+                        v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
+                    }
+                    v.x = apply_act(v.x, act), v.y = apply_act(v.y, act), v.z = apply_act(v.z, act), v.w = apply_act(v.w, act);
+                    *reinterpret_cast<float4 *>(out + (size_t)r * ldo + c) = v;
+                }
+            }
+    }
 }
 
 }  // namespace
@@ -148,6 +314,19 @@ extern "C" int dpm_linear_batched(const float *x, int ldx, long long sx, const f
                      sx % 4 == 0 && sw % 4 == 0;
     const long long big = (long long)batch * dpm_cdiv(R, 64) * dpm_cdiv(Cout, 64);
     // 64x64 tiles measured best or tied against 128x128 / 128x64 on every shape of the path (scripts/gemm_bench.py)
+    // Long reductions over a big output (K >= 1024, >= 512 tiles of 128x128) amortise the 128x128 kernel's tile
+    // switch: 128 vs 110 TFLOP/s at 4096^3.  Every shape of the registration path has K <= 512 with 32768 rows
+    // or fewer, where the 64x64 kernel's higher occupancy measured equal or better (scripts/gemm_bench.py).
+    const bool vec_out = (ldo & 3) == 0 && ((uintptr_t)out & 15) == 0 && so % 4 == 0 && Cout % 4 == 0 &&
+                         (!bias || ((uintptr_t)bias & 15) == 0) &&
+                         (!residual || ((ldr & 3) == 0 && ((uintptr_t)residual & 15) == 0 && sr % 4 == 0));
+    const long long blocks128 = (long long)batch * dpm_cdiv(R, 128) * dpm_cdiv(Cout, 128);
+    if (vec && vec_out && Cin >= 1024 && blocks128 >= 512) {
+        const int gx = dpm_cdiv(Cout, 128), gy = dpm_cdiv(R, 128), ntiles = batch * gx * gy;
+        hipLaunchKernelGGL((gemm_nt_mfma128_kernel<32>), dim3(min(ntiles, 512)), dim3(256), 0, st, x, ldx, sx, W, ldw, sw,
+                           bias, residual, ldr, sr, out, ldo, so, R, Cin, Cout, act, gx, gy, ntiles);
+        return dpm_launch_status();
+    }
     const bool t64 = big >= 192 || (R > 1024 && Cout > 32);
     const dim3 grid = t64 ? dim3(dpm_cdiv(Cout, 64), dpm_cdiv(R, 64), batch) : dim3(dpm_cdiv(Cout, 32), dpm_cdiv(R, 32), batch);
 #define DPM_GEMM_LAUNCH(BM, BN, V)                                                                                  \

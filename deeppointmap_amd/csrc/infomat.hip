@@ -358,13 +358,31 @@ extern "C" size_t dpm_infomat_workspace_bytes(int n_pairs, int N1, int N2) {
     return 256 + (size_t)n_pairs * ws_slice_bytes(N1, N2);
 }
 
-static int launch_infomat(PairArgs A, int n_pairs, double radius, hipStream_t st) {
+static int launch_grid(PairArgs A, int n_pairs, double radius, hipStream_t st) {
     hipLaunchKernelGGL(grid_setup_kernel, dim3(n_pairs), dim3(1024), 0, st, A, (float)radius);
     hipLaunchKernelGGL(grid_build_kernel, dim3(SLABS, n_pairs), dim3(1024), 0, st, A);
+    return dpm_launch_status();
+}
+
+static int launch_search(PairArgs A, int n_pairs, double radius, hipStream_t st) {
     hipLaunchKernelGGL(nn1_moments_kernel, dim3(dpm_cdiv(A.N1, 256), n_pairs), dim3(256), 0, st, A,
                        (float)(radius * radius));
     hipLaunchKernelGGL(infomat_finalize_kernel, dim3(n_pairs), dim3(64), 0, st, A);
     return dpm_launch_status();
+}
+
+static int launch_infomat(PairArgs A, int n_pairs, double radius, hipStream_t st) {
+    const int rc = launch_grid(A, n_pairs, radius, st);
+    return rc ? rc : launch_search(A, n_pairs, radius, st);
+}
+
+static PairArgs batched_args(const float *pcd, int N, const int32_t *src_frame, const int32_t *dst_frame,
+                             void *workspace) {
+    PairArgs A{};
+    A.pcd1 = pcd, A.pcd2 = pcd, A.f1 = src_frame, A.f2 = dst_frame, A.stride1 = 3LL * N, A.stride2 = 3LL * N;
+    A.ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), A.ws_stride = ws_slice_bytes(N, N);
+    A.N1 = N, A.N2 = N;
+    return A;
 }
 
 extern "C" int dpm_information_matrix(const float *pcd1, int N1, const float *pcd2, int N2, const float *Rt,
@@ -384,10 +402,26 @@ extern "C" int dpm_information_matrix_batched(const float *pcd, int N, const int
                                               dpm_stream_t stream) {
     DPM_CHECK_ARG(pcd && src_frame && dst_frame && Rt && out && workspace && N >= 1 && n_pairs >= 1 && radius > 0.0);
     DPM_CHECK_ARG(rt_stride >= 12 && out_stride >= 36);
-    PairArgs A{};
-    A.pcd1 = pcd, A.pcd2 = pcd, A.f1 = src_frame, A.f2 = dst_frame, A.stride1 = 3LL * N, A.stride2 = 3LL * N;
+    PairArgs A = batched_args(pcd, N, src_frame, dst_frame, workspace);
     A.Rt = Rt, A.rt_stride = rt_stride, A.out = out, A.out_stride = out_stride;
-    A.ws = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), A.ws_stride = ws_slice_bytes(N, N);
-    A.N1 = N, A.N2 = N;
     return launch_infomat(A, n_pairs, radius, (hipStream_t)stream);
+}
+
+// The two halves of dpm_information_matrix_batched.  The grid depends on the target scans only -- not on the
+// pose -- so a pipeline builds it while the frames are still being encoded and runs only the search after
+// the registration.
+extern "C" int dpm_infomat_build_grids(const float *pcd, int N, const int32_t *dst_frame, int n_pairs, double radius,
+                                       void *workspace, dpm_stream_t stream) {
+    DPM_CHECK_ARG(pcd && dst_frame && workspace && N >= 1 && n_pairs >= 1 && radius > 0.0);
+    return launch_grid(batched_args(pcd, N, nullptr, dst_frame, workspace), n_pairs, radius, (hipStream_t)stream);
+}
+
+extern "C" int dpm_infomat_search_grids(const float *pcd, int N, const int32_t *src_frame, const int32_t *dst_frame,
+                                        int n_pairs, const float *Rt, int rt_stride, double radius, float *out,
+                                        int out_stride, void *workspace, dpm_stream_t stream) {
+    DPM_CHECK_ARG(pcd && src_frame && dst_frame && Rt && out && workspace && N >= 1 && n_pairs >= 1 && radius > 0.0);
+    DPM_CHECK_ARG(rt_stride >= 12 && out_stride >= 36);
+    PairArgs A = batched_args(pcd, N, src_frame, dst_frame, workspace);
+    A.Rt = Rt, A.rt_stride = rt_stride, A.out = out, A.out_stride = out_stride;
+    return launch_search(A, n_pairs, radius, (hipStream_t)stream);
 }

@@ -381,14 +381,34 @@ def information_matrix(pcd1: torch.Tensor, pcd2: torch.Tensor, Rt: torch.Tensor,
 
 
 def information_matrix_batched(pcd: torch.Tensor, src_frame: torch.Tensor, dst_frame: torch.Tensor, Rt_rows: torch.Tensor,
-                               out_rows: torch.Tensor, radius: float = 1.0) -> None:
+                               out_rows: torch.Tensor, radius: float = 1.0, grids: Optional[torch.Tensor] = None) -> None:
     """pcd (F,3,N) metres; pair p = (src_frame[p], dst_frame[p]) (int32 GPU tensors); Rt_rows (P, >=12) and
-    out_rows (P, >=36) are row views (unit column stride) -- typically columns of one edge table."""
+    out_rows (P, >=36) are row views (unit column stride) -- typically columns of one edge table.
+    grids: the workspace returned by information_matrix_grids(pcd, dst_frame, radius) -- only the search runs."""
     _chk(pcd, torch.float32, "pcd"), _chk(src_frame, torch.int32, "src_frame"), _chk(dst_frame, torch.int32, "dst_frame")
     _rows2d(Rt_rows, "Rt_rows"), _rows2d(out_rows, "out_rows")
     P_, N = src_frame.numel(), pcd.shape[2]
     lib = _lib.load()
+    if grids is not None:
+        if grids.numel() != lib.dpm_infomat_workspace_bytes(P_, N, N):
+            raise ValueError("grids was built for a different (n_pairs, N)")
+        _lib.check(lib.dpm_infomat_search_grids(_ptr(pcd), N, _ptr(src_frame), _ptr(dst_frame), P_, _ptr(Rt_rows),
+                                                Rt_rows.stride(0), float(radius), _ptr(out_rows), out_rows.stride(0),
+                                                _ptr(grids), _stream(pcd)), "dpm_infomat_search_grids")
+        return
     ws = torch.empty(lib.dpm_infomat_workspace_bytes(P_, N, N), device=pcd.device, dtype=torch.uint8)
     _lib.check(lib.dpm_information_matrix_batched(_ptr(pcd), N, _ptr(src_frame), _ptr(dst_frame), P_, _ptr(Rt_rows),
                                                   Rt_rows.stride(0), float(radius), _ptr(out_rows), out_rows.stride(0),
                                                   _ptr(ws), _stream(pcd)), "dpm_information_matrix_batched")
+
+
+def information_matrix_grids(pcd: torch.Tensor, dst_frame: torch.Tensor, radius: float = 1.0) -> torch.Tensor:
+    """The pose-independent half of information_matrix_batched: sorts the target scan of every pair into its
+    search grid.  Returns the workspace to pass as `grids=` (same pcd, dst_frame and radius)."""
+    _chk(pcd, torch.float32, "pcd"), _chk(dst_frame, torch.int32, "dst_frame")
+    P_, N = dst_frame.numel(), pcd.shape[2]
+    lib = _lib.load()
+    ws = torch.empty(lib.dpm_infomat_workspace_bytes(P_, N, N), device=pcd.device, dtype=torch.uint8)
+    _lib.check(lib.dpm_infomat_build_grids(_ptr(pcd), N, _ptr(dst_frame), P_, float(radius), _ptr(ws), _stream(pcd)),
+               "dpm_infomat_build_grids")
+    return ws

@@ -42,6 +42,7 @@ class HotPath:
         self.feature_streams = 1     # >1: consecutive batches' feature stages alternate between side streams
         self._side = None      # side HIP streams for the software pipeline (submit / flush)
         self._pending = None
+        self._rings = {}
 
     @torch.no_grad()
     def extract(self, points: torch.Tensor, padding: torch.Tensor, presampled=None) -> torch.Tensor:
@@ -51,22 +52,26 @@ class HotPath:
 
     @torch.no_grad()
     def register(self, desc: torch.Tensor, pcd_m: Optional[torch.Tensor], pairs, table: Optional[torch.Tensor] = None,
-                 materialize: bool = True):
+                 materialize: bool = True, pair_index=None, grids: Optional[torch.Tensor] = None):
         """desc (F,131,S); pcd_m (F,3,N) scans in metres (None: skip the information matrix);
         pairs: list of (src_frame, dst_frame).  All pairs are registered in ONE batched pass.
         Returns (edges, table): table (E, EDGE_FLOATS) is filled on the device by the kernels themselves
         (20-float registration header | 6x6 information) -- it is what a rank ships to rank 0.
-        materialize=False skips building Edge objects (no host synchronisation at all)."""
+        materialize=False skips building Edge objects (no host synchronisation at all).
+        pair_index: (src, dst) int32 device tensors of `pairs` when the caller already holds them;
+        grids: ops.information_matrix_grids(pcd_m, dst) built ahead of time (the pose-independent half)."""
         pairs = list(pairs)
         dev = desc.device
         if table is None:
             table = torch.zeros(len(pairs), EDGE_FLOATS, device=dev, dtype=torch.float32)
-        sidx = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev)
-        didx = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev)
+        if pair_index is None:
+            pair_index = (torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev),
+                          torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev))
+        sidx, didx = pair_index
         res = self.decoder.registration_forward_pairs(desc, sidx, didx, num_sample=self.num_sample,
                                                       header_out=table[:, :ops.RES_HDR])
         if pcd_m is not None:
-            ops.information_matrix_batched(pcd_m, sidx, didx, table[:, :12], table[:, ops.RES_HDR:])
+            ops.information_matrix_batched(pcd_m, sidx, didx, table[:, :12], table[:, ops.RES_HDR:], grids=grids)
         edges = []
         if materialize:
             head = table[:, :ops.RES_HDR].cpu()
@@ -77,13 +82,23 @@ class HotPath:
                                   res[e, ops.RES_HDR:ops.RES_HDR + n_in], float(head[e, 12]), info))
         return edges, table
 
+    def _ring_pairs(self, F: int, dev):
+        """Every frame against its predecessor (frame 0 against the last of the batch): the pair list and its
+        device index tensors, built once per batch size."""
+        key = (F, str(dev))
+        if key not in self._rings:
+            pairs = [((f - 1) % F, f) for f in range(F)]
+            self._rings[key] = (pairs, (torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev),
+                                        torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev)))
+        return self._rings[key]
+
     @torch.no_grad()
     def step(self, points: torch.Tensor, padding: torch.Tensor, pcd_m: Optional[torch.Tensor], materialize: bool = True):
         """One batch: every frame is encoded and registered against its predecessor (frame 0 against
         the last frame of the batch, so a batch of F frames carries exactly F edges)."""
         desc = self.extract(points, padding)
-        F = desc.shape[0]
-        edges, table = self.register(desc, pcd_m, [((f - 1) % F, f) for f in range(F)], materialize=materialize)
+        pairs, index = self._ring_pairs(desc.shape[0], desc.device)
+        edges, table = self.register(desc, pcd_m, pairs, materialize=materialize, pair_index=index)
         return desc, edges, table
 
     # -- streaming mode: software pipeline over consecutive batches ----------------------------------------
@@ -109,12 +124,21 @@ class HotPath:
             self._pending = dict(geo=[], reg=None, n=0, nf=0)
         sa = self._side["geo"][self._pending["n"] % len(self._side["geo"])]
         self._pending["n"] += 1
+        grids = None
+        if pcd_m is not None:
+            ring = self._ring_pairs(points.shape[0], dev)  # before the stream switch: a first call copies H2D
         with torch.cuda.stream(sa):
             pre = self.encoder.presample(points, padding, levels=self.geometry_levels)
             ready = sa.record_event()
+            if pcd_m is not None:
+                # the information matrix's target grids need no pose: built here, off the registration stream
+                grids = ops.information_matrix_grids(pcd_m, ring[1][1])
+                grids.record_stream(self._side["reg"])
+                grids_ready = sa.record_event()
         for t in pre.values():
             t.record_stream(main)  # produced on a geometry stream, consumed on the caller's stream
-        self._pending["geo"].append((pre, ready, points, padding, pcd_m))
+        self._pending["geo"].append((pre, ready, points, padding,
+                                     (pcd_m, grids, grids_ready) if pcd_m is not None else None))
         done = None
         if len(self._pending["geo"]) > self.geometry_depth:
             done = self._advance(self._pending["geo"].pop(0))
@@ -147,11 +171,15 @@ class HotPath:
         dev = self.encoder.device
         main = torch.cuda.current_stream(dev)
         sb = self._side["reg"]
-        desc, desc_ready, pcd_m = reg
+        desc, desc_ready, scans = reg
+        pairs, index = self._ring_pairs(desc.shape[0], dev)
         with torch.cuda.stream(sb):
             sb.wait_event(desc_ready)
-            F = desc.shape[0]
-            _, table = self.register(desc, pcd_m, [((f - 1) % F, f) for f in range(F)], materialize=False)
+            pcd_m = grids = None
+            if scans is not None:
+                pcd_m, grids, grids_ready = scans
+                sb.wait_event(grids_ready)
+            _, table = self.register(desc, pcd_m, pairs, materialize=False, pair_index=index, grids=grids)
             done = sb.record_event()
         table.record_stream(main)
         main.wait_event(done)  # the caller's stream sees finished results (e.g. for the RCCL gather)

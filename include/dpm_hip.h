@@ -271,6 +271,15 @@ int dpm_information_matrix_batched(const float *pcd, int N, const int32_t *src_f
                                    const int32_t *dst_frame, int n_pairs, const float *Rt, int rt_stride,
                                    double radius, float *out, int out_stride, void *workspace,
                                    dpm_stream_t stream);
+/* The same computation in two calls sharing one workspace (dpm_infomat_workspace_bytes(n_pairs, N, N)):
+ * the target grids depend only on the scans, so a caller that pipelines frames builds them before the
+ * poses exist (next to the encoder) and runs only the search after the registration
+ * (system/modules/odometry.py:116-118 calls the function right after registration_forward). */
+int dpm_infomat_build_grids(const float *pcd, int N, const int32_t *dst_frame, int n_pairs, double radius,
+                            void *workspace, dpm_stream_t stream);
+int dpm_infomat_search_grids(const float *pcd, int N, const int32_t *src_frame, const int32_t *dst_frame,
+                             int n_pairs, const float *Rt, int rt_stride, double radius, float *out,
+                             int out_stride, void *workspace, dpm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -214,6 +214,12 @@ def test_batched_information_matrix_equals_single(ops):
         src = torch.tensor([a for a, _ in pairs], dtype=torch.int32, device=DEV)
         dst = torch.tensor([b for _, b in pairs], dtype=torch.int32, device=DEV)
         ops.information_matrix_batched(pts, src, dst, table[:, :12], table[:, 20:])
+        # the two-call form (grids built before the poses exist) is the same computation bit for bit
+        split = table.clone()
+        split[:, 20:] = -1.0
+        grids = ops.information_matrix_grids(pts, dst)
+        ops.information_matrix_batched(pts, src, dst, split[:, :12], split[:, 20:], grids=grids)
+        assert torch.equal(split, table)
         for p, (a, b) in enumerate(pairs):
             want = calculate_information_matrix_from_pcd(pts[a], pts[b], poses[p], device=DEV)
             got = table[p, 20:].view(6, 6).cpu()

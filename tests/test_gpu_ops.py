@@ -225,6 +225,25 @@ def test_linear_layernorm_interp_vs_torch(ops):
         torch.testing.assert_close(y, want, rtol=1e-5, atol=2e-5)
 
 
+def test_linear_large_tiles_vs_torch(ops):
+    """The shapes that take the 128x128 persistent kernel (K >= 1024, >= 512 output tiles) and the 64x64 kernel's
+    staged epilogue with ragged edges, against an fp64 product."""
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    for R, Cin, Cout, relu in [(8192 + 40, 1024, 1024, True), (4096, 1028, 2048, False), (1000, 96, 68, True), (333, 64, 260, False)]:
+        x = torch.randn(R, Cin, device=DEV, generator=gen)
+        W = torch.randn(Cout, Cin, device=DEV, generator=gen) / Cin ** 0.5
+        b, res = torch.randn(Cout, device=DEV, generator=gen), torch.randn(R, Cout, device=DEV, generator=gen)
+        y = ops.linear(x, W, b, act=ops.ACT_RELU if relu else ops.ACT_NONE, residual=res)
+        want = x.double() @ W.double().t() + b.double() + res.double()
+        want = (torch.relu(want) if relu else want).float()
+        torch.testing.assert_close(y, want, rtol=1e-5, atol=3e-5)
+    # batched entry through the big kernel: per-batch strides
+    xb = torch.randn(2, 4096, 1024, device=DEV, generator=gen)
+    Wb = torch.randn(2, 1024, 1024, device=DEV, generator=gen) / 32
+    yb = ops.similarity_batched(xb, Wb)
+    torch.testing.assert_close(yb, torch.bmm(xb.double(), Wb.double().transpose(1, 2)).float(), rtol=1e-5, atol=3e-5)
+
+
 def test_three_interp_vs_oracle(ops):
     gen = torch.Generator().manual_seed(12)
     B, N, S, D1, D2 = 2, 64, 16, 24, 40
