@@ -605,6 +605,8 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
 // The next batch of points is fetched while the replay runs.
 // ---------------------------------------------------------------------------------------------
 constexpr int TIE_U = 4;    // points per thread per step
+constexpr int TIE_HEAD = 4096;  // points walked step by step before the filter pass (a multiple of TIE_U * TIE_T)
+constexpr int TIE_LIST = 512;   // candidates one wave may keep in the filter pass
 constexpr int TIE_T = 256;  // threads per row: the sequential replay bounds a row, so many small workgroups beat few large ones
 
 __device__ __forceinline__ float rlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -648,6 +650,9 @@ __global__ __launch_bounds__(TIE_T) void knn_tie_kernel(const float *__restrict_
     __shared__ float s_dist[TIE_U * TIE_T];
     __shared__ unsigned long long s_mask[TIE_U * (TIE_T / 64)];
     __shared__ float s_top;
+    __shared__ float s_cd[TIE_T / 64][TIE_LIST];
+    __shared__ int s_ci[TIE_T / 64][TIE_LIST];
+    __shared__ int s_cn[TIE_T / 64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int n_rows = min(*tie_count, TIE_CAP);
     for (int r = blockIdx.x; r < n_rows; r += gridDim.x) {
@@ -681,35 +686,87 @@ __global__ __launch_bounds__(TIE_T) void knn_tie_kernel(const float *__restrict_
                 px[u] = pts[3 * i], py[u] = pts[3 * i + 1], pz[u] = pts[3 * i + 2];
             }
         };
-        fetch(K);
-        for (int base = K; base < len; base += TIE_U * TIE_T) {
-            __syncthreads();  // s_top is final for this step; s_dist / s_mask are free again
-            const float top = s_top;
-            bool any = false;
-#pragma unroll
-            for (int u = 0; u < TIE_U; ++u) {
-                const int i = base + u * TIE_T + t;
-                const float d = i < len ? dist(px[u], py[u], pz[u]) : __builtin_inff();
-                s_dist[u * TIE_T + t] = d;
-                const unsigned long long m = __ballot(d < top);
-                if (lane == 0) s_mask[u * (TIE_T / 64) + w] = m;
-                any |= m != 0;
+        // replay of one 64-entry chunk (distance d, point index ii per lane) against the moving top
+        auto replay = [&](float d, int ii) {
+            unsigned long long mm = __ballot(d < rlane(hv, 0));
+            while (mm) {
+                const int l = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                const float dl = rlane(d, l);
+                if (dl < rlane(hv, 0)) heap_adjust_reg(hv, hi, 0, K, dl, rlane(ii, l));  // std::__pop_heap
             }
-            if (base + TIE_U * TIE_T < len) fetch(base + TIE_U * TIE_T);
-            if (__syncthreads_or(any) && w == 0) {
-                // replay, in index order, of the 64-point chunks that had anything below the step's starting top
-                for (int c = 0; c < TIE_U * (TIE_T / 64); ++c) {
-                    if (s_mask[c] == 0) continue;
-                    const float d = s_dist[c * 64 + lane];
-                    unsigned long long mm = __ballot(d < rlane(hv, 0));
-                    while (mm) {
-                        const int l = __builtin_ctzll(mm);
-                        mm &= mm - 1;
-                        const float dl = rlane(d, l);
-                        if (dl < rlane(hv, 0)) heap_adjust_reg(hv, hi, 0, K, dl, base + c * 64 + l);  // std::__pop_heap
+        };
+        // points [from, to) step by step: TIE_U * TIE_T distances per step, flagged chunks replayed by wave 0
+        auto scan_steps = [&](int from, int to) {
+            fetch(from);
+            for (int base = from; base < to; base += TIE_U * TIE_T) {
+                __syncthreads();  // s_top is final for this step; s_dist / s_mask are free again
+                const float top = s_top;
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < TIE_U; ++u) {
+                    const int i = base + u * TIE_T + t;
+                    const float d = i < to ? dist(px[u], py[u], pz[u]) : __builtin_inff();
+                    s_dist[u * TIE_T + t] = d;
+                    const unsigned long long m = __ballot(d < top);
+                    if (lane == 0) s_mask[u * (TIE_T / 64) + w] = m;
+                    any |= m != 0;
+                }
+                if (base + TIE_U * TIE_T < to) fetch(base + TIE_U * TIE_T);
+                if (__syncthreads_or(any) && w == 0) {
+                    for (int c = 0; c < TIE_U * (TIE_T / 64); ++c)
+                        if (s_mask[c] != 0) replay(s_dist[c * 64 + lane], base + c * 64 + lane);
+                    if (lane == 0) s_top = hv;
+                }
+            }
+        };
+        // The top only falls, and it falls fast: after the first few thousand points it is the K-th smallest of
+        // them, which less than 1 % of the rest undercut.  So the head of the frame is walked step by step, and the
+        // rest goes through ONE filter pass against the top reached there (a superset of everything heap-select
+        // would touch): each wave compacts its contiguous quarter of the range, in index order, into its own LDS
+        // list, and wave 0 replays the four lists back to back.  A list that overflows (a frame whose head is far
+        // from the centre) sends the row down the step-by-step path for the whole range.
+        const int stop = min(len, K + TIE_HEAD);
+        scan_steps(K, stop);
+        if (stop < len) {
+            __syncthreads();
+            const float top = s_top;
+            const int seg = (((len - stop + TIE_T / 64 - 1) / (TIE_T / 64)) + 63) & ~63;
+            const int beg = stop + w * seg, end = min(len, beg + seg);
+            int cn = 0;
+            for (int i0 = beg; i0 < end; i0 += 64 * TIE_U) {
+                float fx[TIE_U], fy[TIE_U], fz[TIE_U];
+#pragma unroll
+                for (int u = 0; u < TIE_U; ++u) {
+                    const int i = min(i0 + u * 64 + lane, len - 1);
+                    fx[u] = pts[3 * i], fy[u] = pts[3 * i + 1], fz[u] = pts[3 * i + 2];
+                }
+#pragma unroll
+                for (int u = 0; u < TIE_U; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    const float d = i < end ? dist(fx[u], fy[u], fz[u]) : __builtin_inff();
+                    const unsigned long long m = __ballot(d < top);
+                    if (m == 0) continue;
+                    const int pos = cn + __popcll(m & ((1ull << lane) - 1ull));
+                    if (d < top && pos < TIE_LIST) s_cd[w][pos] = d, s_ci[w][pos] = i;
+                    cn += __popcll(m);
+                }
+            }
+            if (lane == 0) s_cn[w] = cn;
+            __syncthreads();
+            bool overflow = false;
+#pragma unroll
+            for (int k = 0; k < TIE_T / 64; ++k) overflow |= s_cn[k] > TIE_LIST;
+            if (overflow) {
+                scan_steps(stop, len);
+            } else if (w == 0) {
+                for (int k = 0; k < TIE_T / 64; ++k) {
+                    const int n = s_cn[k];
+                    for (int c0 = 0; c0 < n; c0 += 64) {
+                        const bool in = c0 + lane < n;
+                        replay(in ? s_cd[k][c0 + lane] : __builtin_inff(), in ? s_ci[k][c0 + lane] : 0);
                     }
                 }
-                if (lane == 0) s_top = hv;
             }
         }
         if (w == 0) {
