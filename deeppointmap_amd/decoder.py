@@ -196,8 +196,17 @@ class Decoder(ParamTree):
         E = self.model_channel
         k = self._num_pairs(num_sample, M, N)
         # similarity head -> L2 normalise -> M x N similarity -> dual softmax -> top-k   (decoder.py:181-191)
-        a = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", x, ops.ACT_RELU)))
-        b = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", y, ops.ACT_RELU)))
+        if (M == N and x.is_contiguous() and y.is_contiguous() and
+                x.untyped_storage().data_ptr() == y.untyped_storage().data_ptr() and
+                y.storage_offset() == x.storage_offset() + x.numel()):
+            # the joint attention path left src and dst rows back to back: the head (shared weights, row-wise
+            # kernels) runs once over both halves
+            z = x.as_strided((2 * B * M, E), (E, 1), x.storage_offset())
+            ab = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", z, ops.ACT_RELU)))
+            a, b = ab[:B * M], ab[B * M:]
+        else:
+            a = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", x, ops.ACT_RELU)))
+            b = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", y, ops.ACT_RELU)))
         S = ops.similarity_batched(a.view(B, M, E), b.view(B, N, E))
         conf, flat = ops.dual_softmax_topk(S, self.tau, k)
         # offset head on both pair directions                                           (decoder.py:204-207)

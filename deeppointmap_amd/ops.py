@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -107,6 +109,28 @@ def ball_query(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tenso
 
 PROJECTED_COUT = (32, 64, 128, 256, 512)
 
+# Tensors derived from weights alone (a packed copy of weight columns, the product of two weight matrices) are
+# made once per weight version, not once per call.  An entry belongs to the very tensor OBJECTS it was made from
+# (weak references: a freed weight whose address is reused cannot alias it) at their storage address and in-place
+# version, so load_state_dict / .to() / optimiser steps invalidate it.  Callers pass the parameter tensors
+# themselves, not views made per call.
+_DERIVED: dict = {}
+
+
+def _derived(tag: str, sources, make):
+    key = (tag,) + tuple(id(t) for t in sources)
+    stamp = tuple((t.data_ptr(), t._version) for t in sources)
+    hit = _DERIVED.get(key)
+    dev = sources[0].device
+    if hit is not None and hit[1] == stamp and all(r() is t for r, t in zip(hit[0], sources)):
+        torch.cuda.current_stream(dev).wait_event(hit[3])  # made on another stream, possibly moments ago
+        return hit[2]
+    if len(_DERIVED) >= 512:
+        _DERIVED.clear()
+    value = make()
+    _DERIVED[key] = (tuple(weakref.ref(t) for t in sources), stamp, value, torch.cuda.current_stream(dev).record_event())
+    return value
+
 
 def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, generic: bool = False,
                   fused: bool = False) -> torch.Tensor:
@@ -128,7 +152,8 @@ def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, g
     if not generic and not fused and Cout in PROJECTED_COUT:
         W2 = W.reshape(Cout, Cin + 3)
         # a packed copy of the feature columns (rows of the Conv2d weight are Cin+3 floats: not 16-byte aligned)
-        P = linear(fea.reshape(B * N, Cin), W2[:, :Cin].contiguous(), bias)
+        Wf = _derived("feature-columns", (W,), lambda: W2[:, :Cin].contiguous())
+        P = linear(fea.reshape(B * N, Cin), Wf, bias)
         _lib.check(lib.dpm_group_gather_ln_max(_ptr(P), _ptr(xyz), _ptr(centers), _ptr(idx), W2.data_ptr() + 4 * Cin,
                                                Cin + 3, _ptr(gamma), _ptr(beta), B, N, S, K, Cout, float(radius),
                                                _ptr(out), _stream(fea)), "dpm_group_gather_ln_max")
@@ -159,8 +184,9 @@ def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radi
     out = torch.empty(B, S, Cout, device=xyz.device, dtype=torch.float32)
     if not fused and Cout in (32, 64, 128):
         W2 = W.reshape(Cout, Cin + 3)
-        A = linear(W2[:, :Cin], W0.reshape(Cin, 3).t().contiguous())                       # (Cout,3) = W_f W0
-        cvec = linear(W2[:, :Cin], b0.reshape(1, Cin), residual=bias.reshape(Cout, 1))    # (Cout,1) = W_f b0 + b
+        A, cvec = _derived("affine-stage0", (W, W0, b0, bias), lambda: (
+            linear(W2[:, :Cin], W0.reshape(Cin, 3).t().contiguous()),                     # (Cout,3) = W_f W0
+            linear(W2[:, :Cin], b0.reshape(1, Cin), residual=bias.reshape(Cout, 1))))     # (Cout,1) = W_f b0 + b
         _lib.check(_lib.load().dpm_group_affine_ln_max(_ptr(A), _ptr(cvec), _ptr(xyz), _ptr(centers), _ptr(idx),
                                                        W2.data_ptr() + 4 * Cin, Cin + 3, _ptr(gamma), _ptr(beta), B, N, S,
                                                        K, Cout, float(radius), _ptr(out), _stream(xyz)),

@@ -296,6 +296,39 @@ def test_group_mlp_from_xyz_equals_materialised_features(ops):
         torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
+def test_weight_derived_tensors_follow_the_weights(ops):
+    """ops caches what depends on weights alone (packed feature columns, the stage-0 affine map).  In-place updates,
+    and a new weight tensor that lands on a freed one's address, must both be seen."""
+    gen = torch.Generator().manual_seed(29)
+    B, N, S, K, Cin, Cout = 1, 600, 50, 16, 16, 32
+    d = lambda t: t.to(DEV)
+    xyz, fea = d(torch.rand(B, N, 3, generator=gen)), d(torch.randn(B, N, Cin, generator=gen))
+    ctr, idx = xyz[:, :S].contiguous(), d(torch.randint(0, N, (B, S, K), generator=gen).int())
+    bias, gm, bt = d(torch.randn(Cout, generator=gen) * 0.1), d(1 + 0.1 * torch.randn(Cout, generator=gen)), d(0.1 * torch.randn(Cout, generator=gen))
+    W0, b0 = d(torch.randn(Cin, 3, 1, generator=gen)), d(torch.randn(Cin, generator=gen) * 0.1)
+
+    def both(W):
+        a = ops.group_mlp_max(xyz, fea, ctr, idx, W, bias, gm, bt, 0.3)
+        torch.testing.assert_close(a, ops.group_mlp_max(xyz, fea, ctr, idx, W, bias, gm, bt, 0.3, generic=True), rtol=1e-4, atol=1e-4)
+        b = ops.group_mlp_max_from_xyz(xyz, W0, b0, ctr, idx, W, bias, gm, bt, 0.3)
+        torch.testing.assert_close(b, ops.group_mlp_max_from_xyz(xyz, W0, b0, ctr, idx, W, bias, gm, bt, 0.3, fused=True), rtol=1e-4, atol=1e-4)
+        return a.clone(), b.clone()
+
+    W = d(torch.randn(Cout, Cin + 3, 1, 1, generator=gen) / 4)
+    a0, b0_ = both(W)
+    a1, b1 = both(W)                         # second call: served from the cache
+    assert torch.equal(a0, a1) and torch.equal(b0_, b1)
+    W.mul_(-1.5)                             # in-place update (an optimiser step, load_state_dict)
+    a2, _ = both(W)
+    assert not torch.allclose(a0, a2)
+    b0.add_(0.25)                            # any of the sources
+    both(W)
+    for _ in range(3):                       # a fresh tensor, most likely at the freed one's address
+        del W
+        W = d(torch.randn(Cout, Cin + 3, 1, 1, generator=gen) / 4)
+        both(W)
+
+
 def test_prepare_and_channel_first(ops):
     gen = torch.Generator().manual_seed(5)
     pts = torch.randn(3, 4, 1000, generator=gen)
