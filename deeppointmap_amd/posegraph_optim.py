@@ -1,0 +1,309 @@
+"""Pose-graph optimisation for the SLAM back end.
+
+Replaces the open3d calls of PoseGraph.__optim_open3d (reference system/modules/pose_graph.py:565-613):
+`o3d.pipelines.registration.global_optimization(graph, GlobalOptimizationLevenbergMarquardt(),
+GlobalOptimizationConvergenceCriteria(), GlobalOptimizationOption(edge_prune_threshold=0.0,
+preference_loop_closure=2.0, reference_node=...))` on a graph whose edges are all `uncertain=False`
+(pose_graph.py:597), and the g2o writer PoseGraph.to_g2o_file (pose_graph.py:821-842).
+
+open3d (pinned 0.16.0, requirements.txt:15) is a third-party dependency that is absent here, so this is a
+restatement of its published algorithm (cpp/open3d/pipelines/registration/GlobalOptimization.cpp) -- PARITY
+UNPINNED against open3d itself; tests/test_posegraph_optim.py pins it against an independent least-squares solver
+on the same objective (oracle/dpm_oracle.py::pose_graph_least_squares) and against closed-form cases.
+
+  * node i has a 4x4 pose T_i (scan frame -> world); edge (s, t) carries X = the measured transform taking source-
+    scan coordinates into the target scan's frame, and a 6x6 information matrix (rotation block first);
+  * residual of an edge: e = vec6(X^-1 T_t^-1 T_s), vec6 = (rx, ry, rz from R = Rz Ry Rx, translation);
+  * objective: sum_e e^T Lambda e (every edge certain: no line processes, nothing to prune -- the second
+    optimisation pass open3d runs after pruning starts from the first pass's result with the same edges);
+  * Levenberg-Marquardt on left-multiplicative pose updates T_i <- expm6(delta_i) T_i with open3d's linearised
+    Jacobians, damping lambda = 1e-5 max diag(H) initially and the Nielsen update (scale by
+    max(1/3, min(2/3, 1-(2 rho-1)^3)) on success, by 2, 4, 8... on failure);
+  * no node is held fixed during the iterations (the damping fixes the gauge); afterwards every pose is multiplied
+    by the transform that puts the reference node back where it started.
+
+The problem is small (one 6-vector per keyframe), so this is host code: the block-sparse normal equations go
+through scipy's sparse LU (dense Cholesky below 3000 unknowns).  Nothing here touches the GPU.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Sequence, Tuple
+
+import numpy as np
+import scipy.linalg
+import scipy.sparse
+import scipy.sparse.linalg
+
+
+@dataclass
+class ConvergenceCriteria:
+    """Defaults of open3d's GlobalOptimizationConvergenceCriteria."""
+    max_iteration: int = 100
+    min_relative_increment: float = 1e-6
+    min_relative_residual_increment: float = 1e-6
+    min_right_term: float = 1e-6
+    min_residual: float = 1e-6
+    max_iteration_lm: int = 20
+    upper_scale_factor: float = 2.0 / 3.0
+    lower_scale_factor: float = 1.0 / 3.0
+
+
+def transform_to_vec6(T: np.ndarray) -> np.ndarray:
+    """4x4 -> (rx, ry, rz, tx, ty, tz) with R = Rz(rz) Ry(ry) Rx(rx) (open3d TransformMatrix4dToVector6d)."""
+    R = T[:3, :3]
+    sy = math.sqrt(R[0, 0] * R[0, 0] + R[1, 0] * R[1, 0])
+    if sy >= 1e-6:
+        rx, ry, rz = math.atan2(R[2, 1], R[2, 2]), math.atan2(-R[2, 0], sy), math.atan2(R[1, 0], R[0, 0])
+    else:
+        rx, ry, rz = math.atan2(-R[1, 2], R[1, 1]), math.atan2(-R[2, 0], sy), 0.0
+    return np.array([rx, ry, rz, T[0, 3], T[1, 3], T[2, 3]], dtype=np.float64)
+
+
+def vec6_to_transform(v: Sequence[float]) -> np.ndarray:
+    """Inverse of transform_to_vec6 (open3d TransformVector6dToMatrix4d)."""
+    cx, sx, cy, sy, cz, sz = math.cos(v[0]), math.sin(v[0]), math.cos(v[1]), math.sin(v[1]), math.cos(v[2]), math.sin(v[2])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=np.float64)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=np.float64)
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=np.float64)
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = v[3:6]
+    return T
+
+
+def _inv(T: np.ndarray) -> np.ndarray:
+    out = np.eye(4)
+    out[:3, :3] = T[:3, :3].T
+    out[:3, 3] = -T[:3, :3].T @ T[:3, 3]
+    return out
+
+
+def _generators() -> np.ndarray:
+    G = np.zeros((6, 4, 4))
+    G[0, 1, 2], G[0, 2, 1] = -1, 1
+    G[1, 2, 0], G[1, 0, 2] = -1, 1
+    G[2, 0, 1], G[2, 1, 0] = -1, 1
+    G[3, 0, 3] = G[4, 1, 3] = G[5, 2, 3] = 1
+    return G
+
+
+_G = _generators()
+
+
+def _linearized(M: np.ndarray) -> np.ndarray:
+    """First-order vec6 of a near-identity-derivative matrix (open3d GetLinearized6DVector), batched over axis 0."""
+    return np.stack([(-M[..., 1, 2] + M[..., 2, 1]) / 2, (-M[..., 2, 0] + M[..., 0, 2]) / 2,
+                     (-M[..., 0, 1] + M[..., 1, 0]) / 2, M[..., 0, 3], M[..., 1, 3], M[..., 2, 3]], axis=-1)
+
+
+class _Graph:
+    def __init__(self, poses: np.ndarray, edges):
+        self.poses = np.array(poses, dtype=np.float64).reshape(-1, 4, 4).copy()
+        self.src = np.array([e[0] for e in edges], dtype=np.int64)
+        self.dst = np.array([e[1] for e in edges], dtype=np.int64)
+        self.Xinv = np.stack([_inv(np.asarray(e[2], dtype=np.float64)) for e in edges]) if len(edges) else np.zeros((0, 4, 4))
+        self.info = np.stack([np.asarray(e[3], dtype=np.float64).reshape(6, 6) for e in edges]) if len(edges) else np.zeros((0, 6, 6))
+        n = self.poses.shape[0]
+        if len(edges) and (self.src.min() < 0 or self.dst.min() < 0 or self.src.max() >= n or self.dst.max() >= n):
+            raise ValueError("edge endpoint outside the node list")
+
+    def zeta(self, poses: np.ndarray) -> np.ndarray:
+        """(E,6) misalignment vectors."""
+        out = np.empty((self.src.size, 6))
+        for k in range(self.src.size):
+            out[k] = transform_to_vec6(self.Xinv[k] @ _inv(poses[self.dst[k]]) @ poses[self.src[k]])
+        return out
+
+    def residual(self, z: np.ndarray) -> float:
+        return float(np.einsum("ei,eij,ej->", z, self.info, z))
+
+    def linear_system(self, poses: np.ndarray, z: np.ndarray):
+        """Block-sparse H (6n x 6n, CSC) and b of the Gauss-Newton step (open3d ComputeLinearSystem)."""
+        n, E = poses.shape[0], self.src.size
+        Js = np.empty((E, 6, 6))
+        for k in range(E):
+            A = self.Xinv[k] @ _inv(poses[self.dst[k]])          # (4,4)
+            B = poses[self.src[k]]
+            Js[k] = _linearized(A[None] @ _G @ B[None]).T        # column i = derivative along generator i
+        Jt = -Js
+        JsI = np.einsum("eji,ejk->eik", Js, self.info)           # Js^T Lambda
+        JtI = -JsI
+        blocks = {(0, 0): np.einsum("eij,ejk->eik", JsI, Js), (0, 1): np.einsum("eij,ejk->eik", JsI, Jt),
+                  (1, 0): np.einsum("eij,ejk->eik", JtI, Js), (1, 1): np.einsum("eij,ejk->eik", JtI, Jt)}
+        ends = (self.src, self.dst)
+        rows, cols, vals = [], [], []
+        ii, jj = np.meshgrid(np.arange(6), np.arange(6), indexing="ij")
+        for (a, c), blk in blocks.items():
+            rows.append((ends[a][:, None, None] * 6 + ii[None]).ravel())
+            cols.append((ends[c][:, None, None] * 6 + jj[None]).ravel())
+            vals.append(blk.ravel())
+        H = scipy.sparse.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                                    shape=(6 * n, 6 * n)).tocsc()
+        b = np.zeros(6 * n)
+        np.subtract.at(b.reshape(n, 6), self.src, np.einsum("eij,ej->ei", JsI, z))
+        np.subtract.at(b.reshape(n, 6), self.dst, np.einsum("eij,ej->ei", JtI, z))
+        return H, b
+
+
+DENSE_LIMIT = 3000  # unknowns up to which (H + lambda I) is factorised densely
+
+
+def _solve_damped(H, lam: float, b: np.ndarray) -> np.ndarray:
+    n = H.shape[0]
+    if n <= DENSE_LIMIT:
+        A = H.toarray()
+        A[np.diag_indices(n)] += lam
+        try:
+            return scipy.linalg.cho_solve(scipy.linalg.cho_factor(A, lower=True, check_finite=False), b, check_finite=False)
+        except scipy.linalg.LinAlgError:
+            return scipy.linalg.solve(A, b, assume_a="sym")
+    return scipy.sparse.linalg.splu((H + lam * scipy.sparse.identity(n, format="csc")).tocsc()).solve(b)
+
+
+def _levenberg_marquardt(g: _Graph, crit: ConvergenceCriteria) -> Tuple[np.ndarray, dict]:
+    poses = g.poses
+    n = poses.shape[0]
+    stats = dict(iterations=0, residual_start=0.0, residual=0.0)
+    if g.src.size == 0 or n == 0:
+        return poses, stats
+    z = g.zeta(poses)
+    cur = g.residual(z)
+    stats["residual_start"] = stats["residual"] = cur
+    x = np.concatenate([transform_to_vec6(T) for T in poses])
+    H, b = g.linear_system(poses, z)
+    lam = 1e-5 * float(H.diagonal().max())
+    ni, rho = 2.0, 0.0
+    stop = float(np.abs(b).max()) < crit.min_right_term
+    it = 0
+    while not stop:
+        lm = 0
+        while True:
+            delta = _solve_damped(H, lam, b)
+            stop = stop or float(np.linalg.norm(delta)) < crit.min_relative_increment * (float(np.linalg.norm(x)) + crit.min_relative_increment)
+            if not stop:
+                new_poses = np.stack([vec6_to_transform(delta[6 * i:6 * i + 6]) @ poses[i] for i in range(n)])
+                z_new = g.zeta(new_poses)
+                new = g.residual(z_new)
+                rho = (cur - new) / (float(delta @ (lam * delta + b)) + 1e-3)
+                if rho > 0:
+                    stop = stop or (cur - new) < crit.min_relative_residual_increment * cur
+                    if stop:
+                        break
+                    alpha = min(1.0 - (2.0 * rho - 1.0) ** 3, crit.upper_scale_factor)
+                    lam *= max(crit.lower_scale_factor, alpha)
+                    ni = 2.0
+                    cur, z, poses = new, z_new, new_poses
+                    x = np.concatenate([transform_to_vec6(T) for T in poses])
+                    H, b = g.linear_system(poses, z)
+                    stop = stop or float(np.abs(b).max()) < crit.min_right_term
+                    if stop:
+                        break
+                else:
+                    lam *= ni
+                    ni *= 2.0
+            lm += 1
+            stop = stop or lm >= crit.max_iteration_lm
+            if rho > 0 or stop:
+                break
+        it += 1
+        stop = stop or cur < crit.min_residual or it >= crit.max_iteration
+    stats["iterations"], stats["residual"] = it, cur
+    return poses, stats
+
+
+def global_optimization(poses, edges: Iterable[Tuple[int, int, np.ndarray, np.ndarray]], reference_node: int = 0,
+                        criteria: ConvergenceCriteria = None, uncertain: Sequence[bool] = None,
+                        return_stats: bool = False):
+    """poses (n,4,4) node poses; edges = (source_id, target_id, transformation 4x4, information 6x6) exactly as the
+    reference fills o3d PoseGraphEdge (pose_graph.py:589-596: transformation = inv(edge.SE3)).  Returns the refined
+    (n,4,4) float64 poses with node `reference_node` unchanged.  Only certain edges are supported -- the one
+    configuration the reference uses."""
+    if uncertain is not None and any(bool(u) for u in uncertain):
+        raise NotImplementedError("uncertain edges (line processes) are never produced by the reference (pose_graph.py:597)")
+    edges = list(edges)
+    g = _Graph(np.asarray(poses), edges)
+    n = g.poses.shape[0]
+    if not 0 <= reference_node < max(n, 1):
+        raise ValueError("reference_node outside the node list")
+    crit = criteria or ConvergenceCriteria()
+    original = g.poses.copy()
+    first, s1 = _levenberg_marquardt(g, crit)
+    g.poses = first                      # second pass of open3d's GlobalOptimization: same edges (nothing to prune)
+    second, s2 = _levenberg_marquardt(g, crit)
+    if n:
+        comp = original[reference_node] @ _inv(second[reference_node])
+        second = comp[None] @ second
+        second[reference_node] = original[reference_node]   # comp @ pose is the original up to rounding: keep it exact
+    if return_stats:
+        return second, dict(first=s1, second=s2)
+    return second
+
+
+def optimize_pose_graph(node_SE3: Dict[int, np.ndarray], edges: List[Tuple[int, int, np.ndarray, np.ndarray]],
+                        base_token: int = None):
+    """The body of PoseGraph.__optim_open3d on plain containers: node_SE3 {token: SE3_pred of a key-frame scan},
+    edges [(src_token, dst_token, edge.SE3, edge.information_mat)] (non-'locz' edges; edges touching a token that is
+    not a key-frame are skipped, as at pose_graph.py:588-599).  -> ({token: refined 4x4 float32}, mean translation
+    change), the values the reference writes back (pose_graph.py:605-617)."""
+    tokens = list(node_SE3.keys())
+    index = {t: i for i, t in enumerate(tokens)}
+    base = min(tokens) if base_token is None else base_token
+    poses = np.stack([np.asarray(node_SE3[t], dtype=np.float64) for t in tokens]) if tokens else np.zeros((0, 4, 4))
+    packed = [(index[s], index[d], np.linalg.inv(np.asarray(T, dtype=np.float64)), np.asarray(info, dtype=np.float64))
+              for s, d, T, info in edges if s in index and d in index]
+    refined = global_optimization(poses, packed, reference_node=index[base]) if tokens else poses
+    out = {t: refined[i].astype(np.float32) for t, i in index.items()}
+    diff = [float(np.linalg.norm(poses[i][:3, 3].astype(np.float32) - out[t][:3, 3])) for t, i in index.items()]
+    return out, (sum(diff) / len(diff) if diff else 0.0)
+
+
+def _quat_xyzw(R: np.ndarray) -> np.ndarray:
+    """(x, y, z, w), through the same scipy call the reference makes (pose_graph.py:831,835)."""
+    from scipy.spatial.transform import Rotation
+    return Rotation.from_matrix(np.asarray(R, dtype=np.float64)).as_quat()
+
+
+def write_g2o(path: str, node_SE3: Dict[int, np.ndarray], edges: List[Tuple[int, int, np.ndarray, np.ndarray]]) -> None:
+    """PoseGraph.to_g2o_file (pose_graph.py:821-842): VERTEX_SE3:QUAT token x y z qx qy qz qw, then
+    EDGE_SE3:QUAT src dst x y z qx qy qz qw + the 21 upper-triangle information entries, row-major."""
+    with open(path, "w+") as f:
+        for token, T in node_SE3.items():
+            T = np.asarray(T, dtype=np.float64)
+            q = _quat_xyzw(T[:3, :3])
+            f.write(f"VERTEX_SE3:QUAT {token} {T[0, 3]} {T[1, 3]} {T[2, 3]} {q[0]} {q[1]} {q[2]} {q[3]} \n")
+        for s, d, T, info in edges:
+            T, info = np.asarray(T, dtype=np.float64), np.asarray(info, dtype=np.float64)
+            q = _quat_xyzw(T[:3, :3])
+            upper = " ".join(" ".join(str(info[i, j]) for j in range(i, 6)) + " " for i in range(6))
+            f.write(f"EDGE_SE3:QUAT {s} {d} {T[0, 3]} {T[1, 3]} {T[2, 3]} {q[0]} {q[1]} {q[2]} {q[3]} {upper}\n")
+
+
+def read_g2o(path: str):
+    """Inverse of write_g2o (for round-trip tests and for feeding external solvers' output back)."""
+    nodes, edges = {}, []
+
+    def pose(v):
+        x, y, z, qx, qy, qz, qw = v
+        T = np.eye(4)
+        T[:3, :3] = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                              [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                              [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+        T[:3, 3] = (x, y, z)
+        return T
+
+    with open(path) as f:
+        for line in f:
+            w = line.split()
+            if not w:
+                continue
+            if w[0] == "VERTEX_SE3:QUAT":
+                nodes[int(w[1])] = pose([float(v) for v in w[2:9]])
+            elif w[0] == "EDGE_SE3:QUAT":
+                vals = [float(v) for v in w[3:]]
+                info = np.zeros((6, 6))
+                info[np.triu_indices(6)] = vals[7:28]
+                info = info + np.triu(info, 1).T
+                edges.append((int(w[1]), int(w[2]), pose(vals[:7]), info))
+    return nodes, edges

@@ -580,3 +580,53 @@ def lowpass_filter(xyz: Tensor, normals_radius: float = 0.5, normals_num: int = 
     sim, _ = torch.topk(similarity, k=flux, dim=-1)
     sim = sim.sum(1)
     return sim > (sim.mean() - filter_std * sim.std()), sim
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Pose-graph optimisation (reference system/modules/pose_graph.py:565-613 calls
+# open3d.pipelines.registration.global_optimization, open3d 0.16.0 -- absent here: PARITY UNPINNED).
+# Independent checker of deeppointmap_amd/posegraph_optim.py: the same objective
+#     sum_e  vec6(X_e^-1 T_t^-1 T_s)^T  Lambda_e  vec6(...)
+# handed to scipy's trust-region least squares over a GLOBAL Euler+translation parametrisation of every node
+# except the reference -- different parametrisation, different Jacobians (finite differences), different solver.
+# ---------------------------------------------------------------------------------------------------------
+def _pg_vec6(T):
+    R = T[:3, :3]
+    sy = math.sqrt(R[0, 0] ** 2 + R[1, 0] ** 2)
+    if sy >= 1e-6:
+        r = (math.atan2(R[2, 1], R[2, 2]), math.atan2(-R[2, 0], sy), math.atan2(R[1, 0], R[0, 0]))
+    else:
+        r = (math.atan2(-R[1, 2], R[1, 1]), math.atan2(-R[2, 0], sy), 0.0)
+    return np.array([r[0], r[1], r[2], T[0, 3], T[1, 3], T[2, 3]])
+
+
+def _pg_mat(v):
+    from scipy.spatial.transform import Rotation
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_euler("xyz", v[:3]).as_matrix()   # extrinsic x, y, z  ==  Rz Ry Rx
+    T[:3, 3] = v[3:6]
+    return T
+
+
+def pose_graph_least_squares(poses, edges, reference_node: int = 0):
+    """poses (n,4,4); edges [(s, t, X 4x4, info 6x6)] -> refined (n,4,4) with the reference node held fixed."""
+    import scipy.optimize
+    poses = np.asarray(poses, dtype=np.float64)
+    n = poses.shape[0]
+    free = [i for i in range(n) if i != reference_node]
+    chol = [np.linalg.cholesky(np.asarray(e[3], dtype=np.float64) + 1e-12 * np.eye(6)).T for e in edges]  # e^T L e = |U e|^2
+    Xinv = [np.linalg.inv(np.asarray(e[2], dtype=np.float64)) for e in edges]
+
+    def unpack(p):
+        T = poses.copy()
+        for k, i in enumerate(free):
+            T[i] = _pg_mat(p[6 * k:6 * k + 6])
+        return T
+
+    def fun(p):
+        T = unpack(p)
+        return np.concatenate([chol[k] @ _pg_vec6(Xinv[k] @ np.linalg.inv(T[e[1]]) @ T[e[0]]) for k, e in enumerate(edges)])
+
+    p0 = np.concatenate([_pg_vec6(poses[i]) for i in free]) if free else np.zeros(0)
+    sol = scipy.optimize.least_squares(fun, p0, method="trf", xtol=1e-14, ftol=1e-14, gtol=1e-12, x_scale="jac")
+    return unpack(sol.x), float(2 * sol.cost)
