@@ -45,14 +45,31 @@ __device__ __forceinline__ float sqdist(float sx, float sy, float sz, float x, f
 // read after the kernel), so only the LDS exchange needs ordering.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// max / min over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane of the row gets the result
-__device__ __forceinline__ float row16_max_f(float v) {
-    v = fmaxf(v, __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v))));
+// Squared distances are >= +0 and the "must not win" sentinel is -1, and on that domain the order of the floats
+// is the order of their bit patterns as signed integers.  Integer max needs no NaN canonicalisation, so each
+// reduction step is ONE v_max_i32 with a DPP operand instead of mov_dpp + two v_max_f32.
+// The instruction is written out: from update_dpp the compiler builds copy + s_nop + mov_dpp + max per step.
+// s_nop 1 = the two wait states a DPP operand needs after the VALU write of its register (each step reads the
+// previous step's result; the first one covers whatever produced v).
+#define DPM_IMAX_STEP(ctrl) "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctrl " bank_mask:0xf\n\t"
+#define DPM_IMAX_ROW                                                                              \
+    DPM_IMAX_STEP("quad_perm:[1,0,3,2] row_mask:0xf") DPM_IMAX_STEP("quad_perm:[2,3,0,1] row_mask:0xf") \
+    DPM_IMAX_STEP("row_half_mirror row_mask:0xf") DPM_IMAX_STEP("row_mirror row_mask:0xf")
+__device__ __forceinline__ int imax_dpp_row(int v) {
+    asm(DPM_IMAX_ROW "s_nop 0" : "+v"(v));
     return v;
 }
+// max / min over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane of the row gets the result
+__device__ __forceinline__ float row16_max_f(float v) { return __int_as_float(imax_dpp_row(__float_as_int(v))); }
+// wave-wide max of such values (wave-uniform result): rows 1,3 take row 0,2's last lane, rows 2,3 take lane 31's
+__device__ __forceinline__ float wave_max_ordered(float v) {
+    int i = __float_as_int(v);
+    asm(DPM_IMAX_ROW DPM_IMAX_STEP("row_bcast:15 row_mask:0xa") DPM_IMAX_STEP("row_bcast:31 row_mask:0xc") "s_nop 0"
+        : "+v"(i));
+    return __int_as_float(__builtin_amdgcn_readlane(i, 63));
+}
+#undef DPM_IMAX_ROW
+#undef DPM_IMAX_STEP
 __device__ __forceinline__ int row16_min_i(int v) {
     v = min(v, dpp_i<0xB1, 0xF>(v));
     v = min(v, dpp_i<0x4E, 0xF>(v));
@@ -69,7 +86,7 @@ __device__ __forceinline__ int row16_min_i(int v) {
 
 // lane holding the wave's best (largest v; among equal v the smallest idx).  Lanes that must not win pass v < 0.
 __device__ __forceinline__ int wave_argbest(float v, int idx, float &vmax) {
-    vmax = wave_max_dpp(v);
+    vmax = wave_max_ordered(v);
     unsigned long long eq = __ballot(v == vmax);
     if (__popcll(eq) > 1) {  // ties are rare: break them by the smallest original index
         const int imin = wave_min_dpp((v == vmax) ? idx : 0x7fffffff);
@@ -289,8 +306,9 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                                                         int32_t *__restrict__ new_len) {
     constexpr int NW = FB / 64;
     constexpr int OB = 2048;  // picks buffered in LDS between flushes to global memory
-    __shared__ float s_rv[2][NW], s_rx[2][NW], s_ry[2][NW], s_rz[2][NW];
-    __shared__ int s_ri[2][NW];
+    // per-wave bests, double-buffered by round parity: [parity][value, index bits, x, y, z][wave] in ONE block, so
+    // a wave's five fields are one address plus immediate offsets
+    __shared__ float s_ex[2][5][NW];
     __shared__ int s_oidx[OB];
     __shared__ float s_oxyz[OB][3];
 
@@ -340,8 +358,10 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
         //      (s - clamp(s)) reproduces (s - x) monotonically, so box distance <= every point distance
         bool act = false;
         if (mine) {
-            const float cx = fminf(fmaxf(sx, bx0), bx1), cy = fminf(fmaxf(sy, by0), by1),
-                        cz = fminf(fmaxf(sz, bz0), bz1);
+            // clamp(s, lo, hi) as ONE v_med3_f32 (lo <= hi: the median is the clamp; fminf(fmaxf()) costs a NaN
+            // canonicalisation per operand on top of the two instructions)
+            const float cx = __builtin_amdgcn_fmed3f(sx, bx0, bx1), cy = __builtin_amdgcn_fmed3f(sy, by0, by1),
+                        cz = __builtin_amdgcn_fmed3f(sz, bz0, bz1);
             act = sqdist(sx, sy, sz, cx, cy, cz) < bmax;
         }
         unsigned long long m = __ballot(act);
@@ -378,8 +398,9 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                 float v0 = -1.f;
                 if (ok0) {
                     const float d = sqdist(sx, sy, sz, p0.x, p0.y, p0.z);
-                    if (d < c0) closest[q0] = d;
-                    v0 = fminf(d, c0);
+                    const bool lt = d < c0;
+                    if (lt) closest[q0] = d;
+                    v0 = lt ? d : c0;
                 }
                 float vmax;
                 const int L = wave_argbest(v0, o0, vmax);
@@ -393,8 +414,9 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                 float v1 = -1.f;
                 if (ok1) {
                     const float d = sqdist(sx, sy, sz, p1.x, p1.y, p1.z);
-                    if (d < c1) closest[q1] = d;
-                    v1 = fminf(d, c1);
+                    const bool lt = d < c1;
+                    if (lt) closest[q1] = d;
+                    v1 = lt ? d : c1;
                 }
                 float vmax;
                 const int L = wave_argbest(v1, o1, vmax);
@@ -406,23 +428,27 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
         } while (m);
         FPS_T(1);
         const int par = r & 1;
-        if (lane == 0) s_rv[par][w] = wv, s_ri[par][w] = wi, s_rx[par][w] = wbx, s_ry[par][w] = wby, s_rz[par][w] = wbz;
+        if (lane == 0) {
+            float *ex = &s_ex[par][0][w];
+            ex[0] = wv, ex[NW] = __int_as_float(wi), ex[2 * NW] = wbx, ex[3 * NW] = wby, ex[4 * NW] = wbz;
+        }
         FPS_T(2);
         lds_barrier();
         FPS_T(3);
         // cross-wave arg-max: lane reads entry (lane & 15), 16-lane row reduction, winner's fields by broadcast reads
         const int e = lane & (NW - 1);
-        const float ev = s_rv[par][e];
+        const float ev = s_ex[par][0][e];
         const float gv = row16_max_f(ev);
         unsigned eqm = (unsigned)(__ballot(ev == gv) & 0xFFFFull);
         if (__popc(eqm) > 1) {  // equal maxima in different waves: smallest original index wins
-            const int ei = s_ri[par][e];
+            const int ei = __float_as_int(s_ex[par][1][e]);
             const int imin = row16_min_i(ev == gv ? ei : 0x7fffffff);
             eqm = (unsigned)(__ballot(ev == gv && ei == imin) & 0xFFFFull);
         }
         const int gw = __builtin_ctz(eqm);
-        const int gi = s_ri[par][gw];
-        sx = s_rx[par][gw], sy = s_ry[par][gw], sz = s_rz[par][gw];
+        const float *gx = &s_ex[par][1][gw];
+        const int gi = __float_as_int(gx[0]);
+        sx = gx[NW], sy = gx[2 * NW], sz = gx[3 * NW];
         if (t == 0) {
             const int o = r & (OB - 1);
             s_oidx[o] = gi, s_oxyz[o][0] = sx, s_oxyz[o][1] = sy, s_oxyz[o][2] = sz;
