@@ -342,12 +342,15 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
         new_xyz[0] = xyz[0], new_xyz[1] = xyz[1], new_xyz[2] = xyz[2];
         new_len[b] = max(kn, 1);
     }
-    float bmax = __builtin_inff();  // every closest distance starts at +inf
+    // every closest distance starts at +inf; lanes without a bucket hold the "cannot win" value for good, which also
+    // fails every box test below (no distance is < -1), so the round loop needs no `mine` masks
+    float bmax = mine ? __builtin_inff() : -1.f;
     int bidx = 0x7fffffff;
     float wx = 0.f, wy = 0.f, wz = 0.f;  // coordinates of this bucket's current best point
     float sx = xyz[0], sy = xyz[1], sz = xyz[2];
     float wv = -1.f, wbx = 0.f, wby = 0.f, wbz = 0.f;  // this wave's best over ALL its buckets, valid across rounds
     int wi = 0x7fffffff;
+    int wl = 0;  // the bucket slot (lane) that holds the wave's best
 
 #ifdef DPM_FPS_STATS
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = clock64();
@@ -356,15 +359,15 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
         FPS_T(5);
         // ---- which of my wave's buckets can change?  box distance with the point-distance expression:
         //      (s - clamp(s)) reproduces (s - x) monotonically, so box distance <= every point distance
-        bool act = false;
-        if (mine) {
-            // clamp(s, lo, hi) as ONE v_med3_f32 (lo <= hi: the median is the clamp; fminf(fmaxf()) costs a NaN
-            // canonicalisation per operand on top of the two instructions)
-            const float cx = __builtin_amdgcn_fmed3f(sx, bx0, bx1), cy = __builtin_amdgcn_fmed3f(sy, by0, by1),
-                        cz = __builtin_amdgcn_fmed3f(sz, bz0, bz1);
-            act = sqdist(sx, sy, sz, cx, cy, cz) < bmax;
-        }
+        // clamp(s, lo, hi) as ONE v_med3_f32 (lo <= hi: the median is the clamp; fminf(fmaxf()) costs a NaN
+        // canonicalisation per operand on top of the two instructions)
+        const float cx = __builtin_amdgcn_fmed3f(sx, bx0, bx1), cy = __builtin_amdgcn_fmed3f(sy, by0, by1),
+                    cz = __builtin_amdgcn_fmed3f(sz, bz0, bz1);
+        const bool act = sqdist(sx, sy, sz, cx, cy, cz) < bmax;
         unsigned long long m = __ballot(act);
+        // Bucket maxima only ever fall.  If the bucket that held this wave's best is not touched this round, the
+        // wave's best is what it was -- whatever happens to the touched ones -- and nothing needs re-deriving.
+        const bool keep = wv >= 0.f && ((m >> wl) & 1ull) == 0;
         FPS_T(0);
 #ifdef DPM_FPS_STATS
         if (lane == 0 && m) atomicAdd(&((unsigned long long *)pts_all)[-1 - (b & 0)], (unsigned long long)__popcll(m)), atomicMax(&((int *)pts_all)[-4], __popcll(m));
@@ -387,12 +390,12 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
             float c0 = 0.f, c1 = 0.f;
             if (ok0) p0 = pts[q0], c0 = closest[q0];
             if (ok1) p1 = pts[q1], c1 = closest[q1];
-            if (first) {
+            if (first && !keep) {
                 // ... and while they are in flight: the best among this wave's UNCHANGED buckets
-                const int L = wave_argbest((mine && !act) ? bmax : -1.f, bidx, wv);
-                wi = lane_i(bidx, L), wbx = lane_f(wx, L), wby = lane_f(wy, L), wbz = lane_f(wz, L);
-                first = false;
+                wl = wave_argbest(act ? -1.f : bmax, bidx, wv);
+                wi = lane_i(bidx, wl), wbx = lane_f(wx, wl), wby = lane_f(wy, wl), wbz = lane_f(wz, wl);
             }
+            first = false;
             if (one) {
                 const int o0 = ok0 ? __float_as_int(p0.w) : 0x7fffffff;
                 float v0 = -1.f;
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                 const int bi = lane_i(o0, L);
                 const float px = lane_f(p0.x, L), py = lane_f(p0.y, L), pz = lane_f(p0.z, L);
                 if (lane == l0) bmax = vmax, bidx = bi, wx = px, wy = py, wz = pz;
-                if (vmax > wv || (vmax == wv && bi < wi)) wv = vmax, wi = bi, wbx = px, wby = py, wbz = pz;
+                if (!keep && (vmax > wv || (vmax == wv && bi < wi))) wv = vmax, wi = bi, wbx = px, wby = py, wbz = pz, wl = l0;
             }
             if (two) {
                 const int o1 = ok1 ? __float_as_int(p1.w) : 0x7fffffff;
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                 const int bi = lane_i(o1, L);
                 const float px = lane_f(p1.x, L), py = lane_f(p1.y, L), pz = lane_f(p1.z, L);
                 if (lane == l1) bmax = vmax, bidx = bi, wx = px, wy = py, wz = pz;
-                if (vmax > wv || (vmax == wv && bi < wi)) wv = vmax, wi = bi, wbx = px, wby = py, wbz = pz;
+                if (!keep && (vmax > wv || (vmax == wv && bi < wi))) wv = vmax, wi = bi, wbx = px, wby = py, wbz = pz, wl = l1;
             }
         } while (m);
         FPS_T(1);
