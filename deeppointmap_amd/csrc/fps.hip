@@ -386,10 +386,11 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
             if (two) m &= m - 1;
             const int q0 = (l0 * NW + w) * 64 + lane, q1 = (l1 * NW + w) * 64 + lane;
             const bool ok0 = one && q0 < len, ok1 = two && q1 < len;
-            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-            float c0 = 0.f, c1 = 0.f;
-            if (ok0) p0 = pts[q0], c0 = closest[q0];
-            if (ok1) p1 = pts[q1], c1 = closest[q1];
+            // unconditional loads from a clamped slot (a ragged last bucket re-reads the frame's last point; its
+            // lanes are masked out of the values below): no exec-mask juggling around the four loads
+            const int q0c = min(q0, len - 1), q1c = min(q1, len - 1);
+            const float4 p0 = pts[q0c], p1 = pts[q1c];
+            const float c0 = closest[q0c], c1 = closest[q1c];
             if (first && !keep) {
                 // ... and while they are in flight: the best among this wave's UNCHANGED buckets
                 wl = wave_argbest(act ? -1.f : bmax, bidx, wv);
@@ -398,13 +399,10 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
             first = false;
             if (one) {
                 const int o0 = ok0 ? __float_as_int(p0.w) : 0x7fffffff;
-                float v0 = -1.f;
-                if (ok0) {
-                    const float d = sqdist(sx, sy, sz, p0.x, p0.y, p0.z);
-                    const bool lt = d < c0;
-                    if (lt) closest[q0] = d;
-                    v0 = lt ? d : c0;
-                }
+                const float d = sqdist(sx, sy, sz, p0.x, p0.y, p0.z);
+                const bool lt = ok0 && d < c0;
+                if (lt) closest[q0] = d;
+                const float v0 = lt ? d : (ok0 ? c0 : -1.f);
                 float vmax;
                 const int L = wave_argbest(v0, o0, vmax);
                 const int bi = lane_i(o0, L);
@@ -414,13 +412,10 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
             }
             if (two) {
                 const int o1 = ok1 ? __float_as_int(p1.w) : 0x7fffffff;
-                float v1 = -1.f;
-                if (ok1) {
-                    const float d = sqdist(sx, sy, sz, p1.x, p1.y, p1.z);
-                    const bool lt = d < c1;
-                    if (lt) closest[q1] = d;
-                    v1 = lt ? d : c1;
-                }
+                const float d = sqdist(sx, sy, sz, p1.x, p1.y, p1.z);
+                const bool lt = ok1 && d < c1;
+                if (lt) closest[q1] = d;
+                const float v1 = lt ? d : (ok1 ? c1 : -1.f);
                 float vmax;
                 const int L = wave_argbest(v1, o1, vmax);
                 const int bi = lane_i(o1, L);
