@@ -27,9 +27,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // plus a select, so the compiler issues the whole prefetch group back to back and waits for it only where the
 // values are written to LDS one K-tile later.  (With guarded loads it serialised the group behind s_waitcnt
 // vmcnt(0) and the HBM latency was exposed twice per K-tile.)
-template <bool VEC>
+// KFULL (K a multiple of the K-tile: every shape of the path): no k test at all -- with the select the compiler
+// sinks each load into an exec-masked branch of its own, one basic block per load.
+template <bool VEC, bool KFULL = false>
 __device__ __forceinline__ float4 load4(const float *__restrict__ base, int ld, int row, int rows, int k, int K) {
     const float *p = base + (size_t)min(row, rows - 1) * ld;
+    if (VEC && KFULL) return *reinterpret_cast<const float4 *>(p + k);
     if (VEC) {  // ld % 4 == 0, base 16-byte aligned, K % 4 == 0
         const float4 v = *reinterpret_cast<const float4 *>(p + min(k, K - 4));
         return k < K ? v : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -40,7 +43,7 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ base, int ld, 
     return v;
 }
 
-template <int BM, int BN, bool VEC, int KT = 32>
+template <int BM, int BN, bool VEC, int KT = 32, bool KFULL = false>
 __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restrict__ X, int ldx, long long sx,
                                                            const float *__restrict__ W, int ldw, long long sw,
                                                            const float *__restrict__ bias,
@@ -74,9 +77,9 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
 
     float4 xr[PX], wr[PW];
 #pragma unroll
-    for (int p = 0; p < PX; ++p) xr[p] = load4<VEC>(X, ldx, row0 + p * RPP + sr_, R, sk, Cin);
+    for (int p = 0; p < PX; ++p) xr[p] = load4<VEC, KFULL>(X, ldx, row0 + p * RPP + sr_, R, sk, Cin);
 #pragma unroll
-    for (int p = 0; p < PW; ++p) wr[p] = load4<VEC>(W, ldw, col0 + p * RPP + sr_, Cout, sk, Cin);
+    for (int p = 0; p < PW; ++p) wr[p] = load4<VEC, KFULL>(W, ldw, col0 + p * RPP + sr_, Cout, sk, Cin);
 
     for (int k0 = 0; k0 < Cin; k0 += KT) {
         // registers -> LDS (row stride 136 B: 8-byte aligned, so two 8-byte stores per float4)
@@ -93,9 +96,9 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
         __syncthreads();
         if (k0 + KT < Cin) {  // prefetch the next K-tile while this one is consumed
 #pragma unroll
-            for (int p = 0; p < PX; ++p) xr[p] = load4<VEC>(X, ldx, row0 + p * RPP + sr_, R, k0 + KT + sk, Cin);
+            for (int p = 0; p < PX; ++p) xr[p] = load4<VEC, KFULL>(X, ldx, row0 + p * RPP + sr_, R, k0 + KT + sk, Cin);
 #pragma unroll
-            for (int p = 0; p < PW; ++p) wr[p] = load4<VEC>(W, ldw, col0 + p * RPP + sr_, Cout, k0 + KT + sk, Cin);
+            for (int p = 0; p < PW; ++p) wr[p] = load4<VEC, KFULL>(W, ldw, col0 + p * RPP + sr_, Cout, k0 + KT + sk, Cin);
         }
         float a[2][MB], b[2][NB];
 #pragma unroll
@@ -329,15 +332,18 @@ extern "C" int dpm_linear_batched(const float *x, int ldx, long long sx, const f
     }
     const bool t64 = big >= 192 || (R > 1024 && Cout > 32);
     const dim3 grid = t64 ? dim3(dpm_cdiv(Cout, 64), dpm_cdiv(R, 64), batch) : dim3(dpm_cdiv(Cout, 32), dpm_cdiv(R, 32), batch);
-#define DPM_GEMM_LAUNCH(BM, BN, V)                                                                                  \
-    hipLaunchKernelGGL((gemm_nt_mfma_kernel<BM, BN, V>), grid, dim3(256), 0, st, x, ldx, sx, W, ldw, sw, bias, residual, \
-                       ldr, sr, out, ldo, so, R, Cin, Cout, act)
+#define DPM_GEMM_LAUNCH(BM, BN, V, KF)                                                                                \
+    hipLaunchKernelGGL((gemm_nt_mfma_kernel<BM, BN, V, 32, KF>), grid, dim3(256), 0, st, x, ldx, sx, W, ldw, sw, bias,   \
+                       residual, ldr, sr, out, ldo, so, R, Cin, Cout, act)
+    const bool kfull = vec && Cin % 32 == 0;
     if (t64) {
-        if (vec) DPM_GEMM_LAUNCH(64, 64, true);
-        else DPM_GEMM_LAUNCH(64, 64, false);
+        if (kfull) DPM_GEMM_LAUNCH(64, 64, true, true);
+        else if (vec) DPM_GEMM_LAUNCH(64, 64, true, false);
+        else DPM_GEMM_LAUNCH(64, 64, false, false);
     } else {
-        if (vec) DPM_GEMM_LAUNCH(32, 32, true);
-        else DPM_GEMM_LAUNCH(32, 32, false);
+        if (kfull) DPM_GEMM_LAUNCH(32, 32, true, true);
+        else if (vec) DPM_GEMM_LAUNCH(32, 32, true, false);
+        else DPM_GEMM_LAUNCH(32, 32, false, false);
     }
 #undef DPM_GEMM_LAUNCH
     return dpm_launch_status();
