@@ -252,7 +252,9 @@ def main():
                          "us_per_round": round(fps_ms * 1e3 / (cfg.encoder.npoint[0] - 1), 3),
                          "note": "FPS is a chain of 4095 dependent argmax rounds per frame, one CU per frame: latency-"
                                  "bound by construction (us_per_round is the figure that matters); traffic > algorithmic "
-                                 "bytes because each round re-reads the ~12 buckets the new point can change; see DESIGN.md"},
+                                 "bytes because each round re-reads the ~12 buckets the new point can change -- the "
+                                 "reference's loop re-reads the WHOLE frame every round (4095 x 65536 x 16 B = 4.3 GB "
+                                 "per frame, 275 GB per launch), the bucket pruning cuts that ~85x; see DESIGN.md"},
         }
         if gemm_ms > 0:
             tf = gemm_flops[0] / (gemm_ms * 1e-3) / 1e12
