@@ -389,8 +389,12 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
             // unconditional loads from a clamped slot (a ragged last bucket re-reads the frame's last point; its
             // lanes are masked out of the values below): no exec-mask juggling around the four loads
             const int q0c = min(q0, len - 1), q1c = min(q1, len - 1);
-            const float4 p0 = pts[q0c], p1 = pts[q1c];
-            const float c0 = closest[q0c], c1 = closest[q1c];
+            const float4 p0 = pts[q0c];
+            const float c0 = closest[q0c];
+            float4 p1;
+            float c1;
+            if (two) p1 = pts[q1c], c1 = closest[q1c];  // wave-uniform: a scalar branch; an unused load would still
+                                                        // have to be waited for before its registers are reused
             if (first && !keep) {
                 // ... and while they are in flight: the best among this wave's UNCHANGED buckets
                 wl = wave_argbest(act ? -1.f : bmax, bidx, wv);
