@@ -549,7 +549,9 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
     __shared__ float s_td[WPB][TMPN];
     __shared__ int s_ti[WPB][TMPN];
     const unsigned bid = xcd_chunked_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int b = bid / gridDim.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is wave-uniform, but the compiler only knows that through readfirstlane: with it the centre,
+    // its cell, the cell ranges and the chunk loop live in scalar registers (scalar loads, scalar loop control)
+    const int b = bid / gridDim.x, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int s = (bid % gridDim.x) * WPB + w;
     if (s >= S) return;
     if (reuse_idx) {
@@ -571,13 +573,15 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
     if (x0 <= x1) {
         for (int yy = max(cy - 1, 0); yy <= min(cy + 1, G.g - 1); ++yy) {
             const int lo = start[yy * G.g + x0], hi = start[yy * G.g + x1 + 1];
+            // unconditional loads from a clamped slot, the next chunk requested before the current one is offered
+            float4 p = lo < hi ? sorted[min(lo + lane, hi - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
             for (int base = lo; base < hi; base += 64) {
                 const int q = base + lane;
                 const bool ok = q < hi;
-                float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) p = sorted[q];
-                offer(c, ok, p.x, p.y, p.z, sq3(p.x, p.y, p.z), ok ? __float_as_int(p.w) : 0x7fffffff, K, (LdsF)s_d[w],
-                      (LdsI)s_i[w], (LdsF)s_td[w], (LdsI)s_ti[w]);
+                const float4 cur = p;
+                if (base + 64 < hi) p = sorted[min(q + 64, hi - 1)];
+                offer(c, ok, cur.x, cur.y, cur.z, sq3(cur.x, cur.y, cur.z), ok ? __float_as_int(cur.w) : 0x7fffffff, K,
+                      (LdsF)s_d[w], (LdsI)s_i[w], (LdsF)s_td[w], (LdsI)s_ti[w]);
             }
         }
     }
