@@ -38,21 +38,23 @@ constexpr int HD = 32;
 constexpr int RES_HDR = 20;  // floats before the inlier-confidence list in a Kabsch `result`
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// max / sum over the 16 lanes of a DPP row (lanes sharing lane>>4)
+// max / sum over the 16 lanes of a DPP row (lanes sharing lane>>4).  Written out as one DPP-operand instruction
+// per step: from update_dpp + fmaxf the compiler builds copy + s_nop + mov_dpp + canonicalise + max.  s_nop 1 = the
+// two wait states a DPP operand needs after the VALU write of its register.
+#define DPM_ROW16(op)                                                                                   \
+    "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                      \
+    "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                      \
+    "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                          \
+    "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 0"
 __device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v))));
+    asm(DPM_ROW16("v_max_f32_dpp") : "+v"(v));
     return v;
 }
 __device__ __forceinline__ float row16_sum(float v) {
-    v += __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v)));
-    v += __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v)));
-    v += __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v)));
-    v += __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v)));
+    asm(DPM_ROW16("v_add_f32_dpp") : "+v"(v));
     return v;
 }
+#undef DPM_ROW16
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
@@ -143,8 +145,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
                 sacc[j][q] = pv;
                 ps += pv;
             }
-            ps = row16_sum(ps);
-            lrow[q] = lrow[q] * corr + ps;
+            lrow[q] = lrow[q] * corr + ps;  // this lane's share of the row sum; the 16 shares meet once, at the end
             mrow[q] = nm;
             oacc[0][q] *= corr, oacc[1][q] *= corr;
         }
@@ -169,8 +170,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int m = q0 + (lane >> 4) * 4 + q;
+        const float total = row16_sum(lrow[q]);  // before the row test: every lane takes part in the exchange
         if (m >= M) continue;
-        const float inv = 1.f / lrow[q];
+        const float inv = 1.f / total;
         float *o = O + (size_t)b * so + (size_t)m * ldo + h * HD;
         o[lane & 15] = oacc[0][q] * inv;
         o[16 + (lane & 15)] = oacc[1][q] * inv;
