@@ -280,15 +280,17 @@ __global__ __launch_bounds__(256) void nn1_moments_kernel(PairArgs A, float r2) 
                 ++seg;
             }
             if (p >= e) break;
+            // branch-free body: an unconditional load from a clamped slot (p < e here, so e - 1 is a valid one) and
+            // selects; the lanes of a quad past the end of the segment re-read its last point and are masked out
             const int pp = p + ql;
             p += 4;
-            if (pp < e) {
-                const float4 t4 = sorted[pp];
-                const float dx = qx - t4.x, dy = qy - t4.y, dz = qz - t4.z;
-                const float d = (dx * dx + dy * dy) + dz * dz;
-                const int oi = __float_as_int(t4.w);
-                if (d < best || (d == best && oi < bi)) best = d, bi = oi, bx = t4.x, by = t4.y, bz = t4.z;
-            }
+            const float4 t4 = sorted[min(pp, e - 1)];
+            const float dx = qx - t4.x, dy = qy - t4.y, dz = qz - t4.z;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const int oi = __float_as_int(t4.w);
+            const bool take = (pp < e) & ((d < best) | ((d == best) & (oi < bi)));
+            best = take ? d : best, bi = take ? oi : bi;
+            bx = take ? t4.x : bx, by = take ? t4.y : by, bz = take ? t4.z : bz;
         }
         // quad-wide arg-best: (smallest distance, then smallest original index), with the winner's coordinates
 #pragma unroll

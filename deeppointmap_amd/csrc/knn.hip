@@ -302,7 +302,8 @@ __device__ __forceinline__ void offer(Ctr &c, bool ok, float x, float y, float z
 
 __device__ __forceinline__ void offer_d(Ctr &c, float d, int i, int K, LdsF cd, LdsI ci, LdsF td, LdsI ti) {
     const int lane = lane_id();
-    if (d < c.gd || (d == c.gd && i < c.gi)) c.gd = d, c.gi = i;
+    const bool nearer = (d < c.gd) | ((d == c.gd) & (i < c.gi));  // bitwise on purpose: selects, no exec-mask branches
+    c.gd = nearer ? d : c.gd, c.gi = nearer ? i : c.gi;
     const bool in = d <= c.thr;
     const unsigned long long m = __ballot(in);
     if (!m) return;
