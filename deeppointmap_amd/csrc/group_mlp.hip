@@ -426,15 +426,27 @@ namespace {
 // so neither the level-0 features nor their projection ever exist in memory.
 // One wave per centre; G = Cout/(4V) lanes share a row (float4 per lane, V float4 for Cout = 512), 64/G rows per
 // wave pass, LayerNorm sums are DPP / shuffle reductions inside the lane group.
+// The in-row steps are written as v_add_f32 with a DPP operand (one instruction + the two wait states a DPP read
+// needs after the write of its register); from update_dpp the compiler builds copy + s_nop + mov_dpp + add.
+#define DPM_ADD_DPP(ctrl) "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
 template <int G>
 __device__ __forceinline__ float lane_group_sum(float v) {
-    if (G >= 2) v += __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v)));   // quad_perm [1,0,3,2]
-    if (G >= 4) v += __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v)));   // quad_perm [2,3,0,1]
-    if (G >= 8) v += __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v)));  // row_half_mirror
-    if (G >= 16) v += __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v)));  // row_mirror
+    if (G >= 16) asm(DPM_ADD_DPP("quad_perm:[1,0,3,2]") DPM_ADD_DPP("quad_perm:[2,3,0,1]") DPM_ADD_DPP("row_half_mirror")
+                     DPM_ADD_DPP("row_mirror") "s_nop 0" : "+v"(v));
+    else if (G >= 8) asm(DPM_ADD_DPP("quad_perm:[1,0,3,2]") DPM_ADD_DPP("quad_perm:[2,3,0,1]") DPM_ADD_DPP("row_half_mirror")
+                         "s_nop 0" : "+v"(v));
+    else if (G >= 4) asm(DPM_ADD_DPP("quad_perm:[1,0,3,2]") DPM_ADD_DPP("quad_perm:[2,3,0,1]") "s_nop 0" : "+v"(v));
+    else if (G >= 2) asm(DPM_ADD_DPP("quad_perm:[1,0,3,2]") "s_nop 0" : "+v"(v));
     if (G >= 32) v += __shfl_xor(v, 16, 64);
     if (G >= 64) v += __shfl_xor(v, 32, 64);
     return v;
+}
+#undef DPM_ADD_DPP
+// max without the NaN canonicalisation fmaxf drags in (the operands are LayerNorm outputs of finite inputs)
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 template <int COUT, int V, bool AFFINE>
@@ -506,11 +518,12 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
                     y[v][e] -= mean;
                     sq = fmaf(y[v][e], y[v][e], sq);
                 }
-            const float rs = rsqrtf(lane_group_sum<G>(sq) * (1.0f / (float)COUT) + 1e-5f);
+            // var + eps >= 1e-5 is a normal number: the bare v_rsq_f32 (what rsqrtf issues after its denormal scaling)
+            const float rs = __builtin_amdgcn_rsqf(lane_group_sum<G>(sq) * (1.0f / (float)COUT) + 1e-5f);
 #pragma unroll
             for (int v = 0; v < V; ++v)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mx[v][e] = fmaxf(mx[v][e], fmaf(y[v][e] * rs, gm[v][e], bt[v][e]));
+                for (int e = 0; e < 4; ++e) mx[v][e] = vmax_raw(mx[v][e], fmaf(y[v][e] * rs, gm[v][e], bt[v][e]));
         }
         // max over the row groups of the wave (lanes with equal gl), then the first group stores
 #pragma unroll
