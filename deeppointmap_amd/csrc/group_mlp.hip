@@ -456,7 +456,8 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
     const float *__restrict__ Wr, int ldwr, const float *__restrict__ gamma, const float *__restrict__ beta, int N,
     int S, int K, long long total, int cpw, float inv_r, float *__restrict__ out_all) {
     constexpr int G = COUT / (4 * V), RPW = 64 / G;  // lanes per row, rows per wave pass
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gl = lane % G, gr = lane / G;
+    // the wave index through readfirstlane: the centre loop, its frame pointers and the centre itself become scalar
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), gl = lane % G, gr = lane / G;
     // per-lane constants for its 4*V channels: relative-coordinate weights, LayerNorm affine, (AFFINE) the point map
     float wr[V][4][3], gm[V][4], bt[V][4], am[AFFINE ? V : 1][4][3], cv[AFFINE ? V : 1][4];
 #pragma unroll
@@ -488,8 +489,10 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
 #pragma unroll 4
         for (int r0 = 0; r0 < K; r0 += RPW) {
             const int r = min(r0 + gr, K - 1);  // K is a multiple of RPW on every shipped layer; clamped rows repeat
-            const int n = min(max(idx_all[(size_t)cc * K + r], 0), N - 1);
-            const float px = xyz[(size_t)n * 3], py = xyz[(size_t)n * 3 + 1], pz = xyz[(size_t)n * 3 + 2];
+            // 32-bit element offsets from the (scalar) frame pointers: a frame is far below 2^32 bytes
+            const unsigned n = (unsigned)min(max(idx_all[(size_t)cc * K + r], 0), N - 1);
+            const float *pn = xyz + n * 3u;  // one pointer, three adjacent floats: stays one 12-byte load
+            const float px = pn[0], py = pn[1], pz = pn[2];
             const float rx = (px - cx) * inv_r, ry = (py - cy) * inv_r, rz = (pz - cz) * inv_r;
             float y[V][4], sum = 0.f;
 #pragma unroll
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
                     p4.z = fmaf(am[v][2][2], pz, fmaf(am[v][2][1], py, fmaf(am[v][2][0], px, cv[v][2])));
                     p4.w = fmaf(am[v][3][2], pz, fmaf(am[v][3][1], py, fmaf(am[v][3][0], px, cv[v][3])));
                 } else {
-                    p4 = *reinterpret_cast<const float4 *>(P + (size_t)n * COUT + 4 * (gl + G * v));
+                    p4 = *reinterpret_cast<const float4 *>(P + (n * (unsigned)COUT + 4u * (unsigned)(gl + G * v)));
                 }
                 y[v][0] = fmaf(wr[v][0][2], rz, fmaf(wr[v][0][1], ry, fmaf(wr[v][0][0], rx, p4.x)));
                 y[v][1] = fmaf(wr[v][1][2], rz, fmaf(wr[v][1][1], ry, fmaf(wr[v][1][0], rx, p4.y)));
