@@ -176,16 +176,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 // Vectorised variant for the widths of the path (C = 4 * G * V): G lanes share a row (64 / G rows per wave), every
 // lane keeps its V float4 in registers, so x (+ pre) is read exactly once, and the two row sums are DPP / shuffle
 // reductions inside the lane group.  Same two-pass arithmetic as the generic kernel above.
+// (in-row steps as v_add_f32 with a DPP operand: one instruction + the two wait states of a DPP read, where
+// update_dpp compiles to copy + s_nop + mov_dpp + add)
+#define DPM_ADD_DPP(ctrl) "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-    if (G >= 2) v += __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v)));   // quad_perm [1,0,3,2]
-    if (G >= 4) v += __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v)));   // quad_perm [2,3,0,1]
-    if (G >= 8) v += __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v)));  // row_half_mirror
-    if (G >= 16) v += __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v)));  // row_mirror
+    if (G >= 16) asm(DPM_ADD_DPP("quad_perm:[1,0,3,2]") DPM_ADD_DPP("quad_perm:[2,3,0,1]") DPM_ADD_DPP("row_half_mirror")
+                     DPM_ADD_DPP("row_mirror") "s_nop 0" : "+v"(v));
+    else if (G >= 8) asm(DPM_ADD_DPP("quad_perm:[1,0,3,2]") DPM_ADD_DPP("quad_perm:[2,3,0,1]") DPM_ADD_DPP("row_half_mirror")
+                         "s_nop 0" : "+v"(v));
+    else if (G >= 4) asm(DPM_ADD_DPP("quad_perm:[1,0,3,2]") DPM_ADD_DPP("quad_perm:[2,3,0,1]") "s_nop 0" : "+v"(v));
+    else if (G >= 2) asm(DPM_ADD_DPP("quad_perm:[1,0,3,2]") "s_nop 0" : "+v"(v));
     if (G >= 32) v += __shfl_xor(v, 16, 64);
     if (G >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
+#undef DPM_ADD_DPP
 
 template <int G, int V>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float *__restrict__ X, int ldx,
