@@ -43,21 +43,23 @@ __device__ __forceinline__ unsigned xcd_chunked_id(unsigned linear, unsigned tot
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
 
+// Each step is ONE instruction with a DPP operand (plus the two wait states a DPP read needs after the VALU write of
+// its register): from update_dpp + fmaxf / min the compiler builds copy + s_nop + mov_dpp (+ a NaN canonicalisation
+// for floats) + the operation.  Rows 1,3 then take row 0,2's last lane and rows 2,3 take lane 31's, so lane 63 holds
+// the wave's result.  (v_max_f32 on non-NaN inputs returns one of its operands, exactly like fmaxf.)
+#define DPM_WAVE_REDUCE(op)                                                                  \
+    "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"           \
+    "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"           \
+    "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"               \
+    "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                    \
+    "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                  \
+    "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
 __device__ __forceinline__ float wave_max_dpp(float v) {
-    v = fmaxf(v, __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v))));   // quad_perm [1,0,3,2]
-    v = fmaxf(v, __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v))));   // quad_perm [2,3,0,1]
-    v = fmaxf(v, __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v))));  // row_half_mirror
-    v = fmaxf(v, __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v))));  // row_mirror
-    v = fmaxf(v, __int_as_float(dpp_i<0x142, 0xA>(__float_as_int(v))));  // row_bcast:15 -> rows 1,3
-    v = fmaxf(v, __int_as_float(dpp_i<0x143, 0xC>(__float_as_int(v))));  // row_bcast:31 -> rows 2,3
+    asm(DPM_WAVE_REDUCE("v_max_f32_dpp") : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int wave_min_dpp(int v) {
-    v = min(v, dpp_i<0xB1, 0xF>(v));
-    v = min(v, dpp_i<0x4E, 0xF>(v));
-    v = min(v, dpp_i<0x141, 0xF>(v));
-    v = min(v, dpp_i<0x140, 0xF>(v));
-    v = min(v, dpp_i<0x142, 0xA>(v));
-    v = min(v, dpp_i<0x143, 0xC>(v));
+    asm(DPM_WAVE_REDUCE("v_min_i32_dpp") : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
+#undef DPM_WAVE_REDUCE
