@@ -644,6 +644,38 @@ __device__ __forceinline__ void heap_adjust_reg(float &hv, int &hi, int hole, in
     wlane(hv, hole, val), wlane(hi, hole, vi);
 }
 
+// std::__pop_heap + push of `val` at the root (the only heap_adjust the replay issues), evaluated for all nodes at
+// once instead of walking the tree with dependent lane reads:
+//   * every lane fetches its two children (ds_bpermute) and names the bigger one exactly as __adjust_heap does
+//     (right child unless it is smaller than the left; the single child of node (len-2)/2 when len is even);
+//   * the hole's way down is the chain root -> bigger child -> ... -> leaf: at most six scalar lane reads;
+//   * along that chain the old values fall monotonically (heap property), so the push-up of `val` from the leaf
+//     stops at depth k = number of chain nodes below the root whose value is >= val: nodes above depth k take their
+//     bigger child's entry, the node at depth k takes (val, vi), deeper nodes end up where they started.
+__device__ __forceinline__ void heap_replace_top(float &hv, int &hi, int len, float val, int vi) {
+    const int j = lane_id();
+    const int left = 2 * j + 1, right = 2 * j + 2;
+    const float cl = __int_as_float(__builtin_amdgcn_ds_bpermute(left << 2, __float_as_int(hv)));
+    const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(right << 2, __float_as_int(hv)));
+    const int il = __builtin_amdgcn_ds_bpermute(left << 2, hi), ir = __builtin_amdgcn_ds_bpermute(right << 2, hi);
+    const bool two = right < len, one = left < len;
+    const bool take_left = two ? (cr < cl) : true;
+    const int big = one ? (take_left ? left : right) : -1;
+    const float cv = take_left ? cl : cr;
+    const int ci = take_left ? il : ir;
+    unsigned long long path = 1ull;
+    for (int p = 0;;) {
+        const int nb = __builtin_amdgcn_readlane(big, p);
+        if (nb < 0) break;
+        p = nb, path |= 1ull << p;
+    }
+    const bool on = (path >> j) & 1ull;
+    const int depth = __popcll(path & ((1ull << j) - 1ull));
+    const int k = __popcll(__ballot(on && j != 0 && hv >= val));
+    if (on && depth < k) hv = cv, hi = ci;
+    if (on && depth == k) hv = val, hi = vi;
+}
+
 __global__ __launch_bounds__(TIE_T) void knn_tie_kernel(const float *__restrict__ points_all,
                                                        const int32_t *__restrict__ lengths,
                                                        const float *__restrict__ centers_all, int N, int S, int K,
@@ -698,7 +730,7 @@ __global__ __launch_bounds__(TIE_T) void knn_tie_kernel(const float *__restrict_
                 const int l = __builtin_ctzll(mm);
                 mm &= mm - 1;
                 const float dl = rlane(d, l);
-                if (dl < rlane(hv, 0)) heap_adjust_reg(hv, hi, 0, K, dl, rlane(ii, l));  // std::__pop_heap
+                if (dl < rlane(hv, 0)) heap_replace_top(hv, hi, K, dl, rlane(ii, l));  // std::__pop_heap
             }
         };
         // points [from, to) step by step: TIE_U * TIE_T distances per step, flagged chunks replayed by wave 0
