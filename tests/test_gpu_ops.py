@@ -143,7 +143,9 @@ def test_knn_boundary_ties_follow_reference_topk(ops):
     # libstdc++ heap-select (torch.topk CPU, K*64 <= N); the kernel re-runs such rows through an exact
     # emulation, so the index sets must be identical, not merely equivalent.
     gen = torch.Generator().manual_seed(31)
-    for N, K, r in [(4096, 32, 0.3), (8192, 32, 0.25), (2048, 16, 0.4)]:
+    # 8192 / 20000 points: beyond the 4096-point head of the tie kernel, i.e. through its filter pass (and, on this
+    # lattice where thousands of points undercut the early top, through the list-overflow fallback as well)
+    for N, K, r in [(4096, 32, 0.3), (8192, 32, 0.25), (2048, 16, 0.4), (20000, 32, 0.2)]:
         pts = (torch.randint(0, 24, (1, N, 3), generator=gen).float() / 24.0)
         ctr = pts[:, torch.randperm(N, generator=gen)[:200]].contiguous()
         pad = torch.zeros(1, N, dtype=torch.bool)
