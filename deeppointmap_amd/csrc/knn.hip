@@ -645,32 +645,37 @@ __device__ __forceinline__ void heap_adjust_reg(float &hv, int &hi, int hole, in
 }
 
 // std::__pop_heap + push of `val` at the root (the only heap_adjust the replay issues), evaluated for all nodes at
-// once instead of walking the tree with dependent lane reads:
-//   * every lane fetches its two children (ds_bpermute) and names the bigger one exactly as __adjust_heap does
-//     (right child unless it is smaller than the left; the single child of node (len-2)/2 when len is even);
-//   * the hole's way down is the chain root -> bigger child -> ... -> leaf: at most six scalar lane reads;
+// once instead of walking the tree with dependent lane reads (one wave runs the replay: every dependent instruction is
+// exposed latency):
+//   * __adjust_heap sends the hole down through the bigger child of each node -- the right one unless it is smaller
+//     than the left, the single (left) child of node (len-2)/2 when len is even.  "I am my parent's bigger child"
+//     needs only my sibling's value: one ds_bpermute;
+//   * a node is on the hole's way down iff it and all its ancestors below the root are their parent's bigger child:
+//     six shift-and-test steps on the ballot of that predicate, independent per lane;
 //   * along that chain the old values fall monotonically (heap property), so the push-up of `val` from the leaf
-//     stops at depth k = number of chain nodes below the root whose value is >= val: nodes above depth k take their
-//     bigger child's entry, the node at depth k takes (val, vi), deeper nodes end up where they started.
+//     stops at depth k = number of chain nodes below the root whose value is >= val: chain nodes above depth k take
+//     their bigger child's entry (two more bpermute pairs, requested up front), the one at depth k takes (val, vi),
+//     deeper ones end up where they started.
 __device__ __forceinline__ void heap_replace_top(float &hv, int &hi, int len, float val, int vi) {
     const int j = lane_id();
-    const int left = 2 * j + 1, right = 2 * j + 2;
+    const int left = 2 * j + 1, right = 2 * j + 2, sib = (j & 1) ? j + 1 : j - 1;
+    const float sv = __int_as_float(__builtin_amdgcn_ds_bpermute(sib << 2, __float_as_int(hv)));
     const float cl = __int_as_float(__builtin_amdgcn_ds_bpermute(left << 2, __float_as_int(hv)));
     const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(right << 2, __float_as_int(hv)));
     const int il = __builtin_amdgcn_ds_bpermute(left << 2, hi), ir = __builtin_amdgcn_ds_bpermute(right << 2, hi);
-    const bool two = right < len, one = left < len;
-    const bool take_left = two ? (cr < cl) : true;
-    const int big = one ? (take_left ? left : right) : -1;
+    const bool bigger = j < len && ((j & 1) ? (j + 1 >= len || sv < hv) : !(hv < sv));
+    const unsigned long long chain = __ballot(bigger) | 1ull;  // bit 0: the root starts the chain
+    bool on = true;
+    int a = j;
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {  // 64 nodes: at most five ancestors; the root repeats harmlessly
+        on = on && ((chain >> a) & 1ull);
+        a = max((a - 1) >> 1, 0);
+    }
+    const int depth = 31 - __clz(j + 1);
+    const bool take_left = right < len ? (cr < cl) : true;
     const float cv = take_left ? cl : cr;
     const int ci = take_left ? il : ir;
-    unsigned long long path = 1ull;
-    for (int p = 0;;) {
-        const int nb = __builtin_amdgcn_readlane(big, p);
-        if (nb < 0) break;
-        p = nb, path |= 1ull << p;
-    }
-    const bool on = (path >> j) & 1ull;
-    const int depth = __popcll(path & ((1ull << j) - 1ull));
     const int k = __popcll(__ballot(on && j != 0 && hv >= val));
     if (on && depth < k) hv = cv, hi = ci;
     if (on && depth == k) hv = val, hi = vi;
@@ -724,13 +729,14 @@ __global__ __launch_bounds__(TIE_T) void knn_tie_kernel(const float *__restrict_
             }
         };
         // replay of one 64-entry chunk (distance d, point index ii per lane) against the moving top
+        // (the ballot is retaken against the new top after every insertion: the loop runs once per insertion, not
+        // once per entry that was below the top when the chunk started -- early in a frame that is nearly all of them)
         auto replay = [&](float d, int ii) {
             unsigned long long mm = __ballot(d < rlane(hv, 0));
             while (mm) {
                 const int l = __builtin_ctzll(mm);
-                mm &= mm - 1;
-                const float dl = rlane(d, l);
-                if (dl < rlane(hv, 0)) heap_replace_top(hv, hi, K, dl, rlane(ii, l));  // std::__pop_heap
+                heap_replace_top(hv, hi, K, rlane(d, l), rlane(ii, l));  // std::__pop_heap
+                mm = __ballot(d < rlane(hv, 0)) & ((~1ull) << l);
             }
         };
         // points [from, to) step by step: TIE_U * TIE_T distances per step, flagged chunks replayed by wave 0
