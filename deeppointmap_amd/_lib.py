@@ -29,6 +29,8 @@ SIGNATURES = {
     "dpm_knn_workspace_bytes": (c_size_t, [I, I]),
     "dpm_knn_hybrid": (I, [P, P, P, I, I, I, I, D, P, P, P]),
     "dpm_knn_hybrid_reuse": (I, [P, P, P, I, I, I, I, D, P, P, P, P, P]),
+    "dpm_knn_build_grid": (I, [P, P, I, I, D, P, P]),
+    "dpm_knn_hybrid_prebuilt": (I, [P, P, P, I, I, I, I, D, P, P, P]),
     "dpm_ball_query": (I, [P, P, P, I, I, I, I, D, P, P]),
     "dpm_group_mlp_max": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, D, P, P]),
     "dpm_group_mlp_max_generic": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, D, P, P]),

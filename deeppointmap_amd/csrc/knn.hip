@@ -1053,6 +1053,46 @@ extern "C" size_t dpm_knn_workspace_bytes(int B, int N) {
            (size_t)B * (size_t)N * sizeof(float4) + 256 + sizeof(int32_t) * (size_t)TIE_CAP;
 }
 
+namespace {
+struct KnnWs {  // layout of the grid workspace (dpm_knn_workspace_bytes)
+    KnnGrid *hdr;
+    int *start;
+    float4 *sorted;
+    int *tie_count;  // [0] = queued rows; the list follows
+    int32_t *tie_rows;
+};
+KnnWs carve(void *workspace, int B, int N) {
+    KnnWs w;
+    uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    w.hdr = (KnnGrid *)p;
+    p = (p + sizeof(KnnGrid) * (size_t)B + 255) & ~(uintptr_t)255;
+    w.start = (int *)p;
+    p = (p + sizeof(int) * (size_t)B * (GDIM * GDIM + 1) + 255) & ~(uintptr_t)255;
+    w.sorted = (float4 *)p;
+    p = (p + sizeof(float4) * (size_t)B * (size_t)N + 255) & ~(uintptr_t)255;
+    w.tie_count = (int *)p;
+    w.tie_rows = (int32_t *)(p + 64);
+    return w;
+}
+void launch_grid_build(const float *points, const int32_t *lengths, int B, int N, double radius, const KnnWs &w,
+                       hipStream_t st) {
+    // cell edge > sqrt(r^2 + 2e-5): the expanded-form distance can undershoot the true one by ~1.5e-6
+    const float cs_min = (float)(sqrt(radius * radius + 2e-5) * 1.002);
+    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, st, points, lengths, N, cs_min, w.hdr, w.start,
+                       w.sorted, w.tie_count);
+}
+int launch_grid_search(const float *points, const int32_t *lengths, const float *centers, int B, int N, int S, int K,
+                       float r2, int32_t *idx, const KnnWs &w, const int32_t *reuse_idx, const int32_t *center_src,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(knn_grid_kernel, dim3(dpm_cdiv(S, WPB), B), dim3(WPB * 64), 0, st, points, lengths, centers, N,
+                       S, K, r2, w.hdr, w.start, w.sorted, idx, reuse_idx, center_src, w.tie_count, w.tie_rows);
+    if ((long long)K * 64 <= (long long)N)  // the only regime with an order-dependent tie rule
+        hipLaunchKernelGGL(knn_tie_kernel, dim3(2048), dim3(TIE_T), 0, st, points, lengths, centers, N, S, K, r2,
+                           w.tie_count, w.tie_rows, idx);
+    return dpm_launch_status();
+}
+}  // namespace
+
 extern "C" int dpm_knn_hybrid_reuse(const float *points, const int32_t *lengths, const float *centers, int B, int N,
                                     int S, int K, double radius, int32_t *idx, void *workspace,
                                     const int32_t *reuse_idx, const int32_t *center_src, dpm_stream_t stream) {
@@ -1063,29 +1103,33 @@ extern "C" int dpm_knn_hybrid_reuse(const float *points, const int32_t *lengths,
     hipStream_t st = (hipStream_t)stream;
     const float r2 = (float)(radius * radius);
     if (N >= GRID_MIN_N && workspace) {
-        uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
-        KnnGrid *hdr = (KnnGrid *)p;
-        p = (p + sizeof(KnnGrid) * (size_t)B + 255) & ~(uintptr_t)255;
-        int *start = (int *)p;
-        p = (p + sizeof(int) * (size_t)B * (GDIM * GDIM + 1) + 255) & ~(uintptr_t)255;
-        float4 *sorted = (float4 *)p;
-        p = (p + sizeof(float4) * (size_t)B * (size_t)N + 255) & ~(uintptr_t)255;
-        int *tie_count = (int *)p;  // [0] = queued rows; the list follows
-        int32_t *tie_rows = (int32_t *)(p + 64);
-        // cell edge > sqrt(r^2 + 2e-5): the expanded-form distance can undershoot the true one by ~1.5e-6
-        const float cs_min = (float)(sqrt(radius * radius + 2e-5) * 1.002);
-        hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, st, points, lengths, N, cs_min, hdr, start,
-                           sorted, tie_count);
-        hipLaunchKernelGGL(knn_grid_kernel, dim3(dpm_cdiv(S, WPB), B), dim3(WPB * 64), 0, st, points, lengths, centers, N,
-                           S, K, r2, hdr, start, sorted, idx, reuse_idx, center_src, tie_count, tie_rows);
-        if ((long long)K * 64 <= (long long)N)  // the only regime with an order-dependent tie rule
-            hipLaunchKernelGGL(knn_tie_kernel, dim3(2048), dim3(TIE_T), 0, st, points, lengths, centers, N, S, K, r2,
-                               tie_count, tie_rows, idx);
-        return dpm_launch_status();
+        const KnnWs w = carve(workspace, B, N);
+        launch_grid_build(points, lengths, B, N, radius, w, st);
+        return launch_grid_search(points, lengths, centers, B, N, S, K, r2, idx, w, reuse_idx, center_src, st);
     }
     hipLaunchKernelGGL(knn_hybrid_kernel, dim3(dpm_cdiv(S, WPB * CPW), B), dim3(WPB * 64), 0, st, points, lengths, centers,
                        N, S, K, r2, idx, reuse_idx, center_src);
     return dpm_launch_status();
+}
+
+// The two halves of the grid path as separate calls sharing one workspace: the grid depends on the points and the
+// radius only, so a pipeline builds it next to the sampling (before any feature exists) and runs only the search in
+// its feature stage.  One search per build (the build also resets the tie queue the search fills).
+extern "C" int dpm_knn_build_grid(const float *points, const int32_t *lengths, int B, int N, double radius,
+                                  void *workspace, dpm_stream_t stream) {
+    DPM_CHECK_ARG(points && lengths && workspace && B >= 1 && N >= GRID_MIN_N && radius > 0.0);
+    launch_grid_build(points, lengths, B, N, radius, carve(workspace, B, N), (hipStream_t)stream);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_knn_hybrid_prebuilt(const float *points, const int32_t *lengths, const float *centers, int B, int N,
+                                       int S, int K, double radius, int32_t *idx, void *workspace,
+                                       dpm_stream_t stream) {
+    DPM_CHECK_ARG(points && lengths && centers && idx && workspace);
+    DPM_CHECK_ARG(B >= 1 && N >= GRID_MIN_N && S >= 1 && K >= 1 && radius > 0.0);
+    if (K > KMAX) return DPM_EUNSUPPORTED;
+    return launch_grid_search(points, lengths, centers, B, N, S, K, (float)(radius * radius), idx, carve(workspace, B, N),
+                              nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int dpm_knn_hybrid(const float *points, const int32_t *lengths, const float *centers, int B, int N,

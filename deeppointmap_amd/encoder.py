@@ -84,6 +84,21 @@ class Encoder(ParamTree):
                     fidx = torch.where(ar < cur_len.unsqueeze(1), ar, torch.full_like(ar, -1))
                     cur = cur[:, :npoint].contiguous()
                 out[f"fidx{i}"], out[f"xyz{i}"], out[f"len{i}"] = fidx, cur, cur_len
+            # The search grids of the neighbour queries depend on coordinates and radii only: they are sorted here,
+            # next to the sampling, and forward() runs just the searches.  Same bookkeeping as forward(): a
+            # SetAbstraction whose (radius, K) the previous level's LocalAggregation already answered needs none.
+            grids, pts_i, len_i, answered = {}, xyz, lengths, set()
+            for i in range(n_levels):
+                radii, ks = self.encoder_cfg.radius_list[i], self.encoder_cfg.nsample_list[i]
+                if (float(radii[0]), int(ks[0])) not in answered and pts_i.shape[1] >= ops.GRID_MIN_N:
+                    grids[("sa", i)] = ops.knn_grid(pts_i, len_i, radii[0])
+                pts_i, len_i, answered = out[f"xyz{i}"], out[f"len{i}"], set()
+                for j in range(1, len(radii)):
+                    key = (float(radii[j]), int(ks[j]))
+                    if key not in answered and pts_i.shape[1] >= ops.GRID_MIN_N:
+                        grids[("la", i, key)] = ops.knn_grid(pts_i, len_i, radii[j])
+                    answered.add(key)
+            out["grids"] = grids
         return out
 
     @torch.no_grad()
@@ -123,8 +138,10 @@ class Encoder(ParamTree):
                 else:  # levels the geometry pass left to this stream
                     fidx, new_xyz, new_len = ops.fps(xyz, lengths, npoint)
                 prev = self_q.get((float(radii[0]), int(ks[0])))
+                grids = samp.get("grids", {})
                 gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0], reuse_idx=prev,
-                                      center_src=fidx if prev is not None else None)
+                                      center_src=fidx if prev is not None else None,
+                                      grid=grids.get(("sa", i)) if prev is None else None)
                 self_q = {}  # from here on the level is the sampled one
                 if fea is None:
                     m = pre + ".sa.mlp"
@@ -140,7 +157,8 @@ class Encoder(ParamTree):
                     q = f"{pre}.irm.{j - 1}"
                     key = (float(radii[j]), int(ks[j]))
                     if key not in self_q:
-                        self_q[key] = ops.knn_hybrid(new_xyz, new_len, new_xyz, ks[j], radii[j])
+                        self_q[key] = ops.knn_hybrid(new_xyz, new_len, new_xyz, ks[j], radii[j],
+                                                     grid=grids.get(("la", i, key)))
                     lidx = self_q[key]
                     t = self._group(q + ".la.mlp", radii[j], new_xyz, new_fea, new_xyz, lidx)
                     u = self._mlp_ln(t, q + ".pw_conv.0", q + ".pw_conv.1.ln", ops.ACT_RELU)

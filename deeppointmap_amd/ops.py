@@ -71,12 +71,28 @@ def fps(xyz: torch.Tensor, lengths: torch.Tensor, K: int, algo: int = 0):
     return idx, new_xyz, new_len
 
 
+GRID_MIN_N = 1024  # dpm_knn_hybrid searches a grid from this many points per frame on
+
+
+def knn_grid(points: torch.Tensor, lengths: torch.Tensor, radius: float) -> torch.Tensor:
+    """The point-only half of knn_hybrid (N >= GRID_MIN_N): sorts every frame into the search grid of `radius`.
+    Returns the workspace to hand to ONE knn_hybrid(..., grid=...) call with the same points, lengths and radius."""
+    _chk(points, torch.float32, "points"), _chk(lengths, torch.int32, "lengths")
+    B, N, _ = points.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.dpm_knn_workspace_bytes(B, N), device=points.device, dtype=torch.uint8)
+    _lib.check(lib.dpm_knn_build_grid(_ptr(points), _ptr(lengths), B, N, float(radius), _ptr(ws), _stream(points)),
+               "dpm_knn_build_grid")
+    return ws
+
+
 def knn_hybrid(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tensor, K: int,
                radius: float, brute: bool = False, reuse_idx: Optional[torch.Tensor] = None,
-               center_src: Optional[torch.Tensor] = None) -> torch.Tensor:
+               center_src: Optional[torch.Tensor] = None, grid: Optional[torch.Tensor] = None) -> torch.Tensor:
     """points (B,N,3), centers (B,S,3) -> idx (B,S,K) int32.  brute=True forces the all-pairs scan.
     reuse_idx (B,N,K) + center_src (B,S): centres that are points of the frame (center_src >= 0) copy their row of
-    the already computed self-query (same radius, same K); only padded centres are searched."""
+    the already computed self-query (same radius, same K); only padded centres are searched.
+    grid: knn_grid(points, lengths, radius) built ahead of time -- only the search runs."""
     _chk(points, torch.float32, "points")
     _chk(centers, torch.float32, "centers")
     _chk(lengths, torch.int32, "lengths")
@@ -84,6 +100,12 @@ def knn_hybrid(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tenso
     S = centers.shape[1]
     idx = torch.empty(B, S, K, device=points.device, dtype=torch.int32)
     lib = _lib.load()
+    if grid is not None:
+        if brute or reuse_idx is not None or grid.numel() != lib.dpm_knn_workspace_bytes(B, N):
+            raise ValueError("grid= goes with a plain grid search of the (B, N) it was built for")
+        _lib.check(lib.dpm_knn_hybrid_prebuilt(_ptr(points), _ptr(lengths), _ptr(centers), B, N, S, K, float(radius),
+                                               _ptr(idx), _ptr(grid), _stream(points)), "dpm_knn_hybrid_prebuilt")
+        return idx
     nbytes = 0 if brute else lib.dpm_knn_workspace_bytes(B, N)
     ws = torch.empty(nbytes, device=points.device, dtype=torch.uint8) if nbytes else None
     if reuse_idx is not None:

@@ -21,6 +21,15 @@ from .registration import make_descriptors
 EDGE_FLOATS = 56  # per edge: 20-float registration header (R, T, rmse, n_corr, n_inlier, iters, conf30, ...) + 6x6 information
 
 
+def _tensors(d):
+    """every tensor of a (possibly nested) dict"""
+    for v in d.values():
+        if isinstance(v, dict):
+            yield from _tensors(v)
+        elif isinstance(v, torch.Tensor):
+            yield v
+
+
 @dataclass
 class Edge:
     """One odometry edge (what PoseGraph_Edge receives, odometry.py:119-125)."""
@@ -135,7 +144,7 @@ class HotPath:
                 grids = ops.information_matrix_grids(pcd_m, ring[1][1])
                 grids.record_stream(self._side["reg"])
                 grids_ready = sa.record_event()
-        for t in pre.values():
+        for t in _tensors(pre):
             t.record_stream(main)  # produced on a geometry stream, consumed on the caller's stream
         self._pending["geo"].append((pre, ready, points, padding,
                                      (pcd_m, grids, grids_ready) if pcd_m is not None else None))
@@ -155,7 +164,7 @@ class HotPath:
             self._pending["nf"] += 1
             with torch.cuda.stream(sf):
                 sf.wait_event(ready)
-                for t in pre.values():
+                for t in _tensors(pre):
                     t.record_stream(sf)
                 desc = self.extract(points, padding, presampled=pre)
                 desc_ready = sf.record_event()

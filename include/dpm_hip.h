@@ -81,6 +81,14 @@ int dpm_knn_hybrid_reuse(const float *points, const int32_t *lengths, const floa
                          int S, int K, double radius, int32_t *idx, void *workspace, const int32_t *reuse_idx,
                          const int32_t *center_src, dpm_stream_t stream);
 
+/* dpm_knn_hybrid in two calls sharing one workspace (N >= 1024, the grid path): the grid depends on the points and
+ * the radius only, so a caller that pipelines frames builds it while the frames are still being sampled and runs the
+ * search when the centres exist.  One search per build (the build resets the tie queue the search fills). */
+int dpm_knn_build_grid(const float *points, const int32_t *lengths, int B, int N, double radius, void *workspace,
+                       dpm_stream_t stream);
+int dpm_knn_hybrid_prebuilt(const float *points, const int32_t *lengths, const float *centers, int B, int N,
+                            int S, int K, double radius, int32_t *idx, void *workspace, dpm_stream_t stream);
+
 /* Querier.ball_query / ball_query_t3d == pytorch3d.ops.ball_query (utils.py:57-73,99-110): the K
  * smallest indices among the valid points within `radius` (expanded-form distance, like the
  * reference), ascending, padded with the first of them.  idx (B,S,K). */

@@ -175,6 +175,26 @@ def test_knn_grid_equals_brute_force(ops):
         assert (a[:, -12:] == a[:, -12:, :1]).all()  # far-away centres: every slot is the nearest point
 
 
+def test_knn_prebuilt_grid_equals_one_call(ops):
+    """dpm_knn_build_grid + dpm_knn_hybrid_prebuilt (grid sorted ahead of time, e.g. on another stream) against the
+    one-call form: identical neighbour sets and nearest slots (the order of the other slots follows the grid's
+    atomically scattered point order and is free in both forms), ragged frames and boundary-tie rows included."""
+    gen = torch.Generator().manual_seed(41)
+    pts = torch.cat([synthetic.frame(3, 8192).t().unsqueeze(0),
+                     (torch.randint(0, 24, (1, 8192, 3), generator=gen).float() / 24.0)]).contiguous().to(DEV)
+    lens = _lengths([8192, 5000])
+    ctr = pts[:, :700].contiguous()
+    for r, K in [(0.05, 32), (0.25, 32), (0.4, 16)]:
+        one = ops.knn_hybrid(pts, lens, ctr, K, r)
+        grid = ops.knn_grid(pts, lens, r)
+        two = ops.knn_hybrid(pts, lens, ctr, K, r, grid=grid)
+        for f in range(2):
+            assert idx_rows_equal_as_sets(one[f].cpu().numpy(), two[f].cpu().numpy()).all(), (r, K, f)
+        assert torch.equal(one[..., 0], two[..., 0])
+    with pytest.raises(ValueError):
+        ops.knn_hybrid(pts[:, :4096].contiguous(), lens, ctr, 32, 0.1, grid=grid)   # built for another N
+
+
 def test_knn_reuse_of_self_query_is_identical(ops):
     # SetAbstraction centres = FPS picks of the points: rows copied from the self-query must equal a fresh search,
     # including frames with padded centres (fewer valid points than picks), on both the grid and the brute path
