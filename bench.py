@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-pipeline", action="store_true", help="run every step start-to-finish on one stream")
     ap.add_argument("--geometry-depth", type=int, default=None, help="geometry passes kept in flight (pipeline tuning)")
+    ap.add_argument("--geometry-knn", type=int, default=None, help="1: neighbour queries run in the geometry stage, 0: in the feature stage")
     ap.add_argument("--feature-streams", type=int, default=None, help="feature-stage streams (pipeline tuning)")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time breakdown to stderr")
     args = ap.parse_args()
@@ -129,6 +130,8 @@ def main():
     hot = HotPath(init_procedural(Encoder(cfg)).to(dev), init_procedural(Decoder(cfg)).to(dev))
     if args.geometry_depth is not None:
         hot.geometry_depth = args.geometry_depth
+    if args.geometry_knn is not None:
+        hot.encoder.presample_neighbours = bool(args.geometry_knn)
     if args.feature_streams is not None:
         hot.feature_streams = args.feature_streams
     F, N = args.frames, args.points

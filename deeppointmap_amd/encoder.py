@@ -40,6 +40,9 @@ class Encoder(ParamTree):
         # positions agrees with the pick order).  Only the first level is computed; False runs every level
         # (tests assert both give identical tensors).
         self.nested_fps = all(b <= a for a, b in zip(self.encoder_cfg.npoint, self.encoder_cfg.npoint[1:]))
+        # presample() also answers the neighbour queries (coordinates only): a pipeline knob -- where they run moves
+        # work between the geometry and the feature stage, the results are the same tensors either way
+        self.presample_neighbours = False
         self.eval()
 
     # -- helpers -------------------------------------------------------------------------------
@@ -99,7 +102,30 @@ class Encoder(ParamTree):
                         grids[("la", i, key)] = ops.knn_grid(pts_i, len_i, radii[j])
                     answered.add(key)
             out["grids"] = grids
+            if self.presample_neighbours and n_levels == len(self.encoder_cfg.npoint):
+                out["knn"] = self._neighbour_queries(out)
         return out
+
+    def _neighbour_queries(self, samp: dict) -> dict:
+        """Every neighbour query of the encoder -- they depend on coordinates only, like the sampling.  Same reuse
+        rules as forward(): ("sa", i) / ("la", i, (radius, K)) -> idx."""
+        enc, grids, knn = self.encoder_cfg, samp.get("grids", {}), {}
+        xyz, lengths, self_q = samp["xyz"], samp["lengths"], {}
+        for i in range(len(enc.npoint)):
+            radii, ks = enc.radius_list[i], enc.nsample_list[i]
+            fidx, new_xyz, new_len = samp[f"fidx{i}"], samp[f"xyz{i}"], samp[f"len{i}"]
+            prev = self_q.get((float(radii[0]), int(ks[0])))
+            knn[("sa", i)] = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0], reuse_idx=prev,
+                                            center_src=fidx if prev is not None else None,
+                                            grid=grids.get(("sa", i)) if prev is None else None)
+            self_q = {}
+            for j in range(1, len(radii)):
+                key = (float(radii[j]), int(ks[j]))
+                if key not in self_q:
+                    self_q[key] = ops.knn_hybrid(new_xyz, new_len, new_xyz, ks[j], radii[j], grid=grids.get(("la", i, key)))
+                knn[("la", i, key)] = self_q[key]
+            xyz, lengths = new_xyz, new_len
+        return knn
 
     @torch.no_grad()
     def forward(self, points: torch.Tensor, points_padding: torch.Tensor, trace: Optional[dict] = None,
@@ -138,10 +164,12 @@ class Encoder(ParamTree):
                 else:  # levels the geometry pass left to this stream
                     fidx, new_xyz, new_len = ops.fps(xyz, lengths, npoint)
                 prev = self_q.get((float(radii[0]), int(ks[0])))
-                grids = samp.get("grids", {})
-                gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0], reuse_idx=prev,
-                                      center_src=fidx if prev is not None else None,
-                                      grid=grids.get(("sa", i)) if prev is None else None)
+                grids, knn = samp.get("grids", {}), samp.get("knn", {})
+                gidx = knn.get(("sa", i))
+                if gidx is None:
+                    gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0], reuse_idx=prev,
+                                          center_src=fidx if prev is not None else None,
+                                          grid=grids.get(("sa", i)) if prev is None else None)
                 self_q = {}  # from here on the level is the sampled one
                 if fea is None:
                     m = pre + ".sa.mlp"
@@ -157,8 +185,8 @@ class Encoder(ParamTree):
                     q = f"{pre}.irm.{j - 1}"
                     key = (float(radii[j]), int(ks[j]))
                     if key not in self_q:
-                        self_q[key] = ops.knn_hybrid(new_xyz, new_len, new_xyz, ks[j], radii[j],
-                                                     grid=grids.get(("la", i, key)))
+                        self_q[key] = knn[("la", i, key)] if ("la", i, key) in knn else ops.knn_hybrid(
+                            new_xyz, new_len, new_xyz, ks[j], radii[j], grid=grids.get(("la", i, key)))
                     lidx = self_q[key]
                     t = self._group(q + ".la.mlp", radii[j], new_xyz, new_fea, new_xyz, lidx)
                     u = self._mlp_ln(t, q + ".pw_conv.0", q + ".pw_conv.1.ln", ops.ACT_RELU)

@@ -102,6 +102,22 @@ def test_nested_fps_prefix_equals_explicit_chain(cfg_full):
             assert torch.equal(a[k], b[k]), k
 
 
+def test_neighbour_queries_in_the_geometry_pass_change_nothing(cfg_full):
+    """Encoder.presample_neighbours moves the neighbour queries into presample() (a pipeline balancing knob): the
+    descriptors are the same bits -- the max over the K slots does not see their order."""
+    from deeppointmap_amd.encoder import Encoder
+    from deeppointmap_amd.weights import init_procedural
+    enc = init_procedural(Encoder(cfg_full)).to(DEV)
+    pts, pad = synthetic.frames(2, 30000)
+    pad[1, 21000:] = True
+    coor0, fea0, mask0 = enc(pts, pad)
+    enc.presample_neighbours = True
+    pre = enc.presample(pts, pad)
+    assert len(pre["knn"]) >= 6
+    coor1, fea1, mask1 = enc(pts, pad, presampled=pre)
+    assert torch.equal(coor0, coor1) and torch.equal(fea0, fea1) and torch.equal(mask0, mask1)
+
+
 def test_encoder_extra_input_channels_vs_oracle(cfg_reduced):
     """in_channel > 3 (e.g. intensity as a fourth point channel; no shipped config uses it): point_mlp0 is then a
     real GEMM over the input channels and the first set abstraction reads materialised features.  Checked against
