@@ -56,6 +56,27 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 #undef DPM_ROW16
 
+// max / sum over the four lanes l, l+16, l+32, l+48 (one value per DPP row), result in all four: the gfx950 lane
+// swaps exchange half-waves (v_permlane32_swap) and odd/even rows (v_permlane16_swap) in one VALU op each.
+__device__ __forceinline__ float rows4_max(float v) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// Flash-attention structure on fp32 MFMA with the TRANSPOSED score tile: S^T = K Q^T, so that the C-layout registers
+// of a score block (lane l: keys 4(l>>4)+q of the block, query l&15) are already the B operand of O^T = V^T P^T under
+// a k-remap (MFMA (block j, q) contracts the keys 16j + 4g + q, g = lane group, on both operands).  The
+// probabilities never leave the registers (no LDS round trip to re-shape P), a lane owns ONE query -- its running
+// max / sum are scalars, the max needs two lane swaps instead of a 16-lane reduction, the row sum meets once at the
+// end -- and it ends up with 2 x 4 consecutive output channels of that query: two 16-byte stores.
 template <bool VEC>
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
                                                         const float *__restrict__ Kp, int ldk, long long sk,
@@ -63,30 +84,29 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
                                                         float *__restrict__ O, int ldo, long long so, int M,
                                                         int N, float scale) {
     constexpr int TK = 64;                 // keys per tile
-    __shared__ __attribute__((aligned(16))) float Ks[TK][HD + 2];   // B operand of S = Q K^T: B[k=d][j=key] = Ks[key][d]
-    __shared__ __attribute__((aligned(16))) float Vs[TK][HD + 16];  // B operand of O = P V: B[k=key][j=d] = Vs[key][d]
-    __shared__ float Ps[4][16][TK + 2];    // per wave: P in row-major, re-read in the A-operand layout
+    __shared__ __attribute__((aligned(16))) float Ks[TK][HD + 2];  // A operand of S^T: A[i=key][k=d] = Ks[key][d]
+    // A operand of O^T: A[i=d][k=key] = Vs[key][d].  Row stride 36: 16-byte aligned rows, and the four lane groups of
+    // a fragment read (rows 4 apart) land 16 banks apart -- every bank serves exactly two lanes, the b32 minimum.
+    __shared__ __attribute__((aligned(16))) float Vs[TK][HD + 4];
     // all query tiles and heads of one batch element on one XCD: its K / V rows are fetched into that L2 once
     const unsigned bid = xcd_chunked_id((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
                                         gridDim.x * gridDim.y * gridDim.z);
     const int b = bid / (gridDim.x * gridDim.y), h = (bid / gridDim.x) % gridDim.y;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4;
     const int q0 = (bid % gridDim.x) * 64 + w * 16;
     const float *Qb = Q + (size_t)b * sq + h * HD;
     const float *Kb = Kp + (size_t)b * sk + h * HD;
     const float *Vb = V + (size_t)b * sv + h * HD;
 
-    // Q fragments (A operand: A[i=lane&15][k=lane>>4]) for the 8 k-steps of d = 32, pre-scaled
+    // Q^T fragments (B operand: B[k=lane>>4][j=lane&15] = Q[query lane&15][d = 4 ks + (lane>>4)]), pre-scaled
     float qa[HD / 4];
     {
         const int qr = min(q0 + (lane & 15), M - 1);
 #pragma unroll
-        for (int ks = 0; ks < HD / 4; ++ks) qa[ks] = Qb[(size_t)qr * ldq + ks * 4 + (lane >> 4)] * scale;
+        for (int ks = 0; ks < HD / 4; ++ks) qa[ks] = Qb[(size_t)qr * ldq + ks * 4 + g] * scale;
     }
-    f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    float mrow[4], lrow[4];  // running max / sum of the 4 rows this lane holds ((lane>>4)*4 + q)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) mrow[q] = -__builtin_inff(), lrow[q] = 0.f;
+    f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // O^T[d = 16 jd + 4 g + q][query lane&15]
+    float mrow = -__builtin_inff(), lrow = 0.f;  // running max / this lane's share of the sum, query lane&15
 
     // K / V tiles: 64 rows x 32 floats each = 512 float4 per matrix, 2 per thread.  The next tile is fetched into
     // registers (branch-free: rows beyond N re-read the last key; their scores are masked to -inf below, so the
@@ -112,11 +132,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
             const int e = t + p * 256, kr = e >> 3, c4 = (e & 7) * 4;
             float2 *kd = reinterpret_cast<float2 *>(&Ks[kr][c4]);  // row stride 136 B: 8-byte aligned
             kd[0] = make_float2(kreg[p].x, kreg[p].y), kd[1] = make_float2(kreg[p].z, kreg[p].w);
-            *reinterpret_cast<float4 *>(&Vs[kr][c4]) = vreg[p];     // row stride 192 B: 16-byte aligned
+            *reinterpret_cast<float4 *>(&Vs[kr][c4]) = vreg[p];     // row stride 144 B: 16-byte aligned
         }
         __syncthreads();
         if (n0 + TK < N) fetch(n0 + TK);
-        // S tile: 16 queries x 64 keys = 4 MFMA blocks, 8 k-steps each
+        // S^T tile: 64 keys x 16 queries = 4 MFMA blocks (16 keys each), 8 k-steps over d
         f32x4 sacc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) sacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -124,58 +144,61 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
         for (int ks = 0; ks < HD / 4; ++ks) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float bk = Ks[j * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
-                sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[ks], bk, sacc[j], 0, 0, 0);
+                const float ak = Ks[j * 16 + (lane & 15)][ks * 4 + g];
+                sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, qa[ks], sacc[j], 0, 0, 0);
             }
         }
-        // mask keys beyond N, online softmax per row (row = (lane>>4)*4 + q, key = j*16 + (lane&15))
+        // sacc[j][q] = score of key n0 + 16 j + 4 g + q for query lane&15: mask keys beyond N, online softmax
+        float mx = -__builtin_inff();
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (n0 + j * 16 + (lane & 15) >= N) sacc[j] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float mx = fmaxf(fmaxf(sacc[0][q], sacc[1][q]), fmaxf(sacc[2][q], sacc[3][q]));
-            mx = row16_max(mx);
-            const float nm = fmaxf(mrow[q], mx);
-            const float corr = __expf(mrow[q] - nm);  // exp(-inf) = 0 on the first tile
-            float ps = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                if (n0 + j * 16 + g * 4 + q >= N) sacc[j][q] = -__builtin_inff();
+                mx = fmaxf(mx, sacc[j][q]);
+            }
+        mx = rows4_max(mx);
+        const float nm = fmaxf(mrow, mx);
+        const float corr = __expf(mrow - nm);  // exp(-inf) = 0 on the first tile
+        float ps = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
                 const float pv = __expf(sacc[j][q] - nm);
                 sacc[j][q] = pv;
                 ps += pv;
             }
-            lrow[q] = lrow[q] * corr + ps;  // this lane's share of the row sum; the 16 shares meet once, at the end
-            mrow[q] = nm;
-            oacc[0][q] *= corr, oacc[1][q] *= corr;
-        }
-        // P (C layout) -> LDS row-major -> A layout
+        lrow = lrow * corr + ps;
+        mrow = nm;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) oacc[0][q] *= corr, oacc[1][q] *= corr;
+        // O^T += V^T P^T: the score registers are the B operand as they are
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Ps[w][(lane >> 4) * 4 + q][j * 16 + (lane & 15)] = sacc[j][q];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: same-wave LDS ordering is enough
-        __builtin_amdgcn_wave_barrier();
+            for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int ks = 0; ks < TK / 4; ++ks) {
-            const float pa = Ps[w][lane & 15][ks * 4 + (lane >> 4)];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float bv = Vs[ks * 4 + (lane >> 4)][j * 16 + (lane & 15)];
-                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, bv, oacc[j], 0, 0, 0);
+                for (int jd = 0; jd < 2; ++jd) {
+                    const float av = Vs[j * 16 + g * 4 + q][jd * 16 + (lane & 15)];
+                    oacc[jd] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sacc[j][q], oacc[jd], 0, 0, 0);
+                }
             }
-        }
     }
-    // O: row = (lane>>4)*4 + q, column j*16 + (lane&15)
+    // lane: query q0 + (lane&15), channels 16 jd + 4 g .. +3
+    const float inv = 1.f / rows4_sum(lrow);
+    const int m = q0 + (lane & 15);
+    if (m >= M) return;
+    float *o = O + (size_t)b * so + (size_t)m * ldo + h * HD + 4 * g;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int m = q0 + (lane >> 4) * 4 + q;
-        const float total = row16_sum(lrow[q]);  // before the row test: every lane takes part in the exchange
-        if (m >= M) continue;
-        const float inv = 1.f / total;
-        float *o = O + (size_t)b * so + (size_t)m * ldo + h * HD;
-        o[lane & 15] = oacc[0][q] * inv;
-        o[16 + (lane & 15)] = oacc[1][q] * inv;
+    for (int jd = 0; jd < 2; ++jd) {
+        if (VEC) {
+            *reinterpret_cast<float4 *>(o + 16 * jd) =
+                make_float4(oacc[jd][0] * inv, oacc[jd][1] * inv, oacc[jd][2] * inv, oacc[jd][3] * inv);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[16 * jd + q] = oacc[jd][q] * inv;
+        }
     }
 }
 
@@ -921,7 +944,8 @@ extern "C" int dpm_attention(const float *Q, int ldq, long long sq, const float 
                              int N, int heads, int head_dim, dpm_stream_t stream) {
     DPM_CHECK_ARG(Q && K && V && out && B >= 1 && M >= 1 && N >= 1 && heads >= 1);
     if (head_dim != HD) return DPM_EUNSUPPORTED;
-    const bool vec = ldk % 4 == 0 && ldv % 4 == 0 && sk % 4 == 0 && sv % 4 == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0;
+    const bool vec = ldk % 4 == 0 && ldv % 4 == 0 && sk % 4 == 0 && sv % 4 == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0 &&
+                     ldo % 4 == 0 && so % 4 == 0 && ((uintptr_t)out & 15) == 0;  // 16-byte K / V loads and output stores
     const float scale = (float)(1.0 / sqrt((double)head_dim));
     if (vec)
         hipLaunchKernelGGL(attention_kernel<true>, dim3(dpm_cdiv(M, 64), heads, B), dim3(256), 0, (hipStream_t)stream, Q, ldq,
