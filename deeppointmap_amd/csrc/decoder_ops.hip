@@ -77,7 +77,9 @@ __device__ __forceinline__ float rows4_sum(float v) {
 // probabilities never leave the registers (no LDS round trip to re-shape P), a lane owns ONE query -- its running
 // max / sum are scalars, the max needs two lane swaps instead of a 16-lane reduction, the row sum meets once at the
 // end -- and it ends up with 2 x 4 consecutive output channels of that query: two 16-byte stores.
-template <bool VEC>
+// QT = query groups of 16 per wave: with two, every K / V fragment read from LDS feeds two MFMAs and a block covers
+// 128 queries, so the fetch of the first K / V tile (a block lives for only N / 64 tiles) is paid half as often.
+template <bool VEC, int QT>
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
                                                         const float *__restrict__ Kp, int ldk, long long sk,
                                                         const float *__restrict__ V, int ldv, long long sv,
@@ -93,20 +95,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
                                         gridDim.x * gridDim.y * gridDim.z);
     const int b = bid / (gridDim.x * gridDim.y), h = (bid / gridDim.x) % gridDim.y;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4;
-    const int q0 = (bid % gridDim.x) * 64 + w * 16;
+    const int q0 = (bid % gridDim.x) * (64 * QT) + w * (16 * QT);
     const float *Qb = Q + (size_t)b * sq + h * HD;
     const float *Kb = Kp + (size_t)b * sk + h * HD;
     const float *Vb = V + (size_t)b * sv + h * HD;
 
     // Q^T fragments (B operand: B[k=lane>>4][j=lane&15] = Q[query lane&15][d = 4 ks + (lane>>4)]), pre-scaled
-    float qa[HD / 4];
-    {
-        const int qr = min(q0 + (lane & 15), M - 1);
+    float qa[QT][HD / 4];
 #pragma unroll
-        for (int ks = 0; ks < HD / 4; ++ks) qa[ks] = Qb[(size_t)qr * ldq + ks * 4 + g] * scale;
+    for (int u = 0; u < QT; ++u) {
+        const int qr = min(q0 + 16 * u + (lane & 15), M - 1);
+#pragma unroll
+        for (int ks = 0; ks < HD / 4; ++ks) qa[u][ks] = Qb[(size_t)qr * ldq + ks * 4 + g] * scale;
     }
-    f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // O^T[d = 16 jd + 4 g + q][query lane&15]
-    float mrow = -__builtin_inff(), lrow = 0.f;  // running max / this lane's share of the sum, query lane&15
+    f32x4 oacc[QT][2];  // O^T[d = 16 jd + 4 g + q][query 16 u + lane&15]
+    float mrow[QT], lrow[QT];  // running max / this lane's share of the sum, query 16 u + lane&15
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        oacc[u][0] = oacc[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mrow[u] = -__builtin_inff(), lrow[u] = 0.f;
+    }
 
     // K / V tiles: 64 rows x 32 floats each = 512 float4 per matrix, 2 per thread.  The next tile is fetched into
     // registers (branch-free: rows beyond N re-read the last key; their scores are masked to -inf below, so the
@@ -137,42 +145,49 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
         __syncthreads();
         if (n0 + TK < N) fetch(n0 + TK);
         // S^T tile: 64 keys x 16 queries = 4 MFMA blocks (16 keys each), 8 k-steps over d
-        f32x4 sacc[4];
+        f32x4 sacc[QT][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < QT; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sacc[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < HD / 4; ++ks) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float ak = Ks[j * 16 + (lane & 15)][ks * 4 + g];
-                sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, qa[ks], sacc[j], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < QT; ++u)
+                    sacc[u][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, qa[u][ks], sacc[u][j], 0, 0, 0);
             }
         }
-        // sacc[j][q] = score of key n0 + 16 j + 4 g + q for query lane&15: mask keys beyond N, online softmax
-        float mx = -__builtin_inff();
+        // sacc[u][j][q] = score of key n0 + 16 j + 4 g + q for query 16 u + lane&15: mask keys beyond N, online softmax
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int u = 0; u < QT; ++u) {
+            float mx = -__builtin_inff();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (n0 + j * 16 + g * 4 + q >= N) sacc[j][q] = -__builtin_inff();
-                mx = fmaxf(mx, sacc[j][q]);
-            }
-        mx = rows4_max(mx);
-        const float nm = fmaxf(mrow, mx);
-        const float corr = __expf(mrow - nm);  // exp(-inf) = 0 on the first tile
-        float ps = 0.f;
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+                for (int q = 0; q < 4; ++q) {
+                    if (n0 + j * 16 + g * 4 + q >= N) sacc[u][j][q] = -__builtin_inff();
+                    mx = fmaxf(mx, sacc[u][j][q]);
+                }
+            mx = rows4_max(mx);
+            const float nm = fmaxf(mrow[u], mx);
+            const float corr = __expf(mrow[u] - nm);  // exp(-inf) = 0 on the first tile
+            float ps = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float pv = __expf(sacc[j][q] - nm);
-                sacc[j][q] = pv;
-                ps += pv;
-            }
-        lrow = lrow * corr + ps;
-        mrow = nm;
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) oacc[0][q] *= corr, oacc[1][q] *= corr;
+                for (int q = 0; q < 4; ++q) {
+                    const float pv = __expf(sacc[u][j][q] - nm);
+                    sacc[u][j][q] = pv;
+                    ps += pv;
+                }
+            lrow[u] = lrow[u] * corr + ps;
+            mrow[u] = nm;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) oacc[u][0][q] *= corr, oacc[u][1][q] *= corr;
+        }
         // O^T += V^T P^T: the score registers are the B operand as they are
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -181,23 +196,28 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 #pragma unroll
                 for (int jd = 0; jd < 2; ++jd) {
                     const float av = Vs[j * 16 + g * 4 + q][jd * 16 + (lane & 15)];
-                    oacc[jd] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sacc[j][q], oacc[jd], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < QT; ++u)
+                        oacc[u][jd] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sacc[u][j][q], oacc[u][jd], 0, 0, 0);
                 }
             }
     }
-    // lane: query q0 + (lane&15), channels 16 jd + 4 g .. +3
-    const float inv = 1.f / rows4_sum(lrow);
-    const int m = q0 + (lane & 15);
-    if (m >= M) return;
-    float *o = O + (size_t)b * so + (size_t)m * ldo + h * HD + 4 * g;
+    // lane: queries q0 + 16 u + (lane&15), channels 16 jd + 4 g .. +3
 #pragma unroll
-    for (int jd = 0; jd < 2; ++jd) {
-        if (VEC) {
-            *reinterpret_cast<float4 *>(o + 16 * jd) =
-                make_float4(oacc[jd][0] * inv, oacc[jd][1] * inv, oacc[jd][2] * inv, oacc[jd][3] * inv);
-        } else {
+    for (int u = 0; u < QT; ++u) {
+        const float inv = 1.f / rows4_sum(lrow[u]);
+        const int m = q0 + 16 * u + (lane & 15);
+        if (m >= M) continue;
+        float *o = O + (size_t)b * so + (size_t)m * ldo + h * HD + 4 * g;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[16 * jd + q] = oacc[jd][q] * inv;
+        for (int jd = 0; jd < 2; ++jd) {
+            if (VEC) {
+                *reinterpret_cast<float4 *>(o + 16 * jd) = make_float4(oacc[u][jd][0] * inv, oacc[u][jd][1] * inv,
+                                                                       oacc[u][jd][2] * inv, oacc[u][jd][3] * inv);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[16 * jd + q] = oacc[u][jd][q] * inv;
+            }
         }
     }
 }
@@ -947,12 +967,17 @@ extern "C" int dpm_attention(const float *Q, int ldq, long long sq, const float 
     const bool vec = ldk % 4 == 0 && ldv % 4 == 0 && sk % 4 == 0 && sv % 4 == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0 &&
                      ldo % 4 == 0 && so % 4 == 0 && ((uintptr_t)out & 15) == 0;  // 16-byte K / V loads and output stores
     const float scale = (float)(1.0 / sqrt((double)head_dim));
-    if (vec)
-        hipLaunchKernelGGL(attention_kernel<true>, dim3(dpm_cdiv(M, 64), heads, B), dim3(256), 0, (hipStream_t)stream, Q, ldq,
-                           sq, K, ldk, sk, V, ldv, sv, out, ldo, so, M, N, scale);
-    else
-        hipLaunchKernelGGL(attention_kernel<false>, dim3(dpm_cdiv(M, 64), heads, B), dim3(256), 0, (hipStream_t)stream, Q, ldq,
-                           sq, K, ldk, sk, V, ldv, sv, out, ldo, so, M, N, scale);
+    // 32 queries per wave when the query count fills such blocks and there are enough of them for the chip
+    const bool wide = M % 128 == 0 && (long long)(M / 128) * heads * B >= 1024;
+#define DPM_ATT(V, QT)                                                                                                  \
+    hipLaunchKernelGGL((attention_kernel<V, QT>), dim3(dpm_cdiv(M, 64 * QT), heads, B), dim3(256), 0, (hipStream_t)stream, \
+                       Q, ldq, sq, K, ldk, sk, V_, ldv, sv, out, ldo, so, M, N, scale)
+    const float *V_ = V;
+    if (vec && wide) DPM_ATT(true, 2);
+    else if (vec) DPM_ATT(true, 1);
+    else if (wide) DPM_ATT(false, 2);
+    else DPM_ATT(false, 1);
+#undef DPM_ATT
     return dpm_launch_status();
 }
 
