@@ -34,7 +34,8 @@ def test_position_embedding_vs_reference(dec, ops):
 
 def test_attention_core_vs_torch(ops):
     gen = torch.Generator().manual_seed(3)
-    for B, M, N in [(1, 256, 256), (2, 100, 333), (1, 1024, 256), (3, 17, 5)]:
+    # the last two shapes are large enough for the 32-queries-per-wave instantiation (M % 128 == 0, >= 1024 blocks)
+    for B, M, N in [(1, 256, 256), (2, 100, 333), (1, 1024, 256), (3, 17, 5), (64, 256, 256), (70, 128, 200)]:
         q, k, v = (torch.randn(B * n, 256, generator=gen) for n in (M, N, N))
         out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), B, M, N, 8).cpu()
         qh = q.view(B, M, 8, 32).transpose(1, 2).double()
