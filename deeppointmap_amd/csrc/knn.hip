@@ -333,27 +333,20 @@ __device__ __forceinline__ void finish(Ctr &c, const float *__restrict__ pts, in
                                        int32_t *tie_rows = nullptr, int row = 0) {
     const int lane = lane_id();
     wave_mem_sync();
-    // global nearest among the points examined (slot 0 when nothing lies within the radius)
-    float nd = c.gd;
-    int ni = c.gi;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float od_ = __shfl_xor(nd, off, 64);
-        const int oi_ = __shfl_xor(ni, off, 64);
-        if (od_ < nd || (od_ == nd && oi_ < ni)) nd = od_, ni = oi_;
+    // Nearest of all points examined (smallest distance, then smallest index): slot 0.  When anything lies within the
+    // radius it is also the nearest candidate -- every offer updated c.gd / c.gi before the admission test, and the
+    // nearest point is never above an admission bound that admitted something -- so the candidate list is not
+    // searched again.  One DPP min over the order-preserving keys, ties (rare) broken by a second one on the index.
+    const int nk = fkey(c.gd);
+    const int kbest = wave_min_dpp(nk);
+    unsigned long long best = __ballot(nk == kbest);
+    if (__popcll(best) > 1) {
+        const int imin = wave_min_dpp(nk == kbest ? c.gi : 0x7fffffff);
+        best = __ballot(nk == kbest && c.gi == imin);
     }
+    int ni = __builtin_amdgcn_readlane(c.gi, __builtin_ctzll(best));
     if (ni == 0x7fffffff) ni = 0;  // empty frame
-    // nearest candidate (slot 0): smallest distance, then smallest index
-    int first = ni;
-    if (c.cnt > 0) {
-        int kmin = 0x7fffffff;
-        for (int p = lane; p < c.cnt; p += 64) kmin = min(kmin, fkey(cd[p]));
-        kmin = wave_min_dpp(kmin);
-        int imin = 0x7fffffff;
-        for (int p = lane; p < c.cnt; p += 64)
-            if (fkey(cd[p]) == kmin) imin = min(imin, ci[p]);
-        first = wave_min_dpp(imin);
-    }
+    const int first = ni;
     const int k = min(K, c.cnt);
     if (c.cnt > K) {
         bool tie = false;
