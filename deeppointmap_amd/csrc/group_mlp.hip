@@ -486,13 +486,33 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
         for (int v = 0; v < V; ++v)
 #pragma unroll
             for (int e = 0; e < 4; ++e) mx[v][e] = 0.f;  // ReLU floor
-#pragma unroll 4
-        for (int r0 = 0; r0 < K; r0 += RPW) {
-            const int r = min(r0 + gr, K - 1);  // K is a multiple of RPW on every shipped layer; clamped rows repeat
-            // 32-bit element offsets from the (scalar) frame pointers: a frame is far below 2^32 bytes
-            const unsigned n = (unsigned)min(max(idx_all[(size_t)cc * K + r], 0), N - 1);
-            const float *pn = xyz + n * 3u;  // one pointer, three adjacent floats: stays one 12-byte load
-            const float px = pn[0], py = pn[1], pz = pn[2];
+        // UG row passes at a time: their UG index loads go out together, then the UG x (xyz, projected row) gathers,
+        // and only then the arithmetic -- the chain index -> gather is paid once per group instead of once per pass
+        constexpr int UG = V == 1 ? (RPW >= 8 ? 4 : 8) : 2;  // K >= 16 everywhere: never more passes than rows
+        for (int r0 = 0; r0 < K; r0 += RPW * UG) {
+            unsigned ng[UG];
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                const int r = min(r0 + u * RPW + gr, K - 1);  // rows past K repeat the last one: a max does not mind
+                ng[u] = (unsigned)idx_all[(size_t)cc * K + r];
+            }
+            float pxg[UG], pyg[UG], pzg[UG];
+            float4 pg[UG][AFFINE ? 1 : V];
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                // 32-bit element offsets from the (scalar) frame pointers: a frame is far below 2^32 bytes
+                ng[u] = (unsigned)min(max((int)ng[u], 0), N - 1);
+                const float *pn = xyz + ng[u] * 3u;  // one pointer, three adjacent floats: stays one 12-byte load
+                pxg[u] = pn[0], pyg[u] = pn[1], pzg[u] = pn[2];
+                if (!AFFINE) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        pg[u][v] = *reinterpret_cast<const float4 *>(P + (ng[u] * (unsigned)COUT + 4u * (unsigned)(gl + G * v)));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+            const float px = pxg[u], py = pyg[u], pz = pzg[u];
             const float rx = (px - cx) * inv_r, ry = (py - cy) * inv_r, rz = (pz - cz) * inv_r;
             float y[V][4], sum = 0.f;
 #pragma unroll
@@ -504,7 +524,7 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
                     p4.z = fmaf(am[v][2][2], pz, fmaf(am[v][2][1], py, fmaf(am[v][2][0], px, cv[v][2])));
                     p4.w = fmaf(am[v][3][2], pz, fmaf(am[v][3][1], py, fmaf(am[v][3][0], px, cv[v][3])));
                 } else {
-                    p4 = *reinterpret_cast<const float4 *>(P + (n * (unsigned)COUT + 4u * (unsigned)(gl + G * v)));
+                    p4 = pg[u][v];
                 }
                 y[v][0] = fmaf(wr[v][0][2], rz, fmaf(wr[v][0][1], ry, fmaf(wr[v][0][0], rx, p4.x)));
                 y[v][1] = fmaf(wr[v][1][2], rz, fmaf(wr[v][1][1], ry, fmaf(wr[v][1][0], rx, p4.y)));
@@ -527,6 +547,7 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
             for (int v = 0; v < V; ++v)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) mx[v][e] = vmax_raw(mx[v][e], fmaf(y[v][e] * rs, gm[v][e], bt[v][e]));
+                    }
         }
         // max over the row groups of the wave (lanes with equal gl), then the first group stores
 #pragma unroll
