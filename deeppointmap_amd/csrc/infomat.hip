@@ -282,15 +282,22 @@ __global__ __launch_bounds__(256) void nn1_moments_kernel(PairArgs A, float r2) 
             if (p >= e) break;
             // branch-free body: an unconditional load from a clamped slot (p < e here, so e - 1 is a valid one) and
             // selects; the lanes of a quad past the end of the segment re-read its last point and are masked out
+            // NU candidates per lane and trip (4 NU per quad): their loads are in flight together
+            constexpr int NU = 2;  // 3 and 4 measured slower: most segments hold fewer than eight candidates
             const int pp = p + ql;
-            p += 4;
-            const float4 t4 = sorted[min(pp, e - 1)];
-            const float dx = qx - t4.x, dy = qy - t4.y, dz = qz - t4.z;
-            const float d = (dx * dx + dy * dy) + dz * dz;
-            const int oi = __float_as_int(t4.w);
-            const bool take = (pp < e) & ((d < best) | ((d == best) & (oi < bi)));
-            best = take ? d : best, bi = take ? oi : bi;
-            bx = take ? t4.x : bx, by = take ? t4.y : by, bz = take ? t4.z : bz;
+            p += 4 * NU;
+            float4 tc[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) tc[u] = sorted[min(pp + 4 * u, e - 1)];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const float dx = qx - tc[u].x, dy = qy - tc[u].y, dz = qz - tc[u].z;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                const int oi = __float_as_int(tc[u].w);
+                const bool take = (pp + 4 * u < e) & ((d < best) | ((d == best) & (oi < bi)));
+                best = take ? d : best, bi = take ? oi : bi;
+                bx = take ? tc[u].x : bx, by = take ? tc[u].y : by, bz = take ? tc[u].z : bz;
+            }
         }
         // quad-wide arg-best: (smallest distance, then smallest original index), with the winner's coordinates
 #pragma unroll
