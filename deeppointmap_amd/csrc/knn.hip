@@ -602,7 +602,7 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
 // re-checked against the moving top -- exactly the elements std::__heap_select would have touched, in its order.
 // The next batch of points is fetched while the replay runs.
 // ---------------------------------------------------------------------------------------------
-constexpr int TIE_U = 4;    // points per thread per step
+constexpr int TIE_U = 8;    // points per thread per step (loads in flight per thread: latency, not bandwidth, bounds a row)
 constexpr int TIE_HEAD = 4096;  // points walked step by step before the filter pass (a multiple of TIE_U * TIE_T)
 constexpr int TIE_LIST = 512;   // candidates one wave may keep in the filter pass
 constexpr int TIE_T = 256;  // threads per row: the sequential replay bounds a row, so many small workgroups beat few large ones
