@@ -317,24 +317,58 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float *__restric
         if (t < 256) hist[t] = 0u;
         __syncthreads();
         const unsigned prefix = s_prefix, mask = s_mask;
-        for (long long e = t; e < n; e += TK_THREADS) {
-            const unsigned u = __float_as_uint(P[e]);
-            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (t == 0) {
-            unsigned rem = s_krem, bsel = 0;
-            for (int bin = 255; bin >= 0; --bin) {
-                const unsigned c = hist[bin];
-                if (c >= rem) {
-                    bsel = (unsigned)bin;
-                    break;
-                }
-                rem -= c;
+        // four independent loads per trip; a thread counts runs of equal bins in a register and touches the LDS
+        // histogram only when the bin changes (dual-softmax probabilities share their leading bits: without this the
+        // first pass is 65 536 atomics on a handful of addresses)
+        unsigned run_bin = 0xffffffffu, run_cnt = 0u;
+        auto count = [&](unsigned u) {
+            if ((u & mask) != prefix) return;
+            const unsigned bin = (u >> shift) & 255u;
+            if (bin != run_bin) {
+                if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
+                run_bin = bin, run_cnt = 0u;
             }
-            s_krem = rem;
-            s_prefix = prefix | (bsel << shift);
-            s_mask = mask | (255u << shift);
+            ++run_cnt;
+        };
+        long long e = t;
+        for (; e + 3 * TK_THREADS < n; e += 4 * TK_THREADS) {
+            const unsigned u0 = __float_as_uint(P[e]), u1 = __float_as_uint(P[e + TK_THREADS]);
+            const unsigned u2 = __float_as_uint(P[e + 2 * TK_THREADS]), u3 = __float_as_uint(P[e + 3 * TK_THREADS]);
+            count(u0), count(u1), count(u2), count(u3);
+        }
+        for (; e < n; e += TK_THREADS) count(__float_as_uint(P[e]));
+        if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
+        __syncthreads();
+        if (t < 64) {
+            // the bin holding the `rem`-th largest key: lane l owns bins 255-4l .. 252-4l (descending), an inclusive
+            // scan of the lane sums finds the lane, its four bins are then walked
+            const int top = 255 - 4 * t;
+            const unsigned c0 = hist[top], c1 = hist[top - 1], c2 = hist[top - 2], c3 = hist[top - 3];
+            unsigned inc = c0 + c1 + c2 + c3;
+            const unsigned own = inc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(inc, off, 64);
+                if (t >= off) inc += o;
+            }
+            const unsigned rem0 = s_krem;
+            const unsigned long long hit = __ballot(inc >= rem0);
+            const int L = __builtin_ctzll(hit);  // k <= n: some lane always reaches rem0
+            if (t == L) {
+                unsigned rem = rem0 - (inc - own), bsel = (unsigned)top;
+                if (c0 >= rem) {
+                    bsel = (unsigned)top;
+                } else if (c0 + c1 >= rem) {
+                    bsel = (unsigned)(top - 1), rem -= c0;
+                } else if (c0 + c1 + c2 >= rem) {
+                    bsel = (unsigned)(top - 2), rem -= c0 + c1;
+                } else {
+                    bsel = (unsigned)(top - 3), rem -= c0 + c1 + c2;
+                }
+                s_krem = rem;
+                s_prefix = prefix | (bsel << shift);
+                s_mask = mask | (255u << shift);
+            }
         }
         __syncthreads();
     }
@@ -347,8 +381,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float *__restric
     if (c_eq <= TK_MAXK) {
         // unordered collection with LDS atomics: the final sort restores a deterministic order; the
         // equal-to-threshold entries are collected separately and the smallest indices among them are kept
-        for (long long e = t; e < n; e += TK_THREADS) {
-            const float v = P[e];
+        auto collect = [&](float v, long long e) {
             const unsigned u = __float_as_uint(v);
             if (u > thr) {
                 const int p = atomicAdd(&s_base[0], 1);
@@ -356,7 +389,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float *__restric
             } else if (u == thr) {
                 s_eq[atomicAdd(&s_base[1], 1)] = (int)e;
             }
+        };
+        long long e = t;
+        for (; e + 3 * TK_THREADS < n; e += 4 * TK_THREADS) {  // four independent loads per trip
+            const float v0 = P[e], v1 = P[e + TK_THREADS], v2 = P[e + 2 * TK_THREADS], v3 = P[e + 3 * TK_THREADS];
+            collect(v0, e), collect(v1, e + TK_THREADS), collect(v2, e + 2 * TK_THREADS), collect(v3, e + 3 * TK_THREADS);
         }
+        for (; e < n; e += TK_THREADS) collect(P[e], e);
         __syncthreads();
         // sort the equal entries by index (ascending) and append the first take_eq of them
         int ne2 = 1;
