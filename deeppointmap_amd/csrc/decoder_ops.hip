@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict_
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     float mx = -__builtin_inff(), sum = 0.f;
     if (c < N) {
+#pragma unroll 8  // eight loads in flight per thread: the walk down a column is a chain of dependent trips otherwise
         for (int r = g; r < M; r += 4) mx = fmaxf(mx, S[(size_t)r * N + c] * itau);
     }
     sm[g][threadIdx.x & 63] = mx;
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict_
     mx = fmaxf(fmaxf(sm[0][threadIdx.x & 63], sm[1][threadIdx.x & 63]),
                fmaxf(sm[2][threadIdx.x & 63], sm[3][threadIdx.x & 63]));
     if (c < N) {
+#pragma unroll 8
         for (int r = g; r < M; r += 4) sum += expf(S[(size_t)r * N + c] * itau - mx);
     }
     ss[g][threadIdx.x & 63] = sum;
@@ -278,17 +280,17 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void dual_softmax_kernel(float *__restrict__ S, long long total, int M, int N, float itau,
+__global__ __launch_bounds__(256) void dual_softmax_kernel(float *__restrict__ S, long long rows, int M, int N, float itau,
                                                            const float *__restrict__ rmax,
                                                            const float *__restrict__ rsum,
                                                            const float *__restrict__ cmax,
                                                            const float *__restrict__ csum) {
-    // M here is the number of rows of ONE batch element; r runs over all batch*M rows
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const long long r = e / N;
-    const int c = (int)(e - r * N);
-    const size_t cb = (size_t)(r / M) * N + c;
+    // One block = 256 consecutive columns of ONE row (M = rows of one batch element, `rows` = batch * M): the row and
+    // its batch element come from two scalar divisions per block, not from two 64-bit divisions per element.
+    const unsigned cblocks = (unsigned)(N + 255) >> 8;
+    const unsigned r = blockIdx.x / cblocks, c = (blockIdx.x - r * cblocks) * 256u + threadIdx.x;
+    if (r >= rows || c >= (unsigned)N) return;
+    const size_t e = (size_t)r * N + c, cb = (size_t)(r / (unsigned)M) * N + c;
     const float x = S[e] * itau;
     S[e] = (expf(x - rmax[r]) / rsum[r]) * (expf(x - cmax[cb]) / csum[cb]);
 }
@@ -1047,8 +1049,8 @@ extern "C" int dpm_dual_softmax_topk(float *S, int batch, int M, int N, double t
     const long long total = (long long)batch * M * N;
     hipLaunchKernelGGL(row_stats_kernel, dim3(dpm_cdiv((long long)BM, 4)), dim3(256), 0, st, S, (int)BM, N, itau, rmax, rsum);
     hipLaunchKernelGGL(col_stats_kernel, dim3(dpm_cdiv(N, 64), batch), dim3(256), 0, st, S, M, N, itau, cmax, csum);
-    hipLaunchKernelGGL(dual_softmax_kernel, dim3(dpm_cdiv(total, 256)), dim3(256), 0, st, S, total, M, N, itau, rmax,
-                       rsum, cmax, csum);
+    hipLaunchKernelGGL(dual_softmax_kernel, dim3((unsigned)(BM * dpm_cdiv(N, 256))), dim3(256), 0, st, S, (long long)BM, M, N,
+                       itau, rmax, rsum, cmax, csum);
     const long long n = (long long)M * N;
     if (n < TOPK_BIG) {
         hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(TK_THREADS), 0, st, S, n, k, out_val, out_idx);
