@@ -240,31 +240,36 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------
-// 3-NN inverse-distance interpolation + concat [skip | interpolated]; one workgroup per fine point
+// 3-NN inverse-distance interpolation + concat [skip | interpolated]; one WAVE per fine point.
+// Lane j looks at the coarse points j, j + 64, ... and keeps its own three nearest (ascending (distance, index):
+// strict <, the earlier index stays ahead on ties, as topk(k=3, largest=False) on the reference's distance row);
+// the wave's three nearest are then the heads of three rounds of a wave arg-min, the winning lane popping its head.
+// Distances in the expanded form -2ab + |a|^2 + |b|^2 like the reference (pointnext.py:205, utils.py:288-295).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void three_interp_cat_kernel(
+__global__ __launch_bounds__(256) void three_interp_cat_kernel(
     const float *__restrict__ xyz1_all, const float *__restrict__ xyz2_all, const int32_t *__restrict__ len2,
     const float *__restrict__ fea1_all, const float *__restrict__ fea2_all, int N, int S, int D1, int D2,
     float *__restrict__ out_all) {
-    const int b = blockIdx.y, n = blockIdx.x, t = threadIdx.x;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (n >= N) return;
     const float *p = xyz1_all + ((size_t)b * N + n) * 3;
     const float *q = xyz2_all + (size_t)b * S * 3;
     const float *f1 = fea1_all + ((size_t)b * N + n) * D1;
     const float *f2 = fea2_all + (size_t)b * S * D2;
     float *out = out_all + ((size_t)b * N + n) * (D1 + D2);
-    for (int c = t; c < D1; c += 128) out[c] = f1[c];
+    for (int c = lane; c < D1; c += 64) out[c] = f1[c];
     if (S == 1) {
-        for (int c = t; c < D2; c += 128) out[D1 + c] = f2[c];
+        for (int c = lane; c < D2; c += 64) out[D1 + c] = f2[c];
         return;
     }
-    // every thread redundantly finds the 3 nearest valid coarse points (S <= a few hundred).
-    // expanded form -2ab + |a|^2 + |b|^2 like the reference (pointnext.py:205, utils.py:288-295)
     const int ls = min(max(len2[b], 0), S);
     const float px = p[0], py = p[1], pz = p[2];
     const float pp = (px * px + py * py) + pz * pz;  // torch.sum(p**2,-1): sequential, unfused
-    float d0 = __builtin_inff(), d1 = d0, d2 = d0;
-    int i0 = 0, i1 = 0, i2 = 0;
-    for (int j = 0; j < ls; ++j) {
+    const float INF = __builtin_inff();
+    float d0 = INF, d1 = INF, d2 = INF;
+    int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff;
+    for (int j = lane; j < ls; j += 64) {
         const float x = q[3 * j], y = q[3 * j + 1], z = q[3 * j + 2];
         float d = -2.f * fmaf(pz, z, fmaf(py, y, px * x));
         d += pp;
@@ -277,13 +282,29 @@ __global__ __launch_bounds__(128) void three_interp_cat_kernel(
             } else d2 = d, i2 = j;
         }
     }
-    float w0 = 1.f / fmaxf(d0, 1e-8f), w1 = 1.f / fmaxf(d1, 1e-8f), w2 = 1.f / fmaxf(d2, 1e-8f);
+    float bd[3];
+    int bi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // smallest head over the lanes, ties to the smallest index
+        float md = d0;
+        int mi = i0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(md, off, 64);
+            const int oi = __shfl_xor(mi, off, 64);
+            if (od < md || (od == md && oi < mi)) md = od, mi = oi;
+        }
+        bd[k] = md, bi[k] = mi == 0x7fffffff ? 0 : mi;
+        if (i0 == mi && mi != 0x7fffffff) d0 = d1, i0 = i1, d1 = d2, i1 = i2, d2 = INF, i2 = 0x7fffffff;  // pop
+    }
+    float w0 = 1.f / fmaxf(bd[0], 1e-8f), w1 = 1.f / fmaxf(bd[1], 1e-8f), w2 = 1.f / fmaxf(bd[2], 1e-8f);
     if (ls < 3) w2 = 0.f;
     if (ls < 2) w1 = 0.f;
     const float ws = w0 + w1 + w2;
     w0 /= ws, w1 /= ws, w2 /= ws;
-    for (int c = t; c < D2; c += 128)
-        out[D1 + c] = f2[(size_t)i0 * D2 + c] * w0 + f2[(size_t)i1 * D2 + c] * w1 + f2[(size_t)i2 * D2 + c] * w2;
+    for (int c = lane; c < D2; c += 64)
+        out[D1 + c] = f2[(size_t)bi[0] * D2 + c] * w0 + f2[(size_t)bi[1] * D2 + c] * w1 + f2[(size_t)bi[2] * D2 + c] * w2;
 }
 
 }  // namespace
@@ -353,7 +374,7 @@ extern "C" int dpm_three_interp_cat(const float *xyz1, const float *xyz2, const 
                                     dpm_stream_t stream) {
     DPM_CHECK_ARG(xyz1 && xyz2 && lengths2 && fea1 && fea2 && out);
     DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && D1 >= 0 && D2 >= 1);
-    hipLaunchKernelGGL(three_interp_cat_kernel, dim3(N, B), dim3(128), 0, (hipStream_t)stream, xyz1, xyz2, lengths2,
+    hipLaunchKernelGGL(three_interp_cat_kernel, dim3(dpm_cdiv(N, 4), B), dim3(256), 0, (hipStream_t)stream, xyz1, xyz2, lengths2,
                        fea1, fea2, N, S, D1, D2, out);
     return dpm_launch_status();
 }
