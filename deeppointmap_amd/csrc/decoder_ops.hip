@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
                                                         const float *__restrict__ Kp, int ldk, long long sk,
                                                         const float *__restrict__ V, int ldv, long long sv,
                                                         float *__restrict__ O, int ldo, long long so, int M,
-                                                        int N, float scale) {
+                                                        int N, float scale, int kv_shift) {
     constexpr int TK = 64;                 // keys per tile
     __shared__ __attribute__((aligned(16))) float Ks[TK][HD + 2];  // A operand of S^T: A[i=key][k=d] = Ks[key][d]
     // A operand of O^T: A[i=d][k=key] = Vs[key][d].  Row stride 36: 16-byte aligned rows, and the four lane groups of
@@ -97,8 +97,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4;
     const int q0 = (bid % gridDim.x) * (64 * QT) + w * (16 * QT);
     const float *Qb = Q + (size_t)b * sq + h * HD;
-    const float *Kb = Kp + (size_t)b * sk + h * HD;
-    const float *Vb = V + (size_t)b * sv + h * HD;
+    // batch element b reads the keys / values of element (b + kv_shift) mod batch: with the source and target tokens
+    // of B pairs stacked as 2B sequences and kv_shift = B, ONE launch is both directions of a cross attention
+    int bk = b + kv_shift;
+    if (bk >= (int)gridDim.z) bk -= (int)gridDim.z;
+    const float *Kb = Kp + (size_t)bk * sk + h * HD;
+    const float *Vb = V + (size_t)bk * sv + h * HD;
 
     // Q^T fragments (B operand: B[k=lane>>4][j=lane&15] = Q[query lane&15][d = 4 ks + (lane>>4)]), pre-scaled
     float qa[QT][HD / 4];
@@ -1000,10 +1004,10 @@ extern "C" int dpm_posemb(const float *xyz, int ld, const float *dim_t, int F, i
     return dpm_launch_status();
 }
 
-extern "C" int dpm_attention(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
-                             const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
-                             int N, int heads, int head_dim, dpm_stream_t stream) {
-    DPM_CHECK_ARG(Q && K && V && out && B >= 1 && M >= 1 && N >= 1 && heads >= 1);
+extern "C" int dpm_attention_shifted(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                                     const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B,
+                                     int M, int N, int heads, int head_dim, int kv_shift, dpm_stream_t stream) {
+    DPM_CHECK_ARG(Q && K && V && out && B >= 1 && M >= 1 && N >= 1 && heads >= 1 && kv_shift >= 0 && kv_shift < B);
     if (head_dim != HD) return DPM_EUNSUPPORTED;
     const bool vec = ldk % 4 == 0 && ldv % 4 == 0 && sk % 4 == 0 && sv % 4 == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0 &&
                      ldo % 4 == 0 && so % 4 == 0 && ((uintptr_t)out & 15) == 0;  // 16-byte K / V loads and output stores
@@ -1012,7 +1016,7 @@ extern "C" int dpm_attention(const float *Q, int ldq, long long sq, const float 
     const bool wide = M % 128 == 0 && (long long)(M / 128) * heads * B >= 1024;
 #define DPM_ATT(V, QT)                                                                                                  \
     hipLaunchKernelGGL((attention_kernel<V, QT>), dim3(dpm_cdiv(M, 64 * QT), heads, B), dim3(256), 0, (hipStream_t)stream, \
-                       Q, ldq, sq, K, ldk, sk, V_, ldv, sv, out, ldo, so, M, N, scale)
+                       Q, ldq, sq, K, ldk, sk, V_, ldv, sv, out, ldo, so, M, N, scale, kv_shift)
     const float *V_ = V;
     if (vec && wide) DPM_ATT(true, 2);
     else if (vec) DPM_ATT(true, 1);
@@ -1020,6 +1024,12 @@ extern "C" int dpm_attention(const float *Q, int ldq, long long sq, const float 
     else DPM_ATT(false, 1);
 #undef DPM_ATT
     return dpm_launch_status();
+}
+
+extern "C" int dpm_attention(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                             const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
+                             int N, int heads, int head_dim, dpm_stream_t stream) {
+    return dpm_attention_shifted(Q, ldq, sq, K, ldk, sk, V, ldv, sv, out, ldo, so, B, M, N, heads, head_dim, 0, stream);
 }
 
 extern "C" int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stream) {

@@ -153,9 +153,9 @@ class Decoder(ParamTree):
                 z1 = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", zp, 2 * B, M), post=pos)
             ca = pre + ".cross_attn"
             qkv = ops.linear(z1, self.p(ca + ".in_proj_weight"), self.p(ca + ".in_proj_bias"))  # q | k | v of every token
-            a = torch.empty(2 * R, E, device=dev, dtype=torch.float32)
-            ops.attention(qkv[:R, :E], qkv[R:, E:2 * E], qkv[R:, 2 * E:], B, M, M, HEADS, out=a[:R])   # src <- dst
-            ops.attention(qkv[R:, :E], qkv[:R, E:2 * E], qkv[:R, 2 * E:], B, M, M, HEADS, out=a[R:])   # dst <- src
+            # both directions in one launch: sequence b (source of pair b, or target of pair b - B) reads the keys and
+            # values of sequence (b + B) mod 2B, its partner
+            a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], 2 * B, M, M, HEADS, kv_shift=B)
             z2 = self._ln(pre + ".norm2", ops.linear(a, self.p(ca + ".out_proj.weight"), self.p(ca + ".out_proj.bias"),
                                                      residual=z1))
             zp = self._ln(pre + ".norm3", self._lin(pre + ".mlp.2", self._lin(pre + ".mlp.0", z2, ops.ACT_RELU),

@@ -316,9 +316,10 @@ def posemb(xyz_rows: torch.Tensor, dim_t: torch.Tensor, emb_dim: int) -> torch.T
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, M: int, N: int, heads: int = 8,
-              out: Optional[torch.Tensor] = None):
+              out: Optional[torch.Tensor] = None, kv_shift: int = 0):
     """q (B*M,E) / k,v (B*N,E) row views (column slices of wider buffers allowed) -> (B*M,E)
-    (written into `out`, a contiguous (B*M,E) tensor or row range of one, when given)."""
+    (written into `out`, a contiguous (B*M,E) tensor or row range of one, when given).
+    kv_shift: sequence b attends the keys / values of sequence (b + kv_shift) mod B."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _rows2d(t, n)
     E = q.shape[1]
@@ -326,9 +327,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, M: int,
         out = torch.empty(B * M, E, device=q.device, dtype=torch.float32)
     elif tuple(out.shape) != (B * M, E) or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError("out must be a contiguous fp32 (B*M, E) tensor")
-    _lib.check(_lib.load().dpm_attention(_ptr(q), q.stride(0), M * q.stride(0), _ptr(k), k.stride(0), N * k.stride(0),
-                                         _ptr(v), v.stride(0), N * v.stride(0), _ptr(out), E, M * E, B, M, N, heads,
-                                         E // heads, _stream(q)), "dpm_attention")
+    _lib.check(_lib.load().dpm_attention_shifted(_ptr(q), q.stride(0), M * q.stride(0), _ptr(k), k.stride(0),
+                                                 N * k.stride(0), _ptr(v), v.stride(0), N * v.stride(0), _ptr(out), E,
+                                                 M * E, B, M, N, heads, E // heads, int(kv_shift), _stream(q)),
+               "dpm_attention")
     return out
 
 

@@ -176,6 +176,12 @@ int dpm_posemb(const float *xyz, int ld, const float *dim_t, int F, int E, int R
 int dpm_attention(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
                   const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
                   int N, int heads, int head_dim, dpm_stream_t stream);
+/* The same with batch element b reading the keys / values of element (b + kv_shift) mod B: the source and target
+ * tokens of P pairs stacked as B = 2P sequences with kv_shift = P make both directions of DescriptorAttentionLayer's
+ * cross attention (descriptor_attention.py:41-44) one launch. */
+int dpm_attention_shifted(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                          const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
+                          int N, int heads, int head_dim, int kv_shift, dpm_stream_t stream);
 
 /* F.normalize(x, p=2, dim=-1) (decoder.py:185): x / max(||x||, 1e-12), rows (R,C). */
 int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stream);

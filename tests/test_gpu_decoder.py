@@ -48,6 +48,15 @@ def test_attention_core_vs_torch(ops):
     a = ops.attention(qkv[:, :256], qkv[:, 256:512], qkv[:, 512:], 1, 256, 256, 8)
     b = ops.attention(qkv[:, :256].contiguous(), qkv[:, 256:512].contiguous(), qkv[:, 512:].contiguous(), 1, 256, 256, 8)
     assert torch.equal(a, b)
+    # kv_shift: sequence b reads the keys / values of sequence (b + shift) mod B -- both directions of a cross
+    # attention in one launch must equal the two explicit launches bit for bit
+    B, M = 6, 128
+    qkv = torch.randn(B * M, 768, generator=gen).to(DEV)
+    one = ops.attention(qkv[:, :256], qkv[:, 256:512], qkv[:, 512:], B, M, M, 8, kv_shift=B // 2)
+    R = B // 2 * M
+    two = torch.cat([ops.attention(qkv[:R, :256], qkv[R:, 256:512], qkv[R:, 512:], B // 2, M, M, 8),
+                     ops.attention(qkv[R:, :256], qkv[:R, 256:512], qkv[:R, 512:], B // 2, M, M, 8)])
+    assert torch.equal(one, two)
 
 
 def test_dual_softmax_topk_vs_torch(ops):
