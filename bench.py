@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-pipeline", action="store_true", help="run every step start-to-finish on one stream")
     ap.add_argument("--geometry-depth", type=int, default=None, help="geometry passes kept in flight (pipeline tuning)")
+    ap.add_argument("--geometry-group", type=int, default=None, help="batches per first-level sampling launch (pipeline tuning)")
     ap.add_argument("--geometry-knn", type=int, default=None, help="1: neighbour queries run in the geometry stage, 0: in the feature stage")
     ap.add_argument("--feature-streams", type=int, default=None, help="feature-stage streams (pipeline tuning)")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time breakdown to stderr")
@@ -130,6 +131,8 @@ def main():
     hot = HotPath(init_procedural(Encoder(cfg)).to(dev), init_procedural(Decoder(cfg)).to(dev))
     if args.geometry_depth is not None:
         hot.geometry_depth = args.geometry_depth
+    if args.geometry_group is not None:
+        hot.geometry_group = args.geometry_group
     if args.geometry_knn is not None:
         hot.encoder.presample_neighbours = bool(args.geometry_knn)
     if args.feature_streams is not None:
@@ -141,10 +144,11 @@ def main():
     torch.cuda.synchronize()
 
     # HIP events around the dominant kernel (first-stage FPS), recorded on the launch stream
-    fps_events = []
+    fps_events, fps_frames = [], [0]
     orig_fps = ops.fps
 
     def timed_fps(xyz, lengths, K, algo=0):
+        fps_frames[0] = xyz.shape[0]
         if xyz.shape[1] != N:
             return orig_fps(xyz, lengths, K, algo)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -17,6 +17,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
           "-ffp-contract=off"]
 SOURCES = {
     "fps.hip": [],
+    "fps_tree.hip": [],
     "knn.hip": [],
     "encoder_ops.hip": [],
     "gemm.hip": [],

@@ -60,13 +60,33 @@ class Encoder(ParamTree):
 
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
-    def presample(self, points: torch.Tensor, points_padding: torch.Tensor, levels: Optional[int] = None) -> dict:
+    def sample_first_level(self, points_list, padding_list):
+        """First-level farthest point sampling of SEVERAL batches in one launch (the sampling kernel runs one wave per
+        frame: more frames per launch = more of the chip's latency-bound chains in flight).  Returns one
+        (idx, new_xyz, new_lengths) per batch, views of the joint result."""
+        dev = self.device
+        with torch.cuda.device(dev):
+            pts = torch.cat([p.to(device=dev, dtype=torch.float32) for p in points_list], 0)
+            pad = torch.cat([p.to(device=dev) for p in padding_list], 0)
+            xyz, lengths = ops.prepare_points(pts.contiguous(), pad.contiguous())
+            fidx, new, nl = ops.fps(xyz, lengths, self.encoder_cfg.npoint[0])
+        out, o = [], 0
+        for p in points_list:
+            b = p.shape[0]
+            out.append((fidx[o:o + b], new[o:o + b], nl[o:o + b]))
+            o += b
+        return out
+
+    @torch.no_grad()
+    def presample(self, points: torch.Tensor, points_padding: torch.Tensor, levels: Optional[int] = None,
+                  sampled0=None) -> dict:
         """Input staging + the whole farthest-point-sampling chain (all levels), on the CURRENT stream.
         Sampling depends on coordinates only (level i+1 samples the points level i kept), never on features;
         it is a serial chain of dependent rounds that occupies one CU per frame, so a streaming caller runs it
         for batch i+1 on a side stream while batch i finishes on the main stream (pipeline.HotPath.submit).
         Pass the result to forward(..., presampled=...).  `levels` limits the pass to the first FPS levels (the
-        remaining, much shorter ones then run inside forward) -- a knob for balancing pipeline stages."""
+        remaining, much shorter ones then run inside forward) -- a knob for balancing pipeline stages.
+        `sampled0` = (idx, new_xyz, new_lengths) of the first level when the caller sampled it already."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("deeppointmap_amd.Encoder runs on the GPU only: call .to('cuda') first "
@@ -79,7 +99,9 @@ class Encoder(ParamTree):
             cur, cur_len = xyz, lengths
             n_levels = len(self.encoder_cfg.npoint) if levels is None else levels
             for i, npoint in enumerate(self.encoder_cfg.npoint[:n_levels]):
-                if i == 0 or not self.nested_fps:
+                if i == 0 and sampled0 is not None:  # first level sampled by the caller (several batches in one launch)
+                    fidx, cur, cur_len = sampled0
+                elif i == 0 or not self.nested_fps:
                     fidx, cur, cur_len = ops.fps(cur, cur_len, npoint)
                 else:  # prefix of the previous level (index bookkeeping only; rows past a short frame are zero already)
                     cur_len = torch.clamp(cur_len, max=npoint)

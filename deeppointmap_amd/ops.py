@@ -8,6 +8,7 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
 import weakref
 
 import torch
@@ -62,6 +63,8 @@ def fps(xyz: torch.Tensor, lengths: torch.Tensor, K: int, algo: int = 0):
     _chk(lengths, torch.int32, "lengths")
     B, N, _ = xyz.shape
     lib = _lib.load()
+    if algo == 0 and N > 16384 and "DPM_FPS_ALGO" in os.environ:  # tuning knob (scripts/, bench experiments)
+        algo = int(os.environ["DPM_FPS_ALGO"])
     idx = torch.empty(B, K, device=xyz.device, dtype=torch.int32)
     new_xyz = torch.empty(B, K, 3, device=xyz.device, dtype=torch.float32)
     new_len = torch.empty(B, device=xyz.device, dtype=torch.int32)

@@ -47,7 +47,8 @@ class HotPath:
         self.encoder, self.decoder = encoder, decoder
         self.coor_scale, self.num_sample = float(coor_scale), num_sample
         self.geometry_levels = None  # FPS levels run by the geometry stage (None = all; measured best on MI355X)
-        self.geometry_depth = 2      # batches whose geometry pass is in flight ahead of the feature stage
+        self.geometry_depth = 2      # geometry launches in flight ahead of the feature stage (one HIP stream each)
+        self.geometry_group = 1      # batches whose first-level sampling shares ONE launch
         self.feature_streams = 1     # >1: consecutive batches' feature stages alternate between side streams
         self._side = None      # side HIP streams for the software pipeline (submit / flush)
         self._pending = None
@@ -124,34 +125,44 @@ class HotPath:
         fills).  Inputs must already be ready on the device (stage G reads them without waiting for the caller's
         stream)."""
         dev = self.encoder.device
-        main = torch.cuda.current_stream(dev)
         if self._side is None:
             self._side = dict(geo=[torch.cuda.Stream(device=dev) for _ in range(max(1, self.geometry_depth))],
                               reg=torch.cuda.Stream(device=dev),
                               feat=[torch.cuda.Stream(device=dev) for _ in range(self.feature_streams)]
                               if self.feature_streams > 1 else [])
-            self._pending = dict(geo=[], reg=None, n=0, nf=0)
-        sa = self._side["geo"][self._pending["n"] % len(self._side["geo"])]
-        self._pending["n"] += 1
-        grids = None
-        if pcd_m is not None:
-            ring = self._ring_pairs(points.shape[0], dev)  # before the stream switch: a first call copies H2D
-        with torch.cuda.stream(sa):
-            pre = self.encoder.presample(points, padding, levels=self.geometry_levels)
-            ready = sa.record_event()
-            if pcd_m is not None:
-                # the information matrix's target grids need no pose: built here, off the registration stream
-                grids = ops.information_matrix_grids(pcd_m, ring[1][1])
-                grids.record_stream(self._side["reg"])
-                grids_ready = sa.record_event()
-        for t in _tensors(pre):
-            t.record_stream(main)  # produced on a geometry stream, consumed on the caller's stream
-        self._pending["geo"].append((pre, ready, points, padding,
-                                     (pcd_m, grids, grids_ready) if pcd_m is not None else None))
+            self._pending = dict(geo=[], reg=None, n=0, nf=0, hold=[])
+        self._pending["hold"].append((points, padding, pcd_m))
+        if len(self._pending["hold"]) >= max(1, self.geometry_group):
+            self._launch_geometry()
         done = None
-        if len(self._pending["geo"]) > self.geometry_depth:
+        if len(self._pending["geo"]) + len(self._pending["hold"]) > self.geometry_depth * max(1, self.geometry_group) \
+                and self._pending["geo"]:
             done = self._advance(self._pending["geo"].pop(0))
         return done
+
+    def _launch_geometry(self):
+        """Stage G of the held batches on the next geometry stream: one joint first-level sampling launch, then
+        per batch the staging, the lower levels and the search grids."""
+        dev = self.encoder.device
+        main = torch.cuda.current_stream(dev)
+        hold, self._pending["hold"] = self._pending["hold"], []
+        sa = self._side["geo"][self._pending["n"] % len(self._side["geo"])]
+        self._pending["n"] += 1
+        rings = [self._ring_pairs(h[0].shape[0], dev) if h[2] is not None else None for h in hold]  # before the stream switch: a first call copies H2D
+        with torch.cuda.stream(sa):
+            first = self.encoder.sample_first_level([h[0] for h in hold], [h[1] for h in hold]) if len(hold) > 1 else [None]
+            for (points, padding, pcd_m), ring, s0 in zip(hold, rings, first):
+                pre = self.encoder.presample(points, padding, levels=self.geometry_levels, sampled0=s0)
+                ready = sa.record_event()
+                scans = None
+                if pcd_m is not None:
+                    # the information matrix's target grids need no pose: built here, off the registration stream
+                    grids = ops.information_matrix_grids(pcd_m, ring[1][1])
+                    grids.record_stream(self._side["reg"])
+                    scans = (pcd_m, grids, sa.record_event())
+                for t in _tensors(pre):
+                    t.record_stream(main)  # produced on a geometry stream, consumed on the caller's stream
+                self._pending["geo"].append((pre, ready, points, padding, scans))
 
     def _advance(self, geo):
         """features of `geo` on the caller's stream, then registration of the batch before it on stream B."""
@@ -200,6 +211,8 @@ class HotPath:
         out = []
         if self._side is None:
             return out
+        if self._pending["hold"]:
+            self._launch_geometry()
         while self._pending["geo"]:
             r = self._advance(self._pending["geo"].pop(0))
             if r is not None:

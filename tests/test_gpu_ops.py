@@ -56,7 +56,7 @@ def test_fps_bit_exact_vs_reference_fixtures(ops, algo):
         assert int(nl[0]) == min(length, K)
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2, 3])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4])
 def test_fps_full_size_synthetic_bit_exact(ops, algo):
     g = load_golden("fps.npz")
     pts = synthetic.frame(0).t().contiguous()
@@ -72,7 +72,7 @@ def test_fps_batched_ragged_and_ties(ops):
     pts = torch.rand(B, N, 3, generator=gen)
     pts[1] = torch.round(pts[1] * 8) / 8  # heavy ties: first-index rule must hold
     lens = [20000, 20000, 17001, 300, 1]
-    for algo in (1, 2, 3):
+    for algo in (1, 2, 3, 4):
         idx, new, nl = ops.fps(pts.to(DEV), _lengths(lens), K, algo=algo)
         for b in range(B):
             want = O.fps_indices_fast(pts[b], lens[b], K)
@@ -97,11 +97,32 @@ def test_fps_speculative_rounds_on_adversarial_clouds(ops):
     pts = torch.stack([lattice, clusters, line, uniform])
     for K, lens in ((2500, [N, N, N, N]), (20000, [N, 25000, N, 20001])):
         wants = [O.fps_indices_fast(pts[b], lens[b], K) for b in range(4)]
-        for algo in (3,):  # multi-pick rounds
+        for algo in (3, 4):  # multi-pick rounds; one-wave tree
             idx, new, nl = ops.fps(pts.to(DEV), _lengths(lens), K, algo=algo)
             for b in range(4):
                 assert torch.equal(idx[b].cpu().long(), wants[b]), (algo, K, b)
                 assert torch.equal(new[b].cpu(), O.gather_masked(pts[b], wants[b]))
+
+
+def test_fps_tree_ragged_batch_full_size(ops):
+    """algo 4 (one wave per frame over the Sort-Tile-Recursive box tree): full-size frames of different valid lengths
+    in one launch, including lengths that leave slabs and leaves partly empty, and K beyond a short frame."""
+    pts, _ = synthetic.frames(4, 65536)
+    pts = pts.transpose(1, 2).contiguous()
+    pts[3] = torch.round(pts[3] * 64) / 64  # quantised copy: many exactly equal distances
+    lens = [65536, 40001, 16385, 65535]
+    idx, new, nl = ops.fps(pts.to(DEV), _lengths(lens), 4096, algo=4)
+    for b in range(4):
+        want = O.fps_indices_fast(pts[b], lens[b], 4096)
+        assert torch.equal(idx[b].cpu().long(), want), b
+        assert torch.equal(new[b].cpu(), O.gather_masked(pts[b], want))
+    idx2, _, nl2 = ops.fps(pts[:, :17000].contiguous().to(DEV), _lengths([17000, 100, 0, 1]), 300, algo=4)
+    ref2, _, _ = ops.fps(pts[:, :17000].contiguous().to(DEV), _lengths([17000, 100, 0, 1]), 300, algo=2)
+    assert torch.equal(idx2, ref2)  # an empty frame keeps slot 0 = index 0 (utils.py:249-250), like the other kernels
+    for b, l in enumerate([17000, 100, 0, 1]):
+        if l > 0:
+            assert torch.equal(idx2[b].cpu().long(), O.fps_indices_fast(pts[b, :17000], l, 300)), b
+    assert nl2.cpu().tolist() == [300, 100, 1, 1]
 
 
 def test_fps_all_levels_sizes(ops):
