@@ -664,6 +664,17 @@ __device__ T block_sum(T v, T *scratch /* KB/64 entries */) {
     return r;
 }
 
+__device__ float block_max(float v, float *scratch /* KB/64 entries */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int i = 1; i < KB / 64; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}
+
 // one-sided Jacobi SVD of a 3x3 (fp64): A = U diag(s) V^T; returns R = V U^T
 __device__ void rot_from_cov(const double A[9], double Rm[9]) {
     double G[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -725,6 +736,97 @@ __device__ void rot_from_cov(const double A[9], double Rm[9]) {
 // [16] mean of the first 30 inlier confidences (simvec_to_num, system/modules/utils.py:18), [17:20] reserved,
 // [20 : 20+n_inlier] confidences of the inliers (in correspondence order).  `header` (optional) receives a
 // copy of the first 20 floats (lets the caller assemble an edge table without extra kernels).
+// ---- torch.topk's choice among EQUAL weights (decoder.py:233-235: inlier[topk(w, 64)] = True).  The weights are two
+// copies of the confidences, so once some offsets are cut away the 64th and 65th largest weight are the same value
+// about every other call, and which of the two correspondences becomes an initial inlier is whatever the CPU kernel
+// of torch.topk leaves in front: std::nth_element for k * 64 > n, std::partial_sort's heap-select otherwise
+// (aten/src/ATen/native/cpu/TopKImpl.h), on (value, index) pairs in index order with comp(a, b) = a.value > b.value.
+// A straddling tie is resolved by replaying libstdc++'s algorithms step by step on one thread (validated against
+// torch.topk on 1429 tie-heavy arrays, heap fallback of the introselect included); without a tie the set is unique
+// and the parallel ranking above it stands.
+struct VI {
+    float v;
+    int i;
+};
+__device__ __forceinline__ bool vi_gt(const VI &a, const VI &b) { return a.v > b.v; }
+__device__ void vi_adjust_heap(VI *a, int hole, int len, VI value) {  // std::__adjust_heap + __push_heap
+    const int top = hole;
+    int sc = hole;
+    while (sc < (len - 1) / 2) {
+        sc = 2 * (sc + 1);
+        if (vi_gt(a[sc], a[sc - 1])) --sc;
+        a[hole] = a[sc], hole = sc;
+    }
+    if ((len & 1) == 0 && sc == (len - 2) / 2) {
+        sc = 2 * (sc + 1);
+        a[hole] = a[sc - 1], hole = sc - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && vi_gt(a[parent], value)) a[hole] = a[parent], hole = parent, parent = (hole - 1) / 2;
+    a[hole] = value;
+}
+__device__ void vi_heap_select(VI *a, int first, int middle, int last) {  // std::__heap_select
+    const int len = middle - first;
+    if (len >= 2)
+        for (int parent = (len - 2) / 2;; --parent) {
+            vi_adjust_heap(a + first, parent, len, a[first + parent]);
+            if (parent == 0) break;
+        }
+    for (int i = middle; i < last; ++i)
+        if (vi_gt(a[i], a[first])) {
+            const VI value = a[i];
+            a[i] = a[first];
+            vi_adjust_heap(a + first, 0, len, value);
+        }
+}
+__device__ void vi_nth_element(VI *a, int n, int nth) {  // std::nth_element -> std::__introselect
+    int first = 0, last = n;
+    int depth = 2 * (31 - __builtin_clz(n));
+    auto sw = [&](int x, int y) {
+        const VI t = a[x];
+        a[x] = a[y], a[y] = t;
+    };
+    while (last - first > 3) {
+        if (depth == 0) {
+            vi_heap_select(a, first, nth + 1, last);
+            sw(first, nth);
+            return;
+        }
+        --depth;
+        const int A = first + 1, B = first + (last - first) / 2, C = last - 1;  // __move_median_to_first
+        if (vi_gt(a[A], a[B])) {
+            if (vi_gt(a[B], a[C])) sw(first, B);
+            else if (vi_gt(a[A], a[C])) sw(first, C);
+            else sw(first, A);
+        } else if (vi_gt(a[A], a[C])) sw(first, A);
+        else if (vi_gt(a[B], a[C])) sw(first, C);
+        else sw(first, B);
+        const VI pivot = a[first];  // __unguarded_partition(first + 1, last, first)
+        int lo = first + 1, hi = last;
+        while (true) {
+            while (vi_gt(a[lo], pivot)) ++lo;
+            --hi;
+            while (vi_gt(pivot, a[hi])) --hi;
+            if (!(lo < hi)) break;
+            sw(lo, hi);
+            ++lo;
+        }
+        if (lo <= nth) first = lo;
+        else last = lo;
+    }
+    for (int i = first + 1; i < last; ++i) {  // __insertion_sort
+        const VI val = a[i];
+        if (vi_gt(val, a[first])) {
+            for (int j = i; j > first; --j) a[j] = a[j - 1];
+            a[first] = val;
+        } else {
+            int j = i;
+            while (vi_gt(val, a[j - 1])) a[j] = a[j - 1], --j;
+            a[j] = val;
+        }
+    }
+}
+
 __global__ __launch_bounds__(KB) void corr_kabsch_kernel(
     const float *__restrict__ off /* (2k,3) */, const float *__restrict__ sxyz, int lds_, long long ssrc,
     const float *__restrict__ dxyz, int ldd, long long sdst, const int32_t *__restrict__ si,
@@ -810,7 +912,7 @@ __global__ __launch_bounds__(KB) void corr_kabsch_kernel(
             const float wp = wt[p];
             int before = 0;
             for (int q = 0; q < n; ++q) before += (wt[q] > wp) || (wt[q] == wp && q < p);
-            inl[p] = (wp > 0.5f) || (before < min(64, n));
+            inl[p] = (wp > 0.5f ? 1 : 0) | (before < min(64, n) ? 2 : 0);  // bit 1: among the 64 largest by (weight, index)
         }
     } else {
         auto lower = [&](int lo, int hi, int key) {  // first q in [lo,hi) with rank[q] >= key (rank is ascending)
@@ -829,10 +931,38 @@ __global__ __launch_bounds__(KB) void corr_kabsch_kernel(
             const int a_lt = lower(0, nA, j), a_le = lower(0, nA, j + 1);
             const int b_lt = lower(nA, n, k + j) - nA;
             const int before = a_lt + b_lt + (isB ? (a_le - a_lt) : 0);
-            inl[p] = (wt[p] > 0.5f) || (before < min(64, n));
+            inl[p] = (wt[p] > 0.5f ? 1 : 0) | (before < min(64, n) ? 2 : 0);
         }
     }
     __syncthreads();
+    {   // ---- equal weights across the top-64 boundary: the reference's pick (see vi_nth_element above)
+        extern __shared__ VI s_vi[];
+        const int kk = min(64, n);
+        float vmin = __builtin_inff();  // the kk-th largest weight = the smallest one the ranking admitted
+        for (int p = t; p < n; p += KB) {
+            s_vi[p].v = wt[p], s_vi[p].i = p;
+            if (inl[p] & 2) vmin = fminf(vmin, wt[p]);
+        }
+        vmin = -block_max(-vmin, s_f);
+        int ge = 0;
+        for (int p = t; p < n; p += KB) {
+            ge += wt[p] >= vmin;
+            inl[p] = inl[p] != 0;
+        }
+        ge = block_sum(ge, s_cnt);
+        if (ge > kk && !(vmin > 0.5f)) {  // a tie straddles the boundary and the 0.5 rule does not decide it
+            if (t == 0) {
+                if (kk * 64 <= n) vi_heap_select(s_vi, 0, kk, n);
+                else vi_nth_element(s_vi, n, kk - 1);
+            }
+            __syncthreads();
+            for (int p = t; p < n; p += KB)
+                if (wt[p] == vmin) inl[p] = 0;
+            __syncthreads();
+            for (int j = t; j < kk; j += KB) inl[s_vi[j].i] = 1;
+        }
+        __syncthreads();
+    }
     int iter = 0;
     float rmse = 0.f;
     int n_in = 0;
@@ -1113,7 +1243,8 @@ extern "C" int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int l
     DPM_CHECK_ARG(src_xyz && dst_xyz && conf && workspace && result && batch >= 1);
     DPM_CHECK_ARG(!offsets || (src_idx && dst_idx));
     DPM_CHECK_ARG(k >= 1 && ld_src >= 3 && ld_dst >= 3 && num_iter >= 1 && (!header || header_stride >= RES_HDR));
-    hipLaunchKernelGGL(corr_kabsch_kernel, dim3(batch), dim3(KB), 0, (hipStream_t)stream, offsets, src_xyz, ld_src,
+    if (k > 8192) return DPM_EUNSUPPORTED;  // (value, index) of the 2k weights live in LDS: 16 B per pair
+    hipLaunchKernelGGL(corr_kabsch_kernel, dim3(batch), dim3(KB), sizeof(VI) * 2 * (size_t)k, (hipStream_t)stream, offsets, src_xyz, ld_src,
                        stride_src, dst_xyz, ld_dst, stride_dst, src_idx, dst_idx, conf, k,
                        (float)(eps_offset * eps_offset), num_iter, (float)std_ratio, (float *)workspace, result, header,
                        header_stride);

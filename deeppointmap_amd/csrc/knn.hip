@@ -1148,7 +1148,9 @@ extern "C" int dpm_knn_self(const float *xyz, int N, int K, double cell, int32_t
     int *tie_count = (int *)p;
     // one "frame" of N points, all valid: the length lives in the workspace header area
     int32_t *len_dev = (int32_t *)(tie_count + 8);
-    hipError_t e = hipMemcpyAsync(len_dev, &N, sizeof(int32_t), hipMemcpyHostToDevice, st);
+    // written by the device itself (a fill, not a copy from this function's stack: the runtime may stage a pageable
+    // source after we have returned, and a fill is capturable in a HIP graph)
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)len_dev, N, 1, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(knn_grid_build_kernel, dim3(1), dim3(1024), 0, st, xyz, len_dev, N, (float)cell, hdr, start, sorted,
                        tie_count);
@@ -1170,7 +1172,9 @@ extern "C" int dpm_point_normals(const float *xyz, int N, double radius, float *
     p = (p + sizeof(float4) * (size_t)N + 255) & ~(uintptr_t)255;
     int *tie_count = (int *)p;
     int32_t *len_dev = (int32_t *)(tie_count + 8);
-    hipError_t e = hipMemcpyAsync(len_dev, &N, sizeof(int32_t), hipMemcpyHostToDevice, st);
+    // written by the device itself (a fill, not a copy from this function's stack: the runtime may stage a pageable
+    // source after we have returned, and a fill is capturable in a HIP graph)
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)len_dev, N, 1, st);
     if (e != hipSuccess) return (int)e;
     // cell edge slightly above the radius: the 3x3 block then contains every point strictly within it
     hipLaunchKernelGGL(knn_grid_build_kernel, dim3(1), dim3(1024), 0, st, xyz, len_dev, N, (float)(radius * 1.001), hdr, start,

@@ -375,10 +375,13 @@ def correspondence_sets(sd: SD, cfg, xs: Tensor, ps: Tensor, yd: Tensor, pd: Ten
 # ----------------------------------------------------------------------------------------------
 # a15  iterative weighted Kabsch                           decoder.py:227-265
 # ----------------------------------------------------------------------------------------------
-def solve_svd(w: Tensor, src: Tensor, dst: Tensor, num_iter: int = 3, std_ratio: float = 3.0):
+def solve_svd(w: Tensor, src: Tensor, dst: Tensor, num_iter: int = 3, std_ratio: float = 3.0, margins: list = None):
     """w (n,), src/dst (3,n) -> (R (3,3) f32, T (3,1) f32, inlier mask (n,), rmse float).
 
     R = V U^T from torch.svd of the fp64 covariance, no reflection fix (decoder.py:242-243).
+    `margins` (test aid): per round, the smallest relative distance of any residual to the inlier cut mean + 3 std --
+    a round whose margin is at rounding level (< 1e-5) decides an inlier on the last bits of fp32 sums, and any
+    implementation that adds in another order (another BLAS, another thread count, a GPU) may decide it the other way.
     """
     it = 0
     inl = w > 0.5
@@ -394,6 +397,9 @@ def solve_svd(w: Tensor, src: Tensor, dst: Tensor, num_iter: int = 3, std_ratio:
         R, T = R.to(src.dtype), T.to(src.dtype)
         err = torch.norm(R @ src + T - dst, p=2, dim=0)
         new = err <= (err[inl].mean() + std_ratio * err[inl].std())
+        if margins is not None:
+            thr = err[inl].mean() + std_ratio * err[inl].std()
+            margins.append(float(((err - thr).abs() / thr).min()))
         it += 1
         stop = it >= num_iter or bool((inl == new).all()) or int(new.sum()) < 30
         inl = new
@@ -411,9 +417,10 @@ def registration_forward(sd: SD, cfg, src_desc: Tensor, dst_desc: Tensor, num_sa
     x, ps, y, pd = descriptor_attention(sd, cfg, src_desc.unsqueeze(0), dst_desc.unsqueeze(0))
     si, di, conf = descriptor_pairing(sd, cfg, x, y, num_sample)
     src, dst, w = correspondence_sets(sd, cfg, x[0, si], ps[0, si], y[0, di], pd[0, di], conf)
-    R, T, inl, rmse = solve_svd(w, src, dst)
+    margins = [] if trace is not None else None
+    R, T, inl, rmse = solve_svd(w, src, dst, margins=margins)
     if trace is not None:
-        trace.update(x=x, y=y, src_index=si, dst_index=di, conf=conf, src=src, dst=dst, w=w, inlier=inl)
+        trace.update(x=x, y=y, src_index=si, dst_index=di, conf=conf, src=src, dst=dst, w=w, inlier=inl, margins=margins)
     return R, T, w[inl], rmse
 
 

@@ -108,6 +108,27 @@ def test_kabsch_loop_vs_reference(name, ops):
         assert np.linalg.det(R.double().numpy()) < 0  # R = V U^T is left uncorrected (decoder.py:243)
 
 
+@pytest.mark.parametrize("n", [70, 253, 1000, 4095, 4096, 5000])
+def test_kabsch_initial_inliers_with_tied_weights(n, ops):
+    """decoder.py:233-235 seeds the inliers with torch.topk(w, 64), and w holds every confidence twice: equal weights
+    straddle the 64th place about every other call.  Which of them torch.topk returns is std::nth_element's (n < 4096)
+    or std::partial_sort's (n >= 4096) business; the kernel replays it.  The oracle calls torch.topk itself."""
+    g = torch.Generator().manual_seed(n)
+    src = torch.randn(3, n, generator=g) * 10
+    a = 0.2
+    R = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float32)
+    dst = R @ src + torch.tensor([[0.5], [1.0], [-0.25]]) + 0.3 * torch.randn(3, n, generator=g)
+    for levels in (6, 40):  # few distinct values: ties everywhere; more values: the occasional straddling pair
+        w = (torch.randint(0, levels, (n // 2 + 1,), generator=g).float() / (2.5 * levels)).sort(descending=True).values
+        w = torch.cat([w, w])[torch.randperm(2 * w.numel(), generator=g)[:n].sort().values]  # two descending runs, holes
+        Ro, To, inl, rmse = O.solve_svd(w, src, dst)
+        res = ops.corr_kabsch(None, src.t().contiguous().to(DEV), dst.t().contiguous().to(DEV), None, None, w.to(DEV), 2.0).cpu()
+        n_in = int(res[14])
+        assert n_in == int(inl.sum()), (n, levels)
+        assert torch.equal(res[20:20 + n_in], w[inl]), (n, levels)
+        assert float((res[9:12].view(3, 1) - To).norm()) < 2e-5 and rot_angle(res[:9].view(3, 3), Ro) < 1e-5
+
+
 @pytest.mark.parametrize("name", ["synthetic01", "kitti01", "map1024_vs_256"])
 def test_registration_forward_vs_reference(name, dec):
     g = load_golden("decoder.npz")
