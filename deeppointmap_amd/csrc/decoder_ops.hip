@@ -3,6 +3,7 @@
 // (fp64 3x3 SVD on device), row mean.  fp32 like the reference unless stated.
 // Compiled with -ffp-contract=off: every fused multiply-add is an explicit fmaf().
 #include "dpm_common.h"
+#include "topk_emulate.h"
 #include <algorithm>
 
 namespace {
@@ -738,95 +739,9 @@ __device__ void rot_from_cov(const double A[9], double Rm[9]) {
 // copy of the first 20 floats (lets the caller assemble an edge table without extra kernels).
 // ---- torch.topk's choice among EQUAL weights (decoder.py:233-235: inlier[topk(w, 64)] = True).  The weights are two
 // copies of the confidences, so once some offsets are cut away the 64th and 65th largest weight are the same value
-// about every other call, and which of the two correspondences becomes an initial inlier is whatever the CPU kernel
-// of torch.topk leaves in front: std::nth_element for k * 64 > n, std::partial_sort's heap-select otherwise
-// (aten/src/ATen/native/cpu/TopKImpl.h), on (value, index) pairs in index order with comp(a, b) = a.value > b.value.
-// A straddling tie is resolved by replaying libstdc++'s algorithms step by step on one thread (validated against
-// torch.topk on 1429 tie-heavy arrays, heap fallback of the introselect included); without a tie the set is unique
-// and the parallel ranking above it stands.
-struct VI {
-    float v;
-    int i;
-};
-__device__ __forceinline__ bool vi_gt(const VI &a, const VI &b) { return a.v > b.v; }
-__device__ void vi_adjust_heap(VI *a, int hole, int len, VI value) {  // std::__adjust_heap + __push_heap
-    const int top = hole;
-    int sc = hole;
-    while (sc < (len - 1) / 2) {
-        sc = 2 * (sc + 1);
-        if (vi_gt(a[sc], a[sc - 1])) --sc;
-        a[hole] = a[sc], hole = sc;
-    }
-    if ((len & 1) == 0 && sc == (len - 2) / 2) {
-        sc = 2 * (sc + 1);
-        a[hole] = a[sc - 1], hole = sc - 1;
-    }
-    int parent = (hole - 1) / 2;
-    while (hole > top && vi_gt(a[parent], value)) a[hole] = a[parent], hole = parent, parent = (hole - 1) / 2;
-    a[hole] = value;
-}
-__device__ void vi_heap_select(VI *a, int first, int middle, int last) {  // std::__heap_select
-    const int len = middle - first;
-    if (len >= 2)
-        for (int parent = (len - 2) / 2;; --parent) {
-            vi_adjust_heap(a + first, parent, len, a[first + parent]);
-            if (parent == 0) break;
-        }
-    for (int i = middle; i < last; ++i)
-        if (vi_gt(a[i], a[first])) {
-            const VI value = a[i];
-            a[i] = a[first];
-            vi_adjust_heap(a + first, 0, len, value);
-        }
-}
-__device__ void vi_nth_element(VI *a, int n, int nth) {  // std::nth_element -> std::__introselect
-    int first = 0, last = n;
-    int depth = 2 * (31 - __builtin_clz(n));
-    auto sw = [&](int x, int y) {
-        const VI t = a[x];
-        a[x] = a[y], a[y] = t;
-    };
-    while (last - first > 3) {
-        if (depth == 0) {
-            vi_heap_select(a, first, nth + 1, last);
-            sw(first, nth);
-            return;
-        }
-        --depth;
-        const int A = first + 1, B = first + (last - first) / 2, C = last - 1;  // __move_median_to_first
-        if (vi_gt(a[A], a[B])) {
-            if (vi_gt(a[B], a[C])) sw(first, B);
-            else if (vi_gt(a[A], a[C])) sw(first, C);
-            else sw(first, A);
-        } else if (vi_gt(a[A], a[C])) sw(first, A);
-        else if (vi_gt(a[B], a[C])) sw(first, C);
-        else sw(first, B);
-        const VI pivot = a[first];  // __unguarded_partition(first + 1, last, first)
-        int lo = first + 1, hi = last;
-        while (true) {
-            while (vi_gt(a[lo], pivot)) ++lo;
-            --hi;
-            while (vi_gt(pivot, a[hi])) --hi;
-            if (!(lo < hi)) break;
-            sw(lo, hi);
-            ++lo;
-        }
-        if (lo <= nth) first = lo;
-        else last = lo;
-    }
-    for (int i = first + 1; i < last; ++i) {  // __insertion_sort
-        const VI val = a[i];
-        if (vi_gt(val, a[first])) {
-            for (int j = i; j > first; --j) a[j] = a[j - 1];
-            a[first] = val;
-        } else {
-            int j = i;
-            while (vi_gt(val, a[j - 1])) a[j] = a[j - 1], --j;
-            a[j] = val;
-        }
-    }
-}
-
+// about every other call, and which of the two correspondences becomes an initial inlier is whatever torch.topk's CPU
+// kernel leaves in front.  A straddling tie is resolved by replaying it (topk_emulate.h); without a tie the set is
+// unique and the parallel ranking stands.
 __global__ __launch_bounds__(KB) void corr_kabsch_kernel(
     const float *__restrict__ off /* (2k,3) */, const float *__restrict__ sxyz, int lds_, long long ssrc,
     const float *__restrict__ dxyz, int ldd, long long sdst, const int32_t *__restrict__ si,
@@ -952,8 +867,8 @@ __global__ __launch_bounds__(KB) void corr_kabsch_kernel(
         ge = block_sum(ge, s_cnt);
         if (ge > kk && !(vmin > 0.5f)) {  // a tie straddles the boundary and the 0.5 rule does not decide it
             if (t == 0) {
-                if (kk * 64 <= n) vi_heap_select(s_vi, 0, kk, n);
-                else vi_nth_element(s_vi, n, kk - 1);
+                if (kk * 64 <= n) vi_heap_select<true>(s_vi, 0, kk, n);
+                else vi_nth_element<true>(s_vi, n, kk - 1);
             }
             __syncthreads();
             for (int p = t; p < n; p += KB)

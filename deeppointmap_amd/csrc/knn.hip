@@ -33,6 +33,7 @@
 //    become ~150 per centre.  A centre with nothing inside the radius (only padded centres) falls
 //    back to a full scan for its nearest point.
 #include "dpm_common.h"
+#include "topk_emulate.h"
 
 namespace {
 
@@ -252,6 +253,28 @@ __device__ void heap_select_exact(const float *__restrict__ pts, int len, int K,
     }
 }
 
+// torch.topk's OTHER branch, k * 64 > n (every encoder level below 2048 points): std::nth_element over the whole row of
+// N distances in index order (padded points are pushed far away by the reference, utils.py:80-81: they compare above
+// every real point and equal among themselves, which +inf reproduces).  One wave fills the row, lane 0 replays
+// libstdc++ (topk_emulate.h), the K survivors land in hv/hi.  `row` needs N entries (LDS).
+__device__ void nth_select_exact(const float *__restrict__ pts, int len, int N, int K, float cx, float cy, float cz,
+                                 float caa, VI *row, LdsF hv, LdsI hi) {
+    const int lane = lane_id();
+    for (int i = lane; i < N; i += 64) {
+        float d = __builtin_inff();
+        if (i < len) {
+            const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+            d = exp_dist(cx, cy, cz, caa, x, y, z, sq3(x, y, z));
+        }
+        row[i].v = d, row[i].i = i;
+    }
+    wave_mem_sync();
+    if (lane == 0) vi_nth_element<false>(row, N, K - 1);
+    wave_mem_sync();
+    if (lane < K) hv[lane] = row[lane].v, hi[lane] = row[lane].i;
+    wave_mem_sync();
+}
+
 // K survivors of the heap-select in hv/hi -> the K output slots (executed by one full wave): slots beyond the
 // radius are replaced by the nearest point (utils.py:85-87) and the nearest point itself goes to slot 0.
 __device__ __forceinline__ void emit_heap_result(LdsF hv, LdsI hi, int K, float r2, int32_t *__restrict__ out) {
@@ -330,7 +353,7 @@ __device__ __forceinline__ void offer_d(Ctr &c, float d, int i, int K, LdsF cd, 
 __device__ __forceinline__ void finish(Ctr &c, const float *__restrict__ pts, int len, int N, int K, float r2,
                                        LdsF cd, LdsI ci, LdsF td, LdsI ti,
                                        int32_t *__restrict__ out, int *tie_count = nullptr,
-                                       int32_t *tie_rows = nullptr, int row = 0) {
+                                       int32_t *tie_rows = nullptr, int row = 0, VI *nth_row = nullptr) {
     const int lane = lane_id();
     wave_mem_sync();
     // Nearest of all points examined (smallest distance, then smallest index): slot 0.  When anything lies within the
@@ -357,7 +380,7 @@ __device__ __forceinline__ void finish(Ctr &c, const float *__restrict__ pts, in
         wave_mem_sync();
     }
     const bool heap_regime = (long long)K * 64 <= (long long)N;  // torch.topk: partial_sort vs nth_element
-    bool exact_here = c.tie && heap_regime && len >= K;
+    bool exact_here = c.tie && len >= K && (heap_regime || tie_count || nth_row);
     if (exact_here && tie_count) {
         // Grid path: the sequential emulation streams the whole frame and would leave this wave running long after
         // the rest of the kernel has drained, so the row is queued for knn_tie_kernel (one workgroup
@@ -370,10 +393,12 @@ __device__ __forceinline__ void finish(Ctr &c, const float *__restrict__ pts, in
             exact_here = false;
         }
     }
+    if (exact_here && !heap_regime && !nth_row) exact_here = false;  // (queue full and no row scratch: smallest indices)
     if (exact_here) {
         // boundary tie: reproduce the reference's choice exactly (rare, sequential)
         wave_mem_sync();
-        heap_select_exact(pts, len, K, c.x, c.y, c.z, c.aa, cd, ci, td);
+        if (heap_regime) heap_select_exact(pts, len, K, c.x, c.y, c.z, c.aa, cd, ci, td);
+        else nth_select_exact(pts, len, N, K, c.x, c.y, c.z, c.aa, nth_row, cd, ci);
         emit_heap_result(cd, ci, K, r2, out);
     } else {
         // unsorted selection: put the nearest point into slot 0 by swapping it with whatever sits there
@@ -397,7 +422,8 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
                                                               int S, int K, float r2,
                                                               int32_t *__restrict__ idx_all,
                                                               const int32_t *__restrict__ reuse_idx,
-                                                              const int32_t *__restrict__ center_src) {
+                                                              const int32_t *__restrict__ center_src, int nth_rows) {
+    extern __shared__ VI s_nth[];  // nth_rows != 0: N entries per wave for the nth_element replay of tied rows
     __shared__ float s_d[WPB][CPW][CAP];
     __shared__ int s_i[WPB][CPW][CAP];
     __shared__ float s_td[WPB][TMPN];
@@ -437,7 +463,8 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
     for (int j = 0; j < CPW; ++j) {
         if (s0 + j >= S) break;
         finish(c[j], pts, len, N, K, r2, (LdsF)s_d[w][j], (LdsI)s_i[w][j], (LdsF)s_td[w], (LdsI)s_ti[w],
-               idx_all + ((size_t)b * S + (s0 + j)) * K);
+               idx_all + ((size_t)b * S + (s0 + j)) * K, nullptr, nullptr, 0,
+               nth_rows ? s_nth + (size_t)w * N : nullptr);
     }
 }
 
@@ -672,6 +699,28 @@ __device__ __forceinline__ void heap_replace_top(float &hv, int &hi, int len, fl
     const int k = __popcll(__ballot(on && j != 0 && hv >= val));
     if (on && depth < k) hv = cv, hi = ci;
     if (on && depth == k) hv = val, hi = vi;
+}
+
+// Queued boundary-tie rows of the grid search in torch.topk's nth_element regime: one wave per row.
+__global__ __launch_bounds__(64) void knn_tie_nth_kernel(const float *__restrict__ points_all,
+                                                         const int32_t *__restrict__ lengths,
+                                                         const float *__restrict__ centers_all, int N, int S, int K,
+                                                         float r2, const int *__restrict__ tie_count,
+                                                         const int32_t *__restrict__ tie_rows,
+                                                         int32_t *__restrict__ idx_all) {
+    extern __shared__ VI s_row[];
+    __shared__ float s_hv[KMAX];
+    __shared__ int s_hi[KMAX];
+    const int n_rows = min(*tie_count, TIE_CAP);
+    for (int r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const int row = tie_rows[r], b = row / S;
+        const float *pts = points_all + (size_t)b * N * 3;
+        const int len = min(max(lengths[b], 0), N);
+        const float *cp = centers_all + (size_t)row * 3;
+        nth_select_exact(pts, len, N, K, cp[0], cp[1], cp[2], sq3(cp[0], cp[1], cp[2]), s_row, (LdsF)s_hv, (LdsI)s_hi);
+        emit_heap_result((LdsF)s_hv, (LdsI)s_hi, K, r2, idx_all + (size_t)row * K);
+        wave_mem_sync();
+    }
 }
 
 __global__ __launch_bounds__(TIE_T) void knn_tie_kernel(const float *__restrict__ points_all,
@@ -1079,9 +1128,12 @@ int launch_grid_search(const float *points, const int32_t *lengths, const float 
                        hipStream_t st) {
     hipLaunchKernelGGL(knn_grid_kernel, dim3(dpm_cdiv(S, WPB), B), dim3(WPB * 64), 0, st, points, lengths, centers, N,
                        S, K, r2, w.hdr, w.start, w.sorted, idx, reuse_idx, center_src, w.tie_count, w.tie_rows);
-    if ((long long)K * 64 <= (long long)N)  // the only regime with an order-dependent tie rule
+    if ((long long)K * 64 <= (long long)N)  // torch.topk's partial_sort regime: heap-select replay of the queued rows
         hipLaunchKernelGGL(knn_tie_kernel, dim3(2048), dim3(TIE_T), 0, st, points, lengths, centers, N, S, K, r2,
                            w.tie_count, w.tie_rows, idx);
+    else  // nth_element regime (N < 64 K <= 2048)
+        hipLaunchKernelGGL(knn_tie_nth_kernel, dim3(1024), dim3(64), sizeof(VI) * (size_t)N, st, points, lengths, centers, N,
+                           S, K, r2, w.tie_count, w.tie_rows, idx);
     return dpm_launch_status();
 }
 }  // namespace
@@ -1100,8 +1152,10 @@ extern "C" int dpm_knn_hybrid_reuse(const float *points, const int32_t *lengths,
         launch_grid_build(points, lengths, B, N, radius, w, st);
         return launch_grid_search(points, lengths, centers, B, N, S, K, r2, idx, w, reuse_idx, center_src, st);
     }
-    hipLaunchKernelGGL(knn_hybrid_kernel, dim3(dpm_cdiv(S, WPB * CPW), B), dim3(WPB * 64), 0, st, points, lengths, centers,
-                       N, S, K, r2, idx, reuse_idx, center_src);
+    const int nth_rows = (long long)K * 64 > (long long)N;  // torch.topk's nth_element regime: tied rows are replayed
+    hipLaunchKernelGGL(knn_hybrid_kernel, dim3(dpm_cdiv(S, WPB * CPW), B), dim3(WPB * 64),
+                       nth_rows ? sizeof(VI) * (size_t)WPB * N : 0, st, points, lengths, centers, N, S, K, r2, idx, reuse_idx,
+                       center_src, nth_rows);
     return dpm_launch_status();
 }
 

@@ -1,0 +1,97 @@
+"""Seeded INPUTS of the round-2 fixtures (large_reg.npz, knn_ties.npz, converged.npz): built from committed data and
+torch CPU generators, so the fixtures store only what the reference answered.  Imported by
+tests/golden/make_golden_r2.py (which runs the reference on them) and by the tests (which run the oracle and the HIP
+path on them).  No reference code here."""
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# ---- key-frame pool for the map-sized registrations -------------------------------------------------------------
+TILE_A, TILE_B, SCAN = 8, 25, 20          # centre tokens of the two 16-scan tiles; the scan registered against tile A
+LOOP_SRC, LOOP_DST = list(range(0, 32, 2)), 33  # 16 loop-closure candidates against one new scan
+N_POOL = 34
+
+
+def keyframe_pool():
+    """34 key-frame descriptors (131, 256) + poses: the 15 descriptors the reference's encoder produced in
+    slam_trace.npz, re-used with seeded perturbations (non-negative feature noise, 0.3 m coordinate noise), on a
+    gently curving path with 1.5 m between key-frames."""
+    with np.load(os.path.join(HERE, "slam_trace.npz")) as z:
+        base = torch.from_numpy(z["desc"].copy())
+    g = torch.Generator().manual_seed(77)
+    kps, poses = [], []
+    for i in range(N_POOL):
+        b = base[i % base.shape[0]]
+        noise = torch.cat([0.02 * torch.rand(128, 256, generator=g), 0.3 * torch.randn(3, 256, generator=g)])
+        kps.append((b + noise).contiguous() if i >= base.shape[0] else b.clone())
+        a = 0.04 * i
+        SE3 = torch.eye(4)
+        SE3[:3, :3] = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float32)
+        SE3[:3, 3] = torch.tensor([1.5 * i, 0.3 * np.sin(0.5 * i), 0.02 * i])
+        poses.append(SE3)
+    return kps, poses
+
+
+# ---- lattices for the tie rule of torch.topk's std::nth_element branch --------------------------------------------
+def knn_tie_cases():
+    """name -> (points (N,3), centres (S,3), radius, K).  Lattice spacing 0.25: the expanded-form distances
+    -2ab + |a|^2 + |b|^2 of a lattice are exact in fp32, so every row holds groups of EXACTLY equal distances, also
+    across the K-th place; k * 64 > n in every case (nth_element, not partial_sort)."""
+    g = torch.Generator().manual_seed(5)
+
+    def lattice(nx, ny, nz):
+        p = torch.stack(torch.meshgrid(torch.arange(nx * 1.0), torch.arange(ny * 1.0), torch.arange(nz * 1.0), indexing="ij"), -1)
+        p = p.reshape(-1, 3) * 0.25
+        return p[torch.randperm(p.shape[0], generator=g)].contiguous()
+
+    p16, p64, p256, p1024 = lattice(4, 2, 2), lattice(4, 4, 4), lattice(8, 8, 4), lattice(16, 16, 4)
+    return {
+        "n16_k16_r1.6": (p16, p16.clone(), 1.6, 16),
+        "n64_k16_r0.8": (p64, p64[:16].contiguous(), 0.8, 16),
+        "n64_k32_r0.8": (p64, p64.clone(), 0.8, 32),
+        "n64_k32_r0.4": (p64, p64.clone(), 0.4, 32),     # the radius cut removes part of every row
+        "n256_k32_r0.4": (p256, p256.clone(), 0.4, 32),
+        "n256_k32_r0.8": (p256, p256[::4].contiguous(), 0.8, 32),
+        "n1024_k32_r0.6": (p1024, p1024[::4].contiguous(), 0.6, 32),  # the grid search's nth_element regime (1024 <= N < 2048)
+    }
+
+
+# ---- a registration that converges ----------------------------------------------------------------------------------
+CONVERGED_TAU = 0.02
+
+
+def converged_state_dict(sd):
+    """procedural decoder weights, edited so that descriptor identity dominates the match: input projection x100,
+    the attention blocks' output projections and MLP exits x0.01 (the residual stream keeps the projected descriptor),
+    offset head output zero (correspondences are the matched key-points themselves).  With tau = CONVERGED_TAU."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["projection.weight"] *= 100.0
+    for k in sd:
+        if k.startswith("descriptor_attention") and (k.endswith("out_proj.weight") or k.endswith("mlp.2.weight")):
+            sd[k] *= 0.01
+    sd["offset_head.head.weight"].zero_()
+    sd["offset_head.head.bias"].zero_()
+    return sd
+
+
+def converged_cases():
+    """name -> (src (131,256), dst (131,256), R_gt, t_gt): zero-mean random descriptors at random key-points, the
+    target = the source moved by a small rigid motion, permuted, with 2 cm coordinate noise (and feature noise in the
+    second case, so that confident and unconfident pairs mix)."""
+    out = {}
+    for name, seed, noise in (("clean", 0, 0.0), ("noisy", 1, 0.6)):
+        g = torch.Generator().manual_seed(seed)
+        fea = torch.randn(128, 256, generator=g)
+        xyz = torch.cat([(torch.rand(2, 256, generator=g) * 2 - 1) * 40, torch.randn(1, 256, generator=g)], 0)
+        a = 0.05
+        R = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float32)
+        t = torch.tensor([[0.8], [-0.3], [0.05]])
+        perm = torch.randperm(256, generator=g)
+        src = torch.cat([fea, xyz], 0)
+        dst = torch.cat([fea + noise * torch.randn(128, 256, generator=g),
+                         R @ xyz + t + 0.02 * torch.randn(3, 256, generator=g)], 0)[:, perm].contiguous()
+        out[name] = (src, dst, R, t)
+    return out
