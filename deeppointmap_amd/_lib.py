@@ -23,6 +23,9 @@ SIGNATURES = {
     "dpm_error_string": (c_char_p, [I]),
     "dpm_prepare_points": (I, [P, P, I, I, I, P, P, P]),
     "dpm_to_channel_first": (I, [P, I, I, I, P, P]),
+    "dpm_emit_descriptors": (I, [P, P, P, I, I, I, D, P, P, P, P, P]),
+    "dpm_nested_levels": (I, [P, P, I, I, I, P, P, P, P, P]),
+    "dpm_gather_frames": (I, [P, LL, I, I, I, P, I, P, P]),
     "dpm_fps_workspace_bytes": (c_size_t, [I, I, I]),
     "dpm_fps": (I, [P, P, I, I, I, P, P, P, P, P]),
     "dpm_fps_ex": (I, [P, P, I, I, I, P, P, P, P, I, P]),

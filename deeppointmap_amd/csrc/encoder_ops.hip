@@ -320,6 +320,120 @@ extern "C" int dpm_prepare_points(const float *points_cf, const uint8_t *padding
     return dpm_launch_status();
 }
 
+namespace {
+// ------------------------------------------------------------------------------------------
+// Bookkeeping that used to be a string of tiny tensor ops per step.
+// ------------------------------------------------------------------------------------------
+constexpr int MAX_NESTED = 8;
+struct NestedLevels {
+    int n;
+    int npoint[MAX_NESTED];    // K of level i (descending)
+    long long off[MAX_NESTED]; // element offset of level i in the packed outputs (per batch: sum over earlier levels of B * K)
+};
+
+// Levels below the first are prefixes of the first level's pick sequence (Encoder.nested_fps): per level the first K
+// picked coordinates, idx = position (or -1 past the frame's valid count) and the clamped length.
+__global__ __launch_bounds__(256) void nested_levels_kernel(const float *__restrict__ xyz0, const int32_t *__restrict__ len0,
+                                                            int B, int K0, NestedLevels lv, float *__restrict__ xyz_out,
+                                                            int32_t *__restrict__ idx_out, int32_t *__restrict__ len_out) {
+    const int b = blockIdx.y, lvl = blockIdx.z, K = lv.npoint[lvl];
+    const int l0 = len0[b];
+    const int len = min(l0, K);
+    float *xo = xyz_out + 3 * (lv.off[lvl] + (long long)b * K);
+    int32_t *io = idx_out + lv.off[lvl] + (long long)b * K;
+    const float *xi = xyz0 + (size_t)b * K0 * 3;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < K; j += gridDim.x * 256) {
+        xo[3 * j] = xi[3 * j], xo[3 * j + 1] = xi[3 * j + 1], xo[3 * j + 2] = xi[3 * j + 2];
+        io[j] = j < len ? j : -1;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) len_out[lvl * B + b] = len;
+}
+
+// The encoder's return values in one pass: coor (B,3,S), feat (B,C,S), padding (B,S) and, when asked for, the unified
+// descriptor (B,C+3,S) = [feat ; coor * scale] of ExtractionThread.process (odometry.py:47-49).
+__global__ __launch_bounds__(256) void emit_descriptors_kernel(const float *__restrict__ xyz, const float *__restrict__ fea,
+                                                               const int32_t *__restrict__ lengths, int S, int C, float scale,
+                                                               float *__restrict__ coor, float *__restrict__ feat,
+                                                               uint8_t *__restrict__ padding, float *__restrict__ desc) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int CT = C + 3;  // channels of the virtual row [fea ; xyz]
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        if (r < S && c < CT) tile[k][tx] = c < C ? fea[((size_t)b * S + r) * C + c] : xyz[((size_t)b * S + r) * 3 + (c - C)];
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < CT && r < S) {
+            const float v = tile[tx][k];
+            if (c < C) feat[((size_t)b * C + c) * S + r] = v;
+            else coor[((size_t)b * 3 + (c - C)) * S + r] = v;
+            if (desc) desc[((size_t)b * CT + c) * S + r] = c < C ? v : v * scale;
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < 32; k += 256)
+            if (r0 + k < S) padding[(size_t)b * S + r0 + k] = (r0 + k) >= lengths[b];
+}
+
+// out[p, m, c] = src[index[p] * frame_stride + m * ld + c]: rows of selected frames, contiguous
+__global__ __launch_bounds__(256) void gather_frames_kernel(const float *__restrict__ src, long long frame_stride, int rows,
+                                                            int ld, int cols, const int32_t *__restrict__ index,
+                                                            float *__restrict__ out) {
+    const int p = blockIdx.y;
+    const float *s = src + (size_t)index[p] * frame_stride;
+    float *o = out + (size_t)p * rows * cols;
+    const long long n = (long long)rows * cols;
+    if (ld == cols && (cols & 3) == 0 && (((uintptr_t)s | (uintptr_t)o) & 15) == 0) {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (long long)gridDim.x * 256)
+            ((float4 *)o)[i] = ((const float4 *)s)[i];
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            const int m = (int)(i / cols), c = (int)(i % cols);
+            o[i] = s[(size_t)m * ld + c];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int dpm_nested_levels(const float *xyz0, const int32_t *len0, int B, int K0, int n_levels, const int32_t *npoint,
+                                 float *xyz_out, int32_t *idx_out, int32_t *len_out, dpm_stream_t stream) {
+    DPM_CHECK_ARG(xyz0 && len0 && npoint && xyz_out && idx_out && len_out && B >= 1 && K0 >= 1);
+    DPM_CHECK_ARG(n_levels >= 1 && n_levels <= MAX_NESTED);
+    NestedLevels lv;
+    lv.n = n_levels;
+    long long off = 0;
+    int kmax = 1;
+    for (int i = 0; i < n_levels; ++i) {
+        DPM_CHECK_ARG(npoint[i] >= 1 && npoint[i] <= K0);
+        lv.npoint[i] = npoint[i], lv.off[i] = off;
+        off += (long long)B * npoint[i];
+        kmax = npoint[i] > kmax ? npoint[i] : kmax;
+    }
+    hipLaunchKernelGGL(nested_levels_kernel, dim3(dpm_cdiv(kmax, 256), B, n_levels), dim3(256), 0, (hipStream_t)stream, xyz0,
+                       len0, B, K0, lv, xyz_out, idx_out, len_out);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_emit_descriptors(const float *xyz, const float *fea, const int32_t *lengths, int B, int S, int C,
+                                    double coor_scale, float *coor, float *feat, uint8_t *padding, float *desc,
+                                    dpm_stream_t stream) {
+    DPM_CHECK_ARG(xyz && fea && lengths && coor && feat && padding && B >= 1 && S >= 1 && C >= 1);
+    hipLaunchKernelGGL(emit_descriptors_kernel, dim3(dpm_cdiv(C + 3, 32), dpm_cdiv(S, 32), B), dim3(256), 0,
+                       (hipStream_t)stream, xyz, fea, lengths, S, C, (float)coor_scale, coor, feat, padding, desc);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_gather_frames(const float *src, long long frame_stride, int rows, int ld, int cols, const int32_t *index,
+                                 int n, float *out, dpm_stream_t stream) {
+    DPM_CHECK_ARG(src && index && out && rows >= 1 && cols >= 1 && ld >= cols && n >= 1);
+    const long long per = (long long)rows * cols;
+    hipLaunchKernelGGL(gather_frames_kernel, dim3((unsigned)((per / 4 + 255) / 256 < 64 ? ((per / 4 + 255) / 256 ? (per / 4 + 255) / 256 : 1) : 64), n),
+                       dim3(256), 0, (hipStream_t)stream, src, frame_stride, rows, ld, cols, index, out);
+    return dpm_launch_status();
+}
+
 extern "C" int dpm_to_channel_first(const float *x, int B, int R, int C, float *out, dpm_stream_t stream) {
     DPM_CHECK_ARG(x && out && B >= 1 && R >= 1 && C >= 1);
     hipLaunchKernelGGL(to_channel_first_kernel, dim3(dpm_cdiv(C, 32), dpm_cdiv(R, 32), B), dim3(256), 0,

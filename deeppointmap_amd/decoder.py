@@ -135,9 +135,9 @@ class Decoder(ParamTree):
             zu = ops.linear(tu[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=pos_u)
             pre = "descriptor_attention.0"
             z1u = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", zu, U, M), post=pos_u)
-            order = torch.cat([sidx, didx]).long()
-            pos = pos_u.view(U, M * E).index_select(0, order).view(2 * R, E)
-            z1_first = z1u.view(U, M * E).index_select(0, order).view(2 * R, E)
+            order = sidx if didx is None else torch.cat([sidx, didx])  # (2B,) int32: sources then targets
+            pos = ops.gather_frames(pos_u, order, M, E).view(2 * R, E)
+            z1_first = ops.gather_frames(z1u, order, M, E).view(2 * R, E)
             zp = None
         else:
             z_in = torch.cat([ts, td], dim=0)                       # (2R, 131): [src tokens ; dst tokens]
@@ -184,13 +184,14 @@ class Decoder(ParamTree):
         Pairs are independent, so every kernel runs all B of them at once."""
         if pairs is not None:   # src_descriptor holds the U distinct frames, pairs = (sidx, didx) int32 on the device
             dev = self.device
-            sidx, didx = pairs
+            sidx, didx = pairs[0], pairs[1]
+            # pairs may carry the concatenated index list (sources then targets) so that it is built once per pair list
+            order = pairs[2] if len(pairs) > 2 else torch.cat([sidx, didx])
             tu, U, M = self._stage(src_descriptor, dev)
             N, B, C = M, sidx.numel(), self.in_channel
-            x, y = self._attention_layers_joint(None, None, B, M, frames=(tu, sidx, didx))
-            xyz_u = tu.view(U, M, C + 3)[:, :, C:C + 3]
-            xyz_s = xyz_u.index_select(0, sidx.long()).reshape(B * M, 3)
-            xyz_d = xyz_u.index_select(0, didx.long()).reshape(B * M, 3)
+            x, y = self._attention_layers_joint(None, None, B, M, frames=(tu, order, None))
+            xyz_sd = ops.gather_frames(tu, order, M, 3, ld=C + 3, offset=C).view(2 * B * M, 3)
+            xyz_s, xyz_d = xyz_sd[:B * M], xyz_sd[B * M:]
         else:
             x, xyz_s, y, xyz_d, B, M, N = self._descriptor_attention_forward(src_descriptor, dst_descriptor)
         E = self.model_channel
@@ -234,7 +235,8 @@ class Decoder(ParamTree):
 
     @torch.no_grad()
     def registration_forward_pairs(self, descriptors: torch.Tensor, src_frame: torch.Tensor, dst_frame: torch.Tensor,
-                                   num_sample: Union[int, float] = 0.5, header_out: torch.Tensor = None) -> torch.Tensor:
+                                   num_sample: Union[int, float] = 0.5, header_out: torch.Tensor = None,
+                                   order: torch.Tensor = None) -> torch.Tensor:
         """Like registration_forward_batch for pairs drawn from ONE set of frames: descriptors (F,131,M), pair p =
         (src_frame[p], dst_frame[p]) (int32 device tensors).  The per-frame part of the decoder (projection, position
         embedding, first self-attention block) runs once per frame instead of once per pair side; results are
@@ -243,7 +245,8 @@ class Decoder(ParamTree):
         if dev.type != "cuda":
             raise RuntimeError("deeppointmap_amd.Decoder runs on the GPU only (there is no CPU fallback)")
         with torch.cuda.device(dev):
-            return self._register(descriptors, None, num_sample, header_out, pairs=(src_frame, dst_frame))
+            pairs = (src_frame, dst_frame) if order is None else (src_frame, dst_frame, order)
+            return self._register(descriptors, None, num_sample, header_out, pairs=pairs)
 
     @torch.no_grad()
     def registration_forward(self, src_descriptor: torch.Tensor, dst_descriptor: torch.Tensor,

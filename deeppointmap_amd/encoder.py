@@ -96,19 +96,19 @@ class Encoder(ParamTree):
             pad = points_padding.to(device=dev).contiguous()
             xyz, lengths = ops.prepare_points(pts, pad)
             out = dict(pts=pts, xyz=xyz, lengths=lengths)
-            cur, cur_len = xyz, lengths
             n_levels = len(self.encoder_cfg.npoint) if levels is None else levels
-            for i, npoint in enumerate(self.encoder_cfg.npoint[:n_levels]):
-                if i == 0 and sampled0 is not None:  # first level sampled by the caller (several batches in one launch)
-                    fidx, cur, cur_len = sampled0
-                elif i == 0 or not self.nested_fps:
-                    fidx, cur, cur_len = ops.fps(cur, cur_len, npoint)
-                else:  # prefix of the previous level (index bookkeeping only; rows past a short frame are zero already)
-                    cur_len = torch.clamp(cur_len, max=npoint)
-                    ar = torch.arange(npoint, device=dev, dtype=torch.int32).unsqueeze(0)
-                    fidx = torch.where(ar < cur_len.unsqueeze(1), ar, torch.full_like(ar, -1))
-                    cur = cur[:, :npoint].contiguous()
-                out[f"fidx{i}"], out[f"xyz{i}"], out[f"len{i}"] = fidx, cur, cur_len
+            npoint = list(self.encoder_cfg.npoint[:n_levels])
+            if n_levels >= 1 and (self.nested_fps or n_levels == 1):
+                first = sampled0 if sampled0 is not None else ops.fps(xyz, lengths, npoint[0])
+                # every lower level is a prefix of the first level's picks: one bookkeeping launch for all of them
+                lower = ops.nested_levels(first[1], first[2], npoint[1:]) if n_levels > 1 else []
+                for i, (fidx, cur, cur_len) in enumerate([first] + lower):
+                    out[f"fidx{i}"], out[f"xyz{i}"], out[f"len{i}"] = fidx, cur, cur_len
+            else:
+                cur, cur_len = xyz, lengths
+                for i, k in enumerate(npoint):
+                    fidx, cur, cur_len = sampled0 if (i == 0 and sampled0 is not None) else ops.fps(cur, cur_len, k)
+                    out[f"fidx{i}"], out[f"xyz{i}"], out[f"len{i}"] = fidx, cur, cur_len
             # The search grids of the neighbour queries depend on coordinates and radii only: they are sorted here,
             # next to the sampling, and forward() runs just the searches.  Same bookkeeping as forward(): a
             # SetAbstraction whose (radius, K) the previous level's LocalAggregation already answered needs none.
@@ -151,7 +151,10 @@ class Encoder(ParamTree):
 
     @torch.no_grad()
     def forward(self, points: torch.Tensor, points_padding: torch.Tensor, trace: Optional[dict] = None,
-                presampled: Optional[dict] = None) -> List[torch.Tensor]:
+                presampled: Optional[dict] = None, descriptor_scale: float = 0.0) -> List[torch.Tensor]:
+        """-> [coor (B,3,S), fea (B,out_channel,S), padding (B,S)] (encoder.py:51-69).  descriptor_scale > 0 (not in the
+        reference signature; used by the batched hot path): return instead the unified descriptor (B,out_channel+3,S) =
+        [fea ; coor * descriptor_scale] that ExtractionThread.process builds from the triple (odometry.py:47-49)."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("deeppointmap_amd.Encoder runs on the GPU only: call .to('cuda') first "
@@ -228,8 +231,7 @@ class Encoder(ParamTree):
                     trace[q + ".out"] = x
                 levels.append((xyz1, x, len1))
             xyz, fea, lengths = levels[-1]
-            S = xyz.shape[1]
-            coor = ops.to_channel_first(xyz)
-            feat = ops.to_channel_first(fea)
-            padding = torch.arange(S, device=dev).unsqueeze(0) >= lengths.unsqueeze(1)
+            coor, feat, padding, desc = ops.emit_descriptors(xyz, fea, lengths, descriptor_scale)
+            if descriptor_scale > 0:
+                return desc
         return [coor, feat, padding]

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import ctypes
 import os
 import weakref
 
@@ -39,7 +40,7 @@ def _chk(t: torch.Tensor, dtype, name: str):
 def prepare_points(points_cf: torch.Tensor, padding: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """(B,C,N) f32 + (B,N) bool -> xyz (B,N,3), lengths (B,) int32."""
     _chk(points_cf, torch.float32, "points")
-    pad = _chk(padding.to(torch.uint8) if padding.dtype == torch.bool else padding, torch.uint8, "padding")
+    pad = _chk(padding.view(torch.uint8) if padding.dtype == torch.bool else padding, torch.uint8, "padding")  # same bytes
     B, C, N = points_cf.shape
     xyz = torch.empty(B, N, 3, device=points_cf.device, dtype=torch.float32)
     lengths = torch.empty(B, device=points_cf.device, dtype=torch.int32)
@@ -47,6 +48,57 @@ def prepare_points(points_cf: torch.Tensor, padding: torch.Tensor) -> Tuple[torc
     _lib.check(lib.dpm_prepare_points(_ptr(points_cf), _ptr(pad), B, C, N, _ptr(xyz), _ptr(lengths),
                                       _stream(xyz)), "dpm_prepare_points")
     return xyz, lengths
+
+
+def emit_descriptors(xyz: torch.Tensor, fea: torch.Tensor, lengths: torch.Tensor, coor_scale: float = 0.0):
+    """Point-major last level -> the encoder's return triple (coor (B,3,S), feat (B,C,S), padding (B,S) bool) and, with
+    coor_scale > 0, the unified descriptor (B,C+3,S) = [feat ; coor * coor_scale] (odometry.py:47-49); one launch."""
+    _chk(xyz, torch.float32, "xyz"), _chk(fea, torch.float32, "fea"), _chk(lengths, torch.int32, "lengths")
+    B, S, C = fea.shape
+    dev = xyz.device
+    coor = torch.empty(B, 3, S, device=dev, dtype=torch.float32)
+    feat = torch.empty(B, C, S, device=dev, dtype=torch.float32)
+    padding = torch.empty(B, S, device=dev, dtype=torch.bool)
+    desc = torch.empty(B, C + 3, S, device=dev, dtype=torch.float32) if coor_scale > 0 else None
+    _lib.check(_lib.load().dpm_emit_descriptors(_ptr(xyz), _ptr(fea), _ptr(lengths), B, S, C, float(coor_scale), _ptr(coor),
+                                                _ptr(feat), _ptr(padding), _ptr(desc), _stream(xyz)), "dpm_emit_descriptors")
+    return coor, feat, padding, desc
+
+
+def nested_levels(xyz0: torch.Tensor, len0: torch.Tensor, npoints):
+    """Levels below the first as prefixes of its picks: -> [(idx (B,K) int32, xyz (B,K,3), lengths (B,)) per K in npoints],
+    views of three packed buffers written by one launch."""
+    _chk(xyz0, torch.float32, "xyz0"), _chk(len0, torch.int32, "len0")
+    B, K0, _ = xyz0.shape
+    npoints = [int(k) for k in npoints]
+    tot = B * sum(npoints)
+    dev = xyz0.device
+    xyz = torch.empty(tot, 3, device=dev, dtype=torch.float32)
+    idx = torch.empty(tot, device=dev, dtype=torch.int32)
+    lens = torch.empty(len(npoints), B, device=dev, dtype=torch.int32)
+    arr = (ctypes.c_int32 * len(npoints))(*npoints)
+    _lib.check(_lib.load().dpm_nested_levels(_ptr(xyz0), _ptr(len0), B, K0, len(npoints), ctypes.cast(arr, ctypes.c_void_p),
+                                             _ptr(xyz), _ptr(idx), _ptr(lens), _stream(xyz0)), "dpm_nested_levels")
+    out, off = [], 0
+    for i, K in enumerate(npoints):
+        out.append((idx[off:off + B * K].view(B, K), xyz[off:off + B * K].view(B, K, 3), lens[i]))
+        off += B * K
+    return out
+
+
+def gather_frames(src: torch.Tensor, index: torch.Tensor, rows: int, cols: int, ld: int = None, frame_stride: int = None,
+                  offset: int = 0) -> torch.Tensor:
+    """out (n, rows, cols) = rows [0, rows) x columns [offset, offset + cols) of the frames index[p] of `src`
+    (frames `frame_stride` floats apart, rows `ld` floats apart; defaults: packed)."""
+    _chk(src, torch.float32, "src"), _chk(index, torch.int32, "index")
+    ld = cols if ld is None else ld
+    frame_stride = rows * ld if frame_stride is None else frame_stride
+    n = index.numel()
+    out = torch.empty(n, rows, cols, device=src.device, dtype=torch.float32)
+    base = src.data_ptr() + 4 * offset
+    _lib.check(_lib.load().dpm_gather_frames(ctypes.c_void_p(base), frame_stride, rows, ld, cols, _ptr(index), n, _ptr(out),
+                                             _stream(src)), "dpm_gather_frames")
+    return out
 
 
 def to_channel_first(x: torch.Tensor) -> torch.Tensor:

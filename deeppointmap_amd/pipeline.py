@@ -57,8 +57,7 @@ class HotPath:
     @torch.no_grad()
     def extract(self, points: torch.Tensor, padding: torch.Tensor, presampled=None) -> torch.Tensor:
         """(F,3,N) normalised scans -> unified descriptors (F,131,256): rows 0-127 feature, 128-130 xyz in metres."""
-        coor, fea, _ = self.encoder(points, padding, presampled=presampled)
-        return make_descriptors(coor, fea, self.coor_scale)
+        return self.encoder(points, padding, presampled=presampled, descriptor_scale=self.coor_scale)
 
     @torch.no_grad()
     def register(self, desc: torch.Tensor, pcd_m: Optional[torch.Tensor], pairs, table: Optional[torch.Tensor] = None,
@@ -73,13 +72,16 @@ class HotPath:
         pairs = list(pairs)
         dev = desc.device
         if table is None:
-            table = torch.zeros(len(pairs), EDGE_FLOATS, device=dev, dtype=torch.float32)
+            table = torch.empty(len(pairs), EDGE_FLOATS, device=dev, dtype=torch.float32)  # every field is written below
         if pair_index is None:
             pair_index = (torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev),
                           torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev))
-        sidx, didx = pair_index
+        sidx, didx = pair_index[0], pair_index[1]
+        if pcd_m is None:
+            table[:, ops.RES_HDR:].zero_()
         res = self.decoder.registration_forward_pairs(desc, sidx, didx, num_sample=self.num_sample,
-                                                      header_out=table[:, :ops.RES_HDR])
+                                                      header_out=table[:, :ops.RES_HDR],
+                                                      order=pair_index[2] if len(pair_index) > 2 else None)
         if pcd_m is not None:
             ops.information_matrix_batched(pcd_m, sidx, didx, table[:, :12], table[:, ops.RES_HDR:], grids=grids)
         edges = []
@@ -98,8 +100,9 @@ class HotPath:
         key = (F, str(dev))
         if key not in self._rings:
             pairs = [((f - 1) % F, f) for f in range(F)]
-            self._rings[key] = (pairs, (torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev),
-                                        torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev)))
+            si = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev)
+            di = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev)
+            self._rings[key] = (pairs, (si, di, torch.cat([si, di])))  # + sources-then-targets, for the decoder's gathers
         return self._rings[key]
 
     @torch.no_grad()

@@ -50,6 +50,23 @@ int dpm_prepare_points(const float *points_cf, const uint8_t *padding, int B, in
 /* (B,R,C) point-major -> (B,C,R) channel-first (the layout Encoder.forward returns). */
 int dpm_to_channel_first(const float *x, int B, int R, int C, float *out, dpm_stream_t stream);
 
+/* The encoder's return triple [coor (B,3,S), feat (B,C,S), padding (B,S; 1 = padded)] (network/encoder/encoder.py:51-69)
+ * from the point-major level (xyz (B,S,3), fea (B,S,C), lengths), and -- desc != NULL -- the unified descriptor
+ * (B,C+3,S) = [feat ; coor * coor_scale] of ExtractionThread.process (system/modules/odometry.py:47-49), in one pass. */
+int dpm_emit_descriptors(const float *xyz, const float *fea, const int32_t *lengths, int B, int S, int C,
+                         double coor_scale, float *coor, float *feat, uint8_t *padding, float *desc, dpm_stream_t stream);
+
+/* Lower sampling levels as prefixes of the first level's picks (the four lower Sampler.fps calls of
+ * network/encoder/pointnext.py:38-47 when npoint is descending): for level i with K = npoint[i] (host array),
+ * xyz_out / idx_out hold the levels back to back ((B,K,3) / (B,K) each), len_out is (n_levels,B). */
+int dpm_nested_levels(const float *xyz0, const int32_t *len0, int B, int K0, int n_levels, const int32_t *npoint,
+                      float *xyz_out, int32_t *idx_out, int32_t *len_out, dpm_stream_t stream);
+
+/* out[p, m, c] = src[index[p] * frame_stride + m * ld + c], p < n, m < rows, c < cols: per-pair copies of per-frame
+ * rows (what torch.index_select did for the pair lists of odometry.py:103-127). */
+int dpm_gather_frames(const float *src, long long frame_stride, int rows, int ld, int cols, const int32_t *index, int n,
+                      float *out, dpm_stream_t stream);
+
 /* Sampler.fps / Sampler.fps_t3d == pytorch3d.ops.sample_farthest_points
  * (network/encoder/utils.py:210-285): start index 0, dist = (dx*dx+dy*dy)+dz*dz evaluated in
  * fp32 without contraction, next pick = first argmax.  idx (B,K) is -1 where lengths[b] < K;
