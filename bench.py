@@ -87,7 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--points", type=int, default=65536)
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the cpu_baseline sample (0 = skip; default: the whole batch)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements (PCIe-inclusive rate, latency mode, rank-0 consumer)")
     ap.add_argument("--no-pipeline", action="store_true", help="run every step start-to-finish on one stream")
     ap.add_argument("--geometry-depth", type=int, default=None, help="geometry passes kept in flight (pipeline tuning)")
     ap.add_argument("--geometry-group", type=int, default=None, help="batches per first-level sampling launch (pipeline tuning)")
@@ -137,6 +138,7 @@ def main():
         hot.encoder.presample_neighbours = bool(args.geometry_knn)
     if args.feature_streams is not None:
         hot.feature_streams = args.feature_streams
+    hot.chain = world > 1  # block-boundary edges come from the neighbour rank's last frame (shard.exchange_halo)
     F, N = args.frames, args.points
     pts, pad = synthetic.frames(F, N, start=rank * F)  # every rank owns its own block of the sequence
     pts, pad = pts.to(dev), pad.to(dev)
@@ -179,21 +181,23 @@ def main():
 
     ops.linear = timed_linear
 
+    last_gathered = [None]
+
     def step():
         # Streaming mode (HotPath.submit): this batch's input staging + first-level FPS start on a side HIP
         # stream and overlap with the previous batch's remaining stages on the main stream.  Edges stay on the
         # device in `table` (header | information per frame); no host sync inside a step.
         if args.no_pipeline:
             desc, edges, table = hot.step(pts, pad, pcd_m, materialize=False)
-            gather_step_results(desc, table)
+            last_gathered[0] = gather_step_results(desc.contiguous(), table)
             return
         done = hot.submit(pts, pad, pcd_m)
         if done is not None:
-            gather_step_results(*done)
+            last_gathered[0] = gather_step_results(done[0].contiguous(), done[1])
 
     def drain():  # the batches still in the pipe are finished INSIDE the timed region
         for done in hot.flush():
-            gather_step_results(*done)
+            last_gathered[0] = gather_step_results(done[0].contiguous(), done[1])
 
     def fence():
         torch.cuda.synchronize()
@@ -231,6 +235,73 @@ def main():
     fps_ms = sum(a.elapsed_time(b) for a, b in fps_events) / max(len(fps_events), 1)
     gemm_ms = sum(a.elapsed_time(b) for a, b in gemm_events) / max(len(gemm_events), 1)
 
+    # ---- extra measurements, outside the timed region and never part of `value` ---------------------------------
+    extras = {}
+    if not args.no_extras:
+        if world == 1 and not args.no_pipeline:
+            # (1) PCIe-inclusive rate: the scans start in pinned host memory and are copied in every step (the metres copy
+            #     for the information matrix is derived on the device, as a caller holding one scan buffer would)
+            pts_h, pad_h = pts.cpu().pin_memory(), pad.cpu().pin_memory()
+            up = torch.cuda.Stream(device=dev)
+
+            def pcie_step():
+                with torch.cuda.stream(up):
+                    p = pts_h.to(dev, non_blocking=True)
+                    q = pad_h.to(dev, non_blocking=True)
+                    m = p * synthetic.COOR_SCALE
+                    ev = up.record_event()
+                torch.cuda.current_stream(dev).wait_event(ev)
+                for g_ in (hot._side["geo"] if hot._side else []):
+                    g_.wait_event(ev)
+                hot.submit(p, q, m)
+            for _ in range(3):
+                pcie_step()
+            hot.flush()
+            fence()
+            t1 = time.perf_counter()
+            n_pcie = 20
+            for _ in range(n_pcie):
+                pcie_step()
+            hot.flush()
+            fence()
+            extras["pcie_inclusive_fps"] = round(F * n_pcie / (time.perf_counter() - t1), 1)
+            # (2) latency mode: one scan at a time, host to pose, as the reference's single-thread SlamSystem.step
+            #     consumes them (system/core.py:360-393)
+            lat_hot = HotPath(hot.encoder, hot.decoder)
+            one_p, one_q = pts_h[:2], pad_h[:2]
+            for _ in range(2):
+                lat_hot.step(one_p.to(dev), one_q.to(dev), (one_p * synthetic.COOR_SCALE).to(dev), materialize=False)
+            fence()
+            t1 = time.perf_counter()
+            n_lat = 8
+            prev = None
+            for i in range(n_lat):
+                p1 = pts_h[i:i + 1].to(dev, non_blocking=True)
+                d1 = lat_hot.extract(p1, pad_h[i:i + 1].to(dev, non_blocking=True))
+                if prev is not None:
+                    both = torch.cat([prev[0], d1]), torch.cat([prev[1], p1 * synthetic.COOR_SCALE])
+                    lat_hot.register(both[0], both[1], [(0, 1)], materialize=True)  # R, T, rmse back on the host
+                prev = (d1, p1 * synthetic.COOR_SCALE)
+            fence()
+            extras["latency_mode_ms_per_frame"] = round((time.perf_counter() - t1) / n_lat * 1e3, 3)
+        if world > 1:
+            # (3) the sequential consumer on rank 0 (key-frame gating, scan-to-map against 16-scan tiles, pose-graph
+            #     optimisation): the Amdahl term of the sharded path, measured on the last gathered step
+            ms = None
+            if rank == 0 and last_gathered[0] is not None and last_gathered[0][0] is not None:
+                from deeppointmap_amd.consumer import Rank0Consumer
+                cons = Rank0Consumer(hot.decoder, dev)
+                gd, gt = last_gathered[0]
+                cons.consume(gd, gt)           # fills the map (first tiles are short)
+                ms = [cons.consume(gd, gt) for _ in range(2)]
+                extras["rank0_serial_ms"] = round(sum(ms) / len(ms), 2)
+                extras["rank0_consumer"] = {"frames_per_step": int(gd.shape[0]), "keyframe_every": cons.keyframe_every,
+                                            "tile_scans": cons.tile_scans, "scan_to_map_registrations": cons.stats["s2m"],
+                                            "pose_graph_optimisations": cons.stats["optimisations"],
+                                            "note": "sequential SLAM work that stays on rank 0 (mapping.py:136-170, "
+                                                    "loop_closure.py:296-310); not part of `value`"}
+            fence()
+
     if args.stages and rank == 0:
         def tm(fn, n=3):
             fn()
@@ -265,15 +336,22 @@ def main():
             "roofline": {"kernel": "fps_bucket_sort_kernel+fps_bucket_kernel (stage-0 farthest point sampling)",
                          "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK / 1e9), 6), "traffic": pmc_traffic_bytes(F),
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "kernel pair at this batch size, committed; not re-measured in this run)",
                          "avg_launch_ms": round(fps_ms, 4), "algorithmic_bytes_per_launch": alg,
                          "whole_path_frac": round(value / world * B_ALG_FRAME / HBM_PEAK, 6),
                          "us_per_round": round(fps_ms * 1e3 / (cfg.encoder.npoint[0] - 1), 3),
-                         "note": "FPS is a chain of 4095 dependent argmax rounds per frame, one CU per frame: latency-"
+                         "note": "avg_launch_ms exceeds ms_per_step because two launches (two batches' geometry stages) are "
+                                 "in flight on alternating streams; "
+                                 "FPS is a chain of 4095 dependent argmax rounds per frame, one CU per frame: latency-"
                                  "bound by construction (us_per_round is the figure that matters); traffic > algorithmic "
                                  "bytes because each round re-reads the ~12 buckets the new point can change -- the "
                                  "reference's loop re-reads the WHOLE frame every round (4095 x 65536 x 16 B = 4.3 GB "
                                  "per frame, 275 GB per launch), the bucket pruning cuts that ~85x; see DESIGN.md"},
         }
+        line.update(extras)
+        if "rank0_serial_ms" in extras:
+            line["value_with_rank0_consumer"] = round(world * F / (dt / args.steps + extras["rank0_serial_ms"] * 1e-3), 1)
         if gemm_ms > 0:
             tf = gemm_flops[0] / (gemm_ms * 1e-3) / 1e12
             line["roofline_mfma"] = {
@@ -289,9 +367,9 @@ def main():
             # 32: 0.75, 64: 1.09 s/frame encode); `cores` reports the threads actually used
             cores = min(os.cpu_count() or 1, 16)
             os.environ["OMP_NUM_THREADS"] = str(cores)
-            v, enc_s, reg_s = cpu_baseline(args.cpu_frames, N, cores)
+            v, enc_s, reg_s = cpu_baseline(min(args.cpu_frames, F), N, cores)
             line["cpu_baseline"] = {"value": round(v, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-                                    "sample": f"{args.cpu_frames} frames x {N} pts: oracle encode {enc_s:.2f} s/frame "
+                                    "sample": f"{min(args.cpu_frames, F)} frames x {N} pts: oracle encode {enc_s:.2f} s/frame "
                                               f"(C farthest-point sampling), register+information matrix {reg_s:.2f} s/frame"}
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -151,7 +151,7 @@ class Encoder(ParamTree):
 
     @torch.no_grad()
     def forward(self, points: torch.Tensor, points_padding: torch.Tensor, trace: Optional[dict] = None,
-                presampled: Optional[dict] = None, descriptor_scale: float = 0.0) -> List[torch.Tensor]:
+                presampled: Optional[dict] = None, descriptor_scale: float = 0.0, spare_frames: int = 0) -> List[torch.Tensor]:
         """-> [coor (B,3,S), fea (B,out_channel,S), padding (B,S)] (encoder.py:51-69).  descriptor_scale > 0 (not in the
         reference signature; used by the batched hot path): return instead the unified descriptor (B,out_channel+3,S) =
         [fea ; coor * descriptor_scale] that ExtractionThread.process builds from the triple (odometry.py:47-49)."""
@@ -231,7 +231,7 @@ class Encoder(ParamTree):
                     trace[q + ".out"] = x
                 levels.append((xyz1, x, len1))
             xyz, fea, lengths = levels[-1]
-            coor, feat, padding, desc = ops.emit_descriptors(xyz, fea, lengths, descriptor_scale)
+            coor, feat, padding, desc = ops.emit_descriptors(xyz, fea, lengths, descriptor_scale, spare_frames)
             if descriptor_scale > 0:
                 return desc
         return [coor, feat, padding]

@@ -50,7 +50,8 @@ def prepare_points(points_cf: torch.Tensor, padding: torch.Tensor) -> Tuple[torc
     return xyz, lengths
 
 
-def emit_descriptors(xyz: torch.Tensor, fea: torch.Tensor, lengths: torch.Tensor, coor_scale: float = 0.0):
+def emit_descriptors(xyz: torch.Tensor, fea: torch.Tensor, lengths: torch.Tensor, coor_scale: float = 0.0,
+                     spare_frames: int = 0):
     """Point-major last level -> the encoder's return triple (coor (B,3,S), feat (B,C,S), padding (B,S) bool) and, with
     coor_scale > 0, the unified descriptor (B,C+3,S) = [feat ; coor * coor_scale] (odometry.py:47-49); one launch."""
     _chk(xyz, torch.float32, "xyz"), _chk(fea, torch.float32, "fea"), _chk(lengths, torch.int32, "lengths")
@@ -59,7 +60,8 @@ def emit_descriptors(xyz: torch.Tensor, fea: torch.Tensor, lengths: torch.Tensor
     coor = torch.empty(B, 3, S, device=dev, dtype=torch.float32)
     feat = torch.empty(B, C, S, device=dev, dtype=torch.float32)
     padding = torch.empty(B, S, device=dev, dtype=torch.bool)
-    desc = torch.empty(B, C + 3, S, device=dev, dtype=torch.float32) if coor_scale > 0 else None
+    # spare_frames: extra descriptor slots behind the B written ones (a neighbour rank's hand-over frame goes there)
+    desc = torch.empty(B + spare_frames, C + 3, S, device=dev, dtype=torch.float32) if coor_scale > 0 else None
     _lib.check(_lib.load().dpm_emit_descriptors(_ptr(xyz), _ptr(fea), _ptr(lengths), B, S, C, float(coor_scale), _ptr(coor),
                                                 _ptr(feat), _ptr(padding), _ptr(desc), _stream(xyz)), "dpm_emit_descriptors")
     return coor, feat, padding, desc

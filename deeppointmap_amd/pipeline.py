@@ -50,25 +50,54 @@ class HotPath:
         self.geometry_depth = 2      # geometry launches in flight ahead of the feature stage (one HIP stream each)
         self.geometry_group = 1      # batches whose first-level sampling shares ONE launch
         self.feature_streams = 1     # >1: consecutive batches' feature stages alternate between side streams
+        # chain = True: frame 0 of a batch is registered against the frame BEFORE the batch (the previous batch's last
+        # frame, or -- several ranks -- the last frame of the rank that owns the preceding block, shard.exchange_halo)
+        # instead of the batch's own last frame (the single-GPU ring, which costs the same and needs no hand-over)
+        self.chain = False
+        self._halo = None      # (descriptor, scan) of the frame before the next batch
         self._side = None      # side HIP streams for the software pipeline (submit / flush)
         self._pending = None
         self._rings = {}
 
     @torch.no_grad()
     def extract(self, points: torch.Tensor, padding: torch.Tensor, presampled=None) -> torch.Tensor:
-        """(F,3,N) normalised scans -> unified descriptors (F,131,256): rows 0-127 feature, 128-130 xyz in metres."""
-        return self.encoder(points, padding, presampled=presampled, descriptor_scale=self.coor_scale)
+        """(F,3,N) normalised scans -> unified descriptors (F,131,256): rows 0-127 feature, 128-130 xyz in metres.
+        In chain mode the tensor has one more slot (index F) holding the predecessor of frame 0."""
+        return self.encoder(points, padding, presampled=presampled, descriptor_scale=self.coor_scale,
+                            spare_frames=1 if self.chain else 0)
+
+    def _hand_over(self, desc: torch.Tensor, pcd_m: Optional[torch.Tensor]):
+        """chain mode, after extract(): fill slot F of `desc` with the frame before this batch and remember this batch's
+        last frame for the next one.  Returns that predecessor's scan (3,N) (None without scans)."""
+        import torch.distributed as dist
+        from .shard import exchange_halo
+        F = desc.shape[0] - 1
+        last = (desc[F - 1], pcd_m[F - 1] if pcd_m is not None else None)
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi:
+            got = exchange_halo(*last)
+            if dist.get_rank() == 0:  # what arrives is the end of the whole window: the predecessor for the NEXT step
+                use, self._halo = (self._halo if self._halo is not None else last), got
+            else:
+                use = got
+        else:
+            use, self._halo = ((self._halo if self._halo is not None else last),
+                               (last[0].clone(), last[1].clone() if last[1] is not None else None))
+        desc[F].copy_(use[0])
+        return use[1]
 
     @torch.no_grad()
     def register(self, desc: torch.Tensor, pcd_m: Optional[torch.Tensor], pairs, table: Optional[torch.Tensor] = None,
-                 materialize: bool = True, pair_index=None, grids: Optional[torch.Tensor] = None):
+                 materialize: bool = True, pair_index=None, grids: Optional[torch.Tensor] = None,
+                 halo_pcd: Optional[torch.Tensor] = None):
         """desc (F,131,S); pcd_m (F,3,N) scans in metres (None: skip the information matrix);
         pairs: list of (src_frame, dst_frame).  All pairs are registered in ONE batched pass.
         Returns (edges, table): table (E, EDGE_FLOATS) is filled on the device by the kernels themselves
         (20-float registration header | 6x6 information) -- it is what a rank ships to rank 0.
         materialize=False skips building Edge objects (no host synchronisation at all).
         pair_index: (src, dst) int32 device tensors of `pairs` when the caller already holds them;
-        grids: ops.information_matrix_grids(pcd_m, dst) built ahead of time (the pose-independent half)."""
+        grids: ops.information_matrix_grids(pcd_m, dst) built ahead of time (the pose-independent half).
+        halo_pcd (chain mode): scan (3,N) of the frame in descriptor slot F, the source of pair 0."""
         pairs = list(pairs)
         dev = desc.device
         if table is None:
@@ -83,7 +112,15 @@ class HotPath:
                                                       header_out=table[:, :ops.RES_HDR],
                                                       order=pair_index[2] if len(pair_index) > 2 else None)
         if pcd_m is not None:
-            ops.information_matrix_batched(pcd_m, sidx, didx, table[:, :12], table[:, ops.RES_HDR:], grids=grids)
+            F = pcd_m.shape[0]
+            if halo_pcd is not None:
+                # the batched search addresses scans of ONE tensor: it runs with the ring's sources (the grids were built
+                # for exactly these targets), and pair 0 -- whose source scan is the hand-over frame -- is redone alone
+                ring = self._ring_pairs(F, dev)[1]
+                ops.information_matrix_batched(pcd_m, ring[0], didx, table[:, :12], table[:, ops.RES_HDR:], grids=grids)
+                table[0, ops.RES_HDR:].copy_(ops.information_matrix(halo_pcd.contiguous(), pcd_m[pairs[0][1]], table[0, :12], 1.0).reshape(-1))
+            else:
+                ops.information_matrix_batched(pcd_m, sidx, didx, table[:, :12], table[:, ops.RES_HDR:], grids=grids)
         edges = []
         if materialize:
             head = table[:, :ops.RES_HDR].cpu()
@@ -94,12 +131,12 @@ class HotPath:
                                   res[e, ops.RES_HDR:ops.RES_HDR + n_in], float(head[e, 12]), info))
         return edges, table
 
-    def _ring_pairs(self, F: int, dev):
-        """Every frame against its predecessor (frame 0 against the last of the batch): the pair list and its
-        device index tensors, built once per batch size."""
-        key = (F, str(dev))
+    def _ring_pairs(self, F: int, dev, chain: bool = False):
+        """Every frame against its predecessor: the pair list and its device index tensors, built once per batch size.
+        Frame 0's predecessor is the last frame of the batch (ring) or, chain=True, slot F of the descriptor tensor."""
+        key = (F, str(dev), chain)
         if key not in self._rings:
-            pairs = [((f - 1) % F, f) for f in range(F)]
+            pairs = [((f - 1) % F if f or not chain else F, f) for f in range(F)]
             si = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev)
             di = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev)
             self._rings[key] = (pairs, (si, di, torch.cat([si, di])))  # + sources-then-targets, for the decoder's gathers
@@ -110,9 +147,11 @@ class HotPath:
         """One batch: every frame is encoded and registered against its predecessor (frame 0 against
         the last frame of the batch, so a batch of F frames carries exactly F edges)."""
         desc = self.extract(points, padding)
-        pairs, index = self._ring_pairs(desc.shape[0], desc.device)
-        edges, table = self.register(desc, pcd_m, pairs, materialize=materialize, pair_index=index)
-        return desc, edges, table
+        F = points.shape[0]
+        halo_pcd = self._hand_over(desc, pcd_m) if self.chain else None
+        pairs, index = self._ring_pairs(F, desc.device, self.chain)
+        edges, table = self.register(desc, pcd_m, pairs, materialize=materialize, pair_index=index, halo_pcd=halo_pcd)
+        return desc[:F], edges, table
 
     # -- streaming mode: software pipeline over consecutive batches ----------------------------------------
     #   stage G (streams A0/A1, alternating): geometry of batch i -- staging + the FPS chain.  It is a latency
@@ -172,8 +211,11 @@ class HotPath:
         dev = self.encoder.device
         main = torch.cuda.current_stream(dev)
         sb = self._side["reg"]
-        pre, ready, points, padding, pcd_m = geo
+        pre, ready, points, padding, pcd_m = geo   # pcd_m: None or (scans, grids, grids_ready)
+        halo_pcd = None
         if self._side["feat"]:
+            if self.chain:
+                raise NotImplementedError("chain mode runs the feature stage on the caller's stream")
             sf = self._side["feat"][self._pending["nf"] % len(self._side["feat"])]
             self._pending["nf"] += 1
             with torch.cuda.stream(sf):
@@ -185,28 +227,33 @@ class HotPath:
         else:
             main.wait_event(ready)
             desc = self.extract(points, padding, presampled=pre)
+            if self.chain:  # the hand-over is a collective: every rank reaches it once per batch, in batch order
+                halo_pcd = self._hand_over(desc, pcd_m[0] if pcd_m is not None else None)
+                if halo_pcd is not None:
+                    halo_pcd.record_stream(sb)
             desc_ready = main.record_event()
         desc.record_stream(sb)
-        reg, self._pending["reg"] = self._pending["reg"], (desc, desc_ready, pcd_m)
+        reg, self._pending["reg"] = self._pending["reg"], (desc, desc_ready, pcd_m, halo_pcd if self.chain else None)
         return self._register_on_b(reg) if reg is not None else None
 
     def _register_on_b(self, reg):
         dev = self.encoder.device
         main = torch.cuda.current_stream(dev)
         sb = self._side["reg"]
-        desc, desc_ready, scans = reg
-        pairs, index = self._ring_pairs(desc.shape[0], dev)
+        desc, desc_ready, scans, halo_pcd = reg
+        F = desc.shape[0] - (1 if self.chain else 0)
+        pairs, index = self._ring_pairs(F, dev, self.chain)
         with torch.cuda.stream(sb):
             sb.wait_event(desc_ready)
             pcd_m = grids = None
             if scans is not None:
                 pcd_m, grids, grids_ready = scans
                 sb.wait_event(grids_ready)
-            _, table = self.register(desc, pcd_m, pairs, materialize=False, pair_index=index, grids=grids)
+            _, table = self.register(desc, pcd_m, pairs, materialize=False, pair_index=index, grids=grids, halo_pcd=halo_pcd)
             done = sb.record_event()
         table.record_stream(main)
         main.wait_event(done)  # the caller's stream sees finished results (e.g. for the RCCL gather)
-        return desc, table
+        return desc[:F], table
 
     @torch.no_grad()
     def flush(self):

@@ -60,3 +60,23 @@ def gather_step_results(desc: torch.Tensor, edges_packed: torch.Tensor, root: in
     d = out[:, :nd].reshape((world * desc.shape[0],) + tuple(desc.shape[1:]))
     e = out[:, nd:].reshape((world * edges_packed.shape[0],) + tuple(edges_packed.shape[1:]))
     return d, e
+
+
+def exchange_halo(last_desc: torch.Tensor, last_pcd: Optional[torch.Tensor]):
+    """Ring hand-over of a block's LAST frame to the rank that owns the following block: the first frame of rank r's
+    block is registered against the last frame of rank r-1's (reference odometry.py:103-127 registers every new scan
+    against its predecessor).  Sends (descriptor (131,S), scan (3,N) or None) to rank+1, returns what rank-1 sent --
+    one point-to-point message per rank and step (134 KB + 786 KB at 65 536 points).  Rank 0 receives the last frame of
+    the whole window: the predecessor of ITS first frame in the NEXT step (the caller keeps it until then)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    parts = [last_desc.reshape(-1)] + ([last_pcd.reshape(-1)] if last_pcd is not None else [])
+    flat = torch.cat(parts).contiguous()
+    host = flat.is_cuda and dist.get_backend() == "gloo"  # dry-run backend: gloo moves host tensors only
+    send = flat.cpu() if host else flat
+    recv = torch.empty_like(send)
+    ops_ = [dist.P2POp(dist.isend, send, (rank + 1) % world), dist.P2POp(dist.irecv, recv, (rank - 1) % world)]
+    for req in dist.batch_isend_irecv(ops_):
+        req.wait()
+    recv = recv.to(flat.device) if host else recv
+    nd = last_desc.numel()
+    return recv[:nd].view_as(last_desc), (recv[nd:].view_as(last_pcd) if last_pcd is not None else None)

@@ -1,0 +1,103 @@
+"""Two ranks folded onto the one GPU of the test box (gloo rendezvous on 127.0.0.1, the DPM_BENCH_BACKEND=gloo dry-run
+path of bench.py): the HIP hot path runs under a process group, block-boundary edges come from the neighbour rank's
+last frame (shard.exchange_halo), and rank 0 receives exactly the descriptors and edge tables that ONE process
+produces for the same frames in sequence."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F, N = 3, 8192
+
+
+def _hot(dev):
+    from deeppointmap_amd.config import reduced_args
+    from deeppointmap_amd.decoder import Decoder
+    from deeppointmap_amd.encoder import Encoder
+    from deeppointmap_amd.pipeline import HotPath
+    from deeppointmap_amd.weights import init_procedural
+    cfg = reduced_args()
+    hot = HotPath(init_procedural(Encoder(cfg)).to(dev), init_procedural(Decoder(cfg)).to(dev))
+    hot.chain = True
+    return hot
+
+
+def _block(rank, step, world, dev):
+    """frames of rank `rank` in step `step`: the global sequence is cut into steps of world * F frames"""
+    from deeppointmap_amd import synthetic
+    pts, pad = synthetic.frames(F, N, start=(step * world + rank) * F)
+    return pts.to(dev), pad.to(dev), (pts * 60.0).contiguous().to(dev)
+
+
+def _worker(rank, world, port, q, pipelined):
+    import torch.distributed as dist
+    from deeppointmap_amd.shard import gather_step_results
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_grad_enabled(False)
+    dev = torch.device("cuda:0")
+    hot = _hot(dev)
+    got = []
+    for step in range(2):
+        pts, pad, pcd = _block(rank, step, world, dev)
+        if pipelined:
+            done = hot.submit(pts, pad, pcd)
+            outs = [done] if done is not None else []
+        else:
+            desc, _, table = hot.step(pts, pad, pcd, materialize=False)
+            outs = [(desc, table)]
+        for d, t in outs:
+            gd, gt = gather_step_results(d.contiguous(), t)
+            if rank == 0:
+                got.append((gd.cpu(), gt.cpu()))
+    if pipelined:
+        for d, t in hot.flush():
+            gd, gt = gather_step_results(d.contiguous(), t)
+            if rank == 0:
+                got.append((gd.cpu(), gt.cpu()))
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put([(d.numpy(), t.numpy()) for d, t in got])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_two_ranks_equal_one_process_in_sequence(pipelined):
+    import numpy as np
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200 + (50 if pipelined else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, pipelined)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # one process, the same 4 blocks in sequence order (step 0: rank 0, rank 1; step 1: rank 0, rank 1)
+    dev = torch.device("cuda:0")
+    hot = _hot(dev)
+    want = []
+    for step in range(2):
+        blocks = []
+        for rank in range(world):
+            desc, _, table = hot.step(*_block(rank, step, world, dev), materialize=False)
+            blocks.append((desc.cpu().numpy().copy(), table.cpu().numpy().copy()))
+        want.append((np.concatenate([b[0] for b in blocks]), np.concatenate([b[1] for b in blocks])))
+    assert len(got) == 2
+    for s, ((gd, gt), (wd, wt)) in enumerate(zip(got, want)):
+        assert gd.shape[:2] == (world * F, 131) and gt.shape == (world * F, 56)
+        assert np.array_equal(gd, wd), s                       # descriptors: the very same kernels on the same frames
+        # edges: rank 1's first edge has rank 0's last frame as its source (halo), and from step 1 on rank 0's first
+        # edge has rank 1's last frame of the step before: all of it equals the single process walking the sequence
+        np.testing.assert_allclose(gt, wt, rtol=0, atol=0, err_msg=f"step {s}")
+    # and the boundary edge is a real one: not the ring edge a lone batch would have produced
+    lone = _hot(dev)
+    lone.chain = False
+    _, _, ring_table = lone.step(*_block(1, 0, world, dev), materialize=False)
+    assert not np.allclose(ring_table.cpu().numpy()[0, :12], want[0][1][F, :12])
