@@ -125,3 +125,55 @@ def preprocess_scan(xyz: torch.Tensor, voxel_size: float = 0.3, min_dis: float =
     pts = ops.to_channel_first(out[:n_out].unsqueeze(0).contiguous()) if n_out else out[:0].t().unsqueeze(0)
     pad = torch.zeros(1, n_out, dtype=torch.bool, device=dev)
     return (pts, pad, idx[:n_out]) if return_index else (pts, pad)
+
+
+def preprocess_scans(scans, voxel_size: float = 0.3, min_dis: float = 1.0, max_dis: float = 60.0, ratio: float = 60.0,
+                     padding_to: int = -1, max_cells: int = MAX_CELLS, streams: int = 4):
+    """The head of the shipped chain (VoxelSample -> DistanceSample -> CoordinatesNormalization) for a LIST of raw scans
+    ((N_i,3|4) fp32, CPU or GPU) in one go: the scans' kernels are spread over `streams` HIP streams (one voxel-grid
+    workspace per stream), their output lengths come back with ONE host synchronisation, and the results are packed into
+    the batch the encoder -- and the reference's multi-thread extractor, system/core.py:141-169 -- takes:
+    points (B,3,M) fp32, padding (B,M) bool (True past a scan's length), lengths list.  M = the longest scan, or
+    `padding_to` when positive (ToTensor(padding_to), configs/infer/*.yaml:29; scans longer than it are an error).
+    Per scan the points are bit-identical to preprocess_scan()."""
+    if not scans:
+        raise ValueError("no scans")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lib = _lib.load()
+    cur = torch.cuda.current_stream(dev)
+    side = [torch.cuda.Stream(device=dev) for _ in range(min(streams, len(scans)))]
+    work = [torch.empty(lib.dpm_preprocess_workspace_bytes(max_cells), device=dev, dtype=torch.uint8) for _ in side]
+    status = torch.zeros(len(scans), 2, device=dev, dtype=torch.int32)
+    outs = []
+    for st in side:
+        st.wait_stream(cur)
+    for b, xyz in enumerate(scans):
+        st = side[b % len(side)]
+        with torch.cuda.stream(st):
+            x = xyz.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
+            if x.dim() != 2 or x.shape[1] < 3:
+                raise ValueError("every scan must be (N,3) or (N,>=3)")
+            N, stride = x.shape
+            out = torch.empty(N, 3, device=dev, dtype=torch.float32)
+            idx = torch.empty(N, device=dev, dtype=torch.int32)
+            _lib.check(lib.dpm_preprocess_scan(ops._ptr(x), N, stride, float(voxel_size), float(min_dis), float(max_dis),
+                                               float(ratio), int(max_cells), ops._ptr(out), ops._ptr(idx), N,
+                                               ops._ptr(status[b]), ops._ptr(work[b % len(side)]), st.cuda_stream),
+                       "dpm_preprocess_scan")
+            x.record_stream(st)
+            outs.append(out)
+    for st in side:
+        cur.wait_stream(st)
+    st_host = status.cpu().tolist()  # the one host sync of the batch
+    if any(o for _, o in st_host):
+        raise ValueError(f"voxel grid exceeds max_cells={max_cells}; crop the scans or raise max_cells")
+    lengths = [n for n, _ in st_host]
+    M = max(lengths) if padding_to <= 0 else padding_to
+    if max(lengths) > M:
+        raise ValueError(f"a scan keeps {max(lengths)} points, more than padding_to={padding_to}")
+    pts = torch.zeros(len(scans), 3, M, device=dev, dtype=torch.float32)
+    for b, (out, n) in enumerate(zip(outs, lengths)):
+        if n:
+            pts[b, :, :n] = out[:n].t()
+    pad = torch.arange(M, device=dev).unsqueeze(0) >= torch.tensor(lengths, device=dev).unsqueeze(1)
+    return pts, pad, lengths
