@@ -10,6 +10,7 @@ from typing import Optional, Tuple
 
 import ctypes
 import os
+import threading
 import weakref
 
 import torch
@@ -194,21 +195,41 @@ PROJECTED_COUT = (32, 64, 128, 256, 512)
 # version, so load_state_dict / .to() / optimiser steps invalidate it.  Callers pass the parameter tensors
 # themselves, not views made per call.
 _DERIVED: dict = {}
+_DERIVED_LOCK = threading.Lock()   # the reference drives one Encoder / Decoder from several threads (core.py:54-57)
+_RETIRED: list = []                # replaced values stay alive until the device has been synchronised once more
+
+
+def invalidate_derived() -> None:
+    """Forget every tensor derived from weights.  load_state_dict() calls it (ParamTree); call it yourself after editing
+    weights through `.data` (which does not bump the version counter the cache keys on)."""
+    with _DERIVED_LOCK:
+        _RETIRED.extend(v[2] for v in _DERIVED.values())
+        _DERIVED.clear()
 
 
 def _derived(tag: str, sources, make):
     key = (tag,) + tuple(id(t) for t in sources)
     stamp = tuple((t.data_ptr(), t._version) for t in sources)
-    hit = _DERIVED.get(key)
     dev = sources[0].device
-    if hit is not None and hit[1] == stamp and all(r() is t for r, t in zip(hit[0], sources)):
-        torch.cuda.current_stream(dev).wait_event(hit[3])  # made on another stream, possibly moments ago
-        return hit[2]
-    if len(_DERIVED) >= 512:
-        _DERIVED.clear()
-    value = make()
-    _DERIVED[key] = (tuple(weakref.ref(t) for t in sources), stamp, value, torch.cuda.current_stream(dev).record_event())
-    return value
+    cur = torch.cuda.current_stream(dev)
+    with _DERIVED_LOCK:
+        hit = _DERIVED.get(key)
+        if hit is not None and hit[1] == stamp and all(r() is t for r, t in zip(hit[0], sources)):
+            cur.wait_event(hit[3])       # made on another stream, possibly moments ago
+            for v in (hit[2] if isinstance(hit[2], (tuple, list)) else (hit[2],)):
+                v.record_stream(cur)     # ... and read on this one: the allocator must not recycle it under the reader
+            return hit[2]
+        if len(_RETIRED) > 64:           # rare: bounded by a device sync, after which nothing can still read them
+            torch.cuda.synchronize(dev)
+            _RETIRED.clear()
+        if hit is not None:
+            _RETIRED.append(hit[2])
+        if len(_DERIVED) >= 512:
+            _RETIRED.extend(v[2] for v in _DERIVED.values())
+            _DERIVED.clear()
+        value = make()
+        _DERIVED[key] = (tuple(weakref.ref(t) for t in sources), stamp, value, cur.record_event())
+        return value
 
 
 def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, generic: bool = False,

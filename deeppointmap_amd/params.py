@@ -117,6 +117,17 @@ class ParamTree(nn.Module):
     def p(self, key: str) -> torch.Tensor:
         return self._flat[key]
 
+    def invalidate_caches(self) -> None:
+        """Drop the tensors the kernels derived from these weights (folded point_mlp0, packed feature columns ...).
+        Automatic on load_state_dict(); needed by hand only after in-place edits through `.data`."""
+        from . import ops
+        ops.invalidate_derived()
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_caches()
+        return out
+
     def flat(self) -> Dict[str, torch.Tensor]:
         """{key: tensor} view of the live parameters (what the oracle calls `sd`)."""
         return dict(self._flat)

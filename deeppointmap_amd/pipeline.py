@@ -164,8 +164,8 @@ class HotPath:
     @torch.no_grad()
     def submit(self, points: torch.Tensor, padding: torch.Tensor, pcd_m: Optional[torch.Tensor]):
         """Enqueue a batch; returns the (desc, table) of an earlier batch once the pipe is full (None while it
-        fills).  Inputs must already be ready on the device (stage G reads them without waiting for the caller's
-        stream)."""
+        fills).  The geometry stage waits for whatever the caller's stream has enqueued so far, so inputs may come from
+        asynchronous copies or kernels on that stream."""
         dev = self.encoder.device
         if self._side is None:
             self._side = dict(geo=[torch.cuda.Stream(device=dev) for _ in range(max(1, self.geometry_depth))],
@@ -191,6 +191,7 @@ class HotPath:
         sa = self._side["geo"][self._pending["n"] % len(self._side["geo"])]
         self._pending["n"] += 1
         rings = [self._ring_pairs(h[0].shape[0], dev) if h[2] is not None else None for h in hold]  # before the stream switch: a first call copies H2D
+        sa.wait_stream(main)  # inputs the caller produced asynchronously on its stream (H2D copies, GPU pre-processing)
         with torch.cuda.stream(sa):
             first = self.encoder.sample_first_level([h[0] for h in hold], [h[1] for h in hold]) if len(hold) > 1 else [None]
             for (points, padding, pcd_m), ring, s0 in zip(hold, rings, first):
@@ -224,6 +225,7 @@ class HotPath:
                     t.record_stream(sf)
                 desc = self.extract(points, padding, presampled=pre)
                 desc_ready = sf.record_event()
+            desc.record_stream(main)  # handed to the caller (gather, host copies) on its stream
         else:
             main.wait_event(ready)
             desc = self.extract(points, padding, presampled=pre)
