@@ -176,6 +176,153 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
         }
 }
 
+// GEMM + LayerNorm in one kernel for layers whose output row fits one block (Cout = BN in {32, 64, 128, 256}: every
+// Conv1d / Linear of the path that is followed by a LayerNorm except the widest expansions): out = act(LN(X W^T + bias +
+// pre) * gamma + beta + post).  Same main loop as above (K-tile 32, register prefetch); the epilogue keeps the
+// accumulators in registers: a lane owns 4 consecutive columns of one row per 16x16 block, the row statistics meet
+// through two lane shuffles (the four 16-lane groups of a wave hold the same rows) and one LDS exchange across the
+// waves that share a row (mean first, then the centred squares: the two-pass form of layernorm_vec_kernel).  Saves the
+// separate LayerNorm launch and the round trip of the pre-norm activations through HBM.
+template <int BM, int BN, int WGM, int WGN, bool KFULL>
+__global__ __launch_bounds__(256) void gemm_ln_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W, int ldw,
+                                                      const float *__restrict__ bias, const float *__restrict__ pre,
+                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                      const float *__restrict__ post, float *__restrict__ out, int ldo, int R,
+                                                      int Cin, int act) {
+    constexpr int KT = 32, LDS_LD = KT + 2, LPR = KT / 4, RPP = 256 / LPR;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MB = WM / 16, NB = WN / 16, PX = BM / RPP, PW = BN / RPP;
+    static_assert(WGM * WGN == 4 && MB >= 1 && NB >= 1 && PX >= 1 && PW >= 1, "tile shape");
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    __shared__ float s_red[2][WGN][BM];
+    float (*Xs)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(smem);
+    float (*Ws)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(smem + BM * LDS_LD);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w / WGN, wn = w % WGN;
+    const int row0 = blockIdx.x * BM;
+    const int sr_ = t / LPR, sk = (t % LPR) * 4;
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 xr[PX], wr[PW];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) xr[p] = load4<true, KFULL>(X, ldx, row0 + p * RPP + sr_, R, sk, Cin);
+#pragma unroll
+    for (int p = 0; p < PW; ++p) wr[p] = load4<true, KFULL>(W, ldw, p * RPP + sr_, BN, sk, Cin);
+    for (int k0 = 0; k0 < Cin; k0 += KT) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            float2 *d = reinterpret_cast<float2 *>(&Xs[p * RPP + sr_][sk]);
+            d[0] = make_float2(xr[p].x, xr[p].y), d[1] = make_float2(xr[p].z, xr[p].w);
+        }
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            float2 *d = reinterpret_cast<float2 *>(&Ws[p * RPP + sr_][sk]);
+            d[0] = make_float2(wr[p].x, wr[p].y), d[1] = make_float2(wr[p].z, wr[p].w);
+        }
+        __syncthreads();
+        if (k0 + KT < Cin) {
+#pragma unroll
+            for (int p = 0; p < PX; ++p) xr[p] = load4<true, KFULL>(X, ldx, row0 + p * RPP + sr_, R, k0 + KT + sk, Cin);
+#pragma unroll
+            for (int p = 0; p < PW; ++p) wr[p] = load4<true, KFULL>(W, ldw, p * RPP + sr_, BN, k0 + KT + sk, Cin);
+        }
+        float a[2][MB], b[2][NB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) a[0][i] = Xs[wm * WM + i * 16 + (lane & 15)][lane >> 4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b[0][j] = Ws[wn * WN + j * 16 + (lane & 15)][lane >> 4];
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 4) {
+            const int cur = (kk >> 2) & 1, nxt = cur ^ 1;
+            if (kk + 4 < KT) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) a[nxt][i] = Xs[wm * WM + i * 16 + (lane & 15)][kk + 4 + (lane >> 4)];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) b[nxt][j] = Ws[wn * WN + j * 16 + (lane & 15)][kk + 4 + (lane >> 4)];
+            }
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[cur][j], a[cur][i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: bias + pre, row statistics, affine, post, activation
+    const int cg = (lane >> 4) * 4;  // first of this lane's 4 columns inside a 16-column block
+    float rsum[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int r = min(row0 + wm * WM + i * 16 + (lane & 15), R - 1);
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int c = wn * WN + j * 16 + cg;
+            const float4 bv = bias ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pre) pv = *reinterpret_cast<const float4 *>(pre + (size_t)r * BN + c);
+            acc[i][j][0] += bv.x + pv.x, acc[i][j][1] += bv.y + pv.y, acc[i][j][2] += bv.z + pv.z, acc[i][j][3] += bv.w + pv.w;
+            sacc += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        }
+        sacc += __shfl_xor(sacc, 16, 64);
+        sacc += __shfl_xor(sacc, 32, 64);
+        rsum[i] = sacc;
+        if (WGN > 1 && lane < 16) s_red[0][wn][wm * WM + i * 16 + lane] = sacc;
+    }
+    if (WGN > 1) __syncthreads();
+    float mu[MB], rstd[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        float s_ = rsum[i];
+        if (WGN > 1) {
+            s_ = 0.f;
+#pragma unroll
+            for (int q = 0; q < WGN; ++q) s_ += s_red[0][q][wm * WM + i * 16 + (lane & 15)];
+        }
+        mu[i] = s_ / (float)BN;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[i][j][q] -= mu[i];
+                sq = fmaf(acc[i][j][q], acc[i][j][q], sq);
+            }
+        sq += __shfl_xor(sq, 16, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        rstd[i] = sq;
+        if (WGN > 1 && lane < 16) s_red[1][wn][wm * WM + i * 16 + lane] = sq;
+    }
+    if (WGN > 1) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        float s_ = rstd[i];
+        if (WGN > 1) {
+            s_ = 0.f;
+#pragma unroll
+            for (int q = 0; q < WGN; ++q) s_ += s_red[1][q][wm * WM + i * 16 + (lane & 15)];
+        }
+        const float rs = rsqrtf(s_ / (float)BN + 1e-5f);
+        const int r = row0 + wm * WM + i * 16 + (lane & 15);
+        if (r >= R) continue;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int c = wn * WN + j * 16 + cg;
+            const float4 g4 = *reinterpret_cast<const float4 *>(gamma + c), b4 = *reinterpret_cast<const float4 *>(beta + c);
+            float4 o = make_float4(fmaf(acc[i][j][0] * rs, g4.x, b4.x), fmaf(acc[i][j][1] * rs, g4.y, b4.y),
+                                   fmaf(acc[i][j][2] * rs, g4.z, b4.z), fmaf(acc[i][j][3] * rs, g4.w, b4.w));
+            if (post) {
+                const float4 pv = *reinterpret_cast<const float4 *>(post + (size_t)r * BN + c);
+                o.x += pv.x, o.y += pv.y, o.z += pv.z, o.w += pv.w;
+            }
+            o.x = apply_act(o.x, act), o.y = apply_act(o.y, act), o.z = apply_act(o.z, act), o.w = apply_act(o.w, act);
+            *reinterpret_cast<float4 *>(out + (size_t)r * ldo + c) = o;
+        }
+    }
+}
+
 // Large-shape variant: block tile 128x128, 4 waves as 2x2, wave tile 64x64 = 2x2 blocks of
 // v_mfma_f32_32x32x2_f32 (64 accumulator registers; half the LDS fragment traffic and half the
 // global->LDS staging per flop of the 64x64 kernel).  K-tile 32, LDS row stride 36 floats: 16-byte
@@ -352,4 +499,35 @@ extern "C" int dpm_linear_batched(const float *x, int ldx, long long sx, const f
 extern "C" int dpm_linear(const float *x, int ldx, const float *W, int ldw, const float *bias, const float *residual,
                           int ldr, float *out, int ldo, int R, int Cin, int Cout, int act, dpm_stream_t stream) {
     return dpm_linear_batched(x, ldx, 0, W, ldw, 0, bias, residual, ldr, 0, out, ldo, 0, 1, R, Cin, Cout, act, stream);
+}
+
+// Conv1d(k=1)/Linear + LayerNorm1d (+ residuals, + activation) as ONE kernel: out = act(LN(x W^T + bias + pre) * gamma +
+// beta + post), rows of Cout in {32, 64, 128, 256}; pre / post are packed (R, Cout).  DPM_EUNSUPPORTED for other
+// widths or unaligned operands: the caller then runs dpm_linear + dpm_layernorm.
+extern "C" int dpm_linear_layernorm(const float *x, int ldx, const float *W, int ldw, const float *bias, const float *pre,
+                                    const float *gamma, const float *beta, const float *post, float *out, int ldo, int R,
+                                    int Cin, int Cout, int act, dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && W && gamma && beta && out && R >= 1 && Cin >= 1 && Cout >= 1 && ldx >= Cin && ldw >= Cin && ldo >= Cout);
+    DPM_CHECK_ARG(act >= DPM_ACT_NONE && act <= DPM_ACT_SIGMOID);
+    auto al = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+    if (!(ldx % 4 == 0 && ldw % 4 == 0 && ldo % 4 == 0 && Cin % 4 == 0 && al(x) && al(W) && al(bias) && al(pre) && al(gamma) &&
+          al(beta) && al(post) && al(out)))
+        return DPM_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+#define DPM_GLN(BM, BN, WGM, WGN)                                                                                          \
+    do {                                                                                                                   \
+        if (Cin % 32 == 0)                                                                                                 \
+            hipLaunchKernelGGL((gemm_ln_kernel<BM, BN, WGM, WGN, true>), dim3(dpm_cdiv(R, BM)), dim3(256), 0, st, x, ldx, W, ldw, \
+                               bias, pre, gamma, beta, post, out, ldo, R, Cin, act);                                       \
+        else                                                                                                               \
+            hipLaunchKernelGGL((gemm_ln_kernel<BM, BN, WGM, WGN, false>), dim3(dpm_cdiv(R, BM)), dim3(256), 0, st, x, ldx, W, ldw, \
+                               bias, pre, gamma, beta, post, out, ldo, R, Cin, act);                                       \
+    } while (0)
+    if (Cout == 256) DPM_GLN(64, 256, 1, 4);
+    else if (Cout == 128) DPM_GLN(64, 128, 2, 2);
+    else if (Cout == 64) DPM_GLN(64, 64, 2, 2);
+    else if (Cout == 32) DPM_GLN(128, 32, 4, 1);
+    else return DPM_EUNSUPPORTED;
+#undef DPM_GLN
+    return dpm_launch_status();
 }

@@ -58,6 +58,11 @@ class Decoder(ParamTree):
     def _ln(self, key: str, x, post=None):
         return ops.layernorm(x, self.p(key + ".weight"), self.p(key + ".bias"), post=post)
 
+    def _lin_ln(self, lin: str, ln: str, x, residual, post=None):
+        """LN(x W^T + b + residual) (+ post): projection and LayerNorm in one kernel"""
+        return ops.linear_layernorm(x, self.p(lin + ".weight"), self.p(lin + ".bias"), self.p(ln + ".weight"),
+                                    self.p(ln + ".bias"), pre=residual, post=post)
+
     def _stage(self, desc: torch.Tensor, dev) -> Tuple[torch.Tensor, torch.Tensor, int, int]:
         """(B,131,M) any device -> token-major rows (B*M,131) on the GPU."""
         d = desc.to(device=dev, dtype=torch.float32).contiguous()
@@ -66,18 +71,23 @@ class Decoder(ParamTree):
             raise ValueError(f"descriptor must have {self.in_channel + 3} rows, got {C}")
         return ops.to_channel_first(d).view(B * M, C), B, M
 
-    def _self_attn(self, pre: str, xp, B, M):
+    def _self_attn(self, pre: str, xp, B, M, norm: str = None, post=None):
+        """x + MHA(x, x, x) (norm None) or LN_norm(x + MHA(x, x, x)) + post, the out-projection carrying the norm"""
         E = self.model_channel
         qkv = ops.linear(xp, self.p(pre + ".in_proj_weight"), self.p(pre + ".in_proj_bias"))
         a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, M, M, HEADS)
+        if norm is not None:
+            return self._lin_ln(pre + ".out_proj", norm, a, xp, post)
         return ops.linear(a, self.p(pre + ".out_proj.weight"), self.p(pre + ".out_proj.bias"), residual=xp)
 
-    def _cross_attn(self, pre: str, xq, xkv, B, M, N):
+    def _cross_attn(self, pre: str, xq, xkv, B, M, N, norm: str = None):
         E = self.model_channel
         w, b = self.p(pre + ".in_proj_weight"), self.p(pre + ".in_proj_bias")
         q = ops.linear(xq, w[:E], b[:E])
         kv = ops.linear(xkv, w[E:], b[E:])
         a = ops.attention(q, kv[:, :E], kv[:, E:], B, M, N, HEADS)
+        if norm is not None:
+            return self._lin_ln(pre + ".out_proj", norm, a, xq)
         return ops.linear(a, self.p(pre + ".out_proj.weight"), self.p(pre + ".out_proj.bias"), residual=xq)
 
     def _descriptor_attention_forward(self, src_descriptor, dst_descriptor, src_padding_mask=None,
@@ -104,16 +114,16 @@ class Decoder(ParamTree):
             pre = f"descriptor_attention.{l}"
             last = l == self.attention_layers - 1
             # self attention: LN1(x + attn(x)), then + pos for the cross block   (descriptor_attention.py:31-40)
-            x1 = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", xp, B, M), post=ps)
-            y1 = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", yp, B, N), post=pd)
+            x1 = self._self_attn(pre + ".self_attn", xp, B, M, norm=pre + ".norm1", post=ps)
+            y1 = self._self_attn(pre + ".self_attn", yp, B, N, norm=pre + ".norm1", post=pd)
             # cross attention, both directions read the pre-update tensors      (descriptor_attention.py:41-44)
-            x2 = self._ln(pre + ".norm2", self._cross_attn(pre + ".cross_attn", x1, y1, B, M, N))
-            y2 = self._ln(pre + ".norm2", self._cross_attn(pre + ".cross_attn", y1, x1, B, N, M))
+            x2 = self._cross_attn(pre + ".cross_attn", x1, y1, B, M, N, norm=pre + ".norm2")
+            y2 = self._cross_attn(pre + ".cross_attn", y1, x1, B, N, M, norm=pre + ".norm2")
             # MLP: LN3(mlp(x) + x); the next layer starts with + pos            (descriptor_attention.py:47-48)
-            xp = self._ln(pre + ".norm3", self._lin(pre + ".mlp.2", self._lin(pre + ".mlp.0", x2, ops.ACT_RELU),
-                                                    residual=x2), post=None if last else ps)
-            yp = self._ln(pre + ".norm3", self._lin(pre + ".mlp.2", self._lin(pre + ".mlp.0", y2, ops.ACT_RELU),
-                                                    residual=y2), post=None if last else pd)
+            xp = self._lin_ln(pre + ".mlp.2", pre + ".norm3", self._lin(pre + ".mlp.0", x2, ops.ACT_RELU), x2,
+                              None if last else ps)
+            yp = self._lin_ln(pre + ".mlp.2", pre + ".norm3", self._lin(pre + ".mlp.0", y2, ops.ACT_RELU), y2,
+                              None if last else pd)
         return xp, xyz_s, yp, xyz_d, B, M, N
 
     def _attention_layers_joint(self, ts, td, B, M, frames=None):
@@ -134,7 +144,7 @@ class Decoder(ParamTree):
             pos_u = ops.posemb(tu[:, C:C + 3], self._dimt(dev), E)
             zu = ops.linear(tu[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=pos_u)
             pre = "descriptor_attention.0"
-            z1u = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", zu, U, M), post=pos_u)
+            z1u = self._self_attn(pre + ".self_attn", zu, U, M, norm=pre + ".norm1", post=pos_u)
             order = sidx if didx is None else torch.cat([sidx, didx])  # (2B,) int32: sources then targets
             pos = ops.gather_frames(pos_u, order, M, E).view(2 * R, E)
             z1_first = ops.gather_frames(z1u, order, M, E).view(2 * R, E)
@@ -150,16 +160,15 @@ class Decoder(ParamTree):
             if l == 0 and z1_first is not None:
                 z1 = z1_first
             else:
-                z1 = self._ln(pre + ".norm1", self._self_attn(pre + ".self_attn", zp, 2 * B, M), post=pos)
+                z1 = self._self_attn(pre + ".self_attn", zp, 2 * B, M, norm=pre + ".norm1", post=pos)
             ca = pre + ".cross_attn"
             qkv = ops.linear(z1, self.p(ca + ".in_proj_weight"), self.p(ca + ".in_proj_bias"))  # q | k | v of every token
             # both directions in one launch: sequence b (source of pair b, or target of pair b - B) reads the keys and
             # values of sequence (b + B) mod 2B, its partner
             a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], 2 * B, M, M, HEADS, kv_shift=B)
-            z2 = self._ln(pre + ".norm2", ops.linear(a, self.p(ca + ".out_proj.weight"), self.p(ca + ".out_proj.bias"),
-                                                     residual=z1))
-            zp = self._ln(pre + ".norm3", self._lin(pre + ".mlp.2", self._lin(pre + ".mlp.0", z2, ops.ACT_RELU),
-                                                    residual=z2), post=None if last else pos)
+            z2 = self._lin_ln(ca + ".out_proj", pre + ".norm2", a, z1)
+            zp = self._lin_ln(pre + ".mlp.2", pre + ".norm3", self._lin(pre + ".mlp.0", z2, ops.ACT_RELU), z2,
+                              None if last else pos)
         return zp[:R], zp[R:]
 
     # -- public API ----------------------------------------------------------------------------

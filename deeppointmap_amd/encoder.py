@@ -51,8 +51,8 @@ class Encoder(ParamTree):
         return self.p("point_mlp0.weight").device
 
     def _mlp_ln(self, x: torch.Tensor, conv: str, ln: str, act: int, post: Optional[torch.Tensor] = None):
-        y = ops.linear(x, self.p(conv + ".weight"), self.p(conv + ".bias"))
-        return ops.layernorm(y, self.p(ln + ".weight"), self.p(ln + ".bias"), act=act, post=post)
+        return ops.linear_layernorm(x, self.p(conv + ".weight"), self.p(conv + ".bias"), self.p(ln + ".weight"),
+                                    self.p(ln + ".bias"), act=act, post=post)
 
     def _group(self, prefix: str, radius: float, xyz, fea, centers, idx):
         return ops.group_mlp_max(xyz, fea, centers, idx, self.p(prefix + ".0.weight"), self.p(prefix + ".0.bias"),

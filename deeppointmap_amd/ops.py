@@ -361,6 +361,35 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int
     return out
 
 
+FUSED_LN_WIDTHS = (32, 64, 128, 256)  # dpm_linear_layernorm: the output row must fit one workgroup's tile
+
+
+def linear_layernorm(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                     act: int = ACT_NONE, pre: Optional[torch.Tensor] = None, post: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(LN(x W^T + bias + pre) * gamma + beta + post): Conv1d(k=1)/Linear + LayerNorm1d in one kernel when the
+    output width is one of FUSED_LN_WIDTHS, otherwise the GEMM kernel followed by the LayerNorm kernel (same result up
+    to the summation order of the row statistics)."""
+    Cout, Cin = W.shape[0], W.shape[1]
+    x2 = x.reshape(-1, x.shape[-1])
+    if (Cout in FUSED_LN_WIDTHS and W.is_contiguous() and x2.is_contiguous() and x.dtype == torch.float32 and Cin % 4 == 0
+            and os.environ.get("DPM_NO_FUSED_LN") != "1"):
+        _chk(W, torch.float32, "W")
+        out = torch.empty(*x.shape[:-1], Cout, device=x.device, dtype=torch.float32)
+        for n, t in (("pre", pre), ("post", post)):
+            if t is not None:
+                _chk(t, torch.float32, n)
+                if t.numel() != out.numel():
+                    raise ValueError(f"{n} must have the shape of the output")
+        st = _lib.load().dpm_linear_layernorm(_ptr(x2), x2.stride(0), _ptr(W), Cin, _ptr(bias), _ptr(pre), _ptr(gamma),
+                                              _ptr(beta), _ptr(post), _ptr(out), Cout, x2.shape[0], Cin, Cout, act, _stream(x))
+        if st == 0:
+            return out
+        if st != -2:  # anything but "unsupported shape"
+            _lib.check(st, "dpm_linear_layernorm")
+    y = linear(x, W, bias, residual=pre)
+    return layernorm(y, gamma, beta, act=act, post=post)
+
+
 def three_interp_cat(xyz1, xyz2, lengths2, fea1, fea2) -> torch.Tensor:
     """fine xyz1 (B,N,3)/fea1 (B,N,D1), coarse xyz2 (B,S,3)/fea2 (B,S,D2) -> (B,N,D1+D2)."""
     for n, t in (("xyz1", xyz1), ("xyz2", xyz2), ("fea1", fea1), ("fea2", fea2)):

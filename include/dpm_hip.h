@@ -172,6 +172,14 @@ int dpm_linear_batched(const float *x, int ldx, long long sx, const float *W, in
 int dpm_layernorm(const float *x, int ldx, const float *pre, const float *gamma, const float *beta,
                   const float *post, float *out, int ldo, int R, int C, int act, dpm_stream_t stream);
 
+/* Conv1d(k=1)/nn.Linear followed by LayerNorm1d (network/encoder/utils.py:358-413 build_mlp; the post-norm blocks of
+ * network/decoder/descriptor_attention.py:31-48) as ONE kernel: out = act(LN(x W^T + bias + pre) * gamma + beta + post),
+ * eps 1e-5, biased variance.  Cout in {32,64,128,256}; pre / post packed (R,Cout) or NULL.  Returns DPM_EUNSUPPORTED
+ * for other widths / unaligned operands (run dpm_linear + dpm_layernorm then). */
+int dpm_linear_layernorm(const float *x, int ldx, const float *W, int ldw, const float *bias, const float *pre,
+                         const float *gamma, const float *beta, const float *post, float *out, int ldo, int R, int Cin,
+                         int Cout, int act, dpm_stream_t stream);
+
 /* FeaturePropagation interpolation (network/encoder/pointnext.py:199-216): for each fine point
  * the 3 nearest valid coarse points (expanded-form distance), w_j = (1/max(d_j,1e-8))/sum;
  * out[b,n,:] = cat[fea1[b,n,:D1], sum_j w_j fea2[b,idx_j,:D2]].  S==1 broadcasts fea2. */
