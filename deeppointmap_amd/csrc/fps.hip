@@ -235,7 +235,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                                                         float *__restrict__ closest_all,
                                                         int32_t *__restrict__ idx_all,
                                                         float *__restrict__ new_xyz_all,
-                                                        int32_t *__restrict__ new_len) {
+                                                        int32_t *__restrict__ new_len, int slots) {
     constexpr int NW = FB / 64;
     constexpr int OB = 2048;  // picks buffered in LDS between flushes to global memory
     // per-wave bests, double-buffered by round parity: [parity][value, index bits, x, y, z][wave] in ONE block, so
@@ -246,12 +246,16 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
 
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float *xyz = xyz_all + (size_t)b * N * 3;
-    const float4 *pts = pts_all + (size_t)b * N;
-    float *closest = closest_all + (size_t)b * N;
+    // slots != 0 (Sort-Tile-Recursive packing, algo 5): every frame owns `slots` point slots; unused ones carry the index
+    // INT_MAX and closest = -1 (they never move and never win), so the slot count plays the part of the length below
+    const size_t fstride = slots ? (size_t)slots : (size_t)N;
+    const float4 *pts = pts_all + (size_t)b * fstride;
+    float *closest = closest_all + (size_t)b * fstride;
     int32_t *idx = idx_all + (size_t)b * K;
     float *new_xyz = new_xyz_all + (size_t)b * K * 3;
-    const int len = min(max(lengths[b], 0), N);
-    const int kn = min(len, K);
+    const int true_len = min(max(lengths[b], 0), N);
+    const int kn = min(true_len, K);
+    const int len = slots ? (true_len > 0 ? slots : 0) : true_len;
     const int nb = (len + 63) >> 6;
     const int my_bucket = lane * NW + w;
     const bool mine = my_bucket < nb;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
         float x0 = __builtin_inff(), y0 = x0, z0 = x0, x1 = -x0, y1 = -x0, z1 = -x0;
         if (q < len) {
             const float4 p = pts[q];
-            x0 = x1 = p.x, y0 = y1 = p.y, z0 = z1 = p.z;
+            if (__float_as_int(p.w) != 0x7fffffff) x0 = x1 = p.x, y0 = y1 = p.y, z0 = z1 = p.z;
         }
         x0 = -wave_max_dpp(-x0), y0 = -wave_max_dpp(-y0), z0 = -wave_max_dpp(-z0);
         x1 = wave_max_dpp(x1), y1 = wave_max_dpp(y1), z1 = wave_max_dpp(z1);
@@ -726,6 +730,9 @@ int launch(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_
 }  // namespace
 
 // fps_tree.hip
+size_t dpm_fps_str_bucket_workspace_bytes(int B, int N);
+int dpm_fps_str_bucket_sort(const float *xyz, const int32_t *lengths, int B, int N, float4 *pts, float *closest, float4 *tmp,
+                            hipStream_t st);
 size_t dpm_fps_tree_workspace_bytes(int B, int N);
 int dpm_fps_tree_launch(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx, float *new_xyz,
                         int32_t *new_lengths, void *workspace, hipStream_t st);
@@ -734,7 +741,9 @@ extern "C" size_t dpm_fps_workspace_bytes(int B, int N, int K) {
     (void)K;
     // bucket algorithms: float4 sorted points + closest, per frame; tree algorithm: see fps_tree.hip
     const size_t bucket = (size_t)B * (size_t)N * (sizeof(float4) + sizeof(int32_t)) + 512;
-    const size_t tree = N > 16384 && N <= 65536 ? dpm_fps_tree_workspace_bytes(B, N) : 0;
+    size_t tree = N > 16384 && N <= 65536 ? dpm_fps_tree_workspace_bytes(B, N) : 0;
+    const size_t strb = N > 16384 && N <= 65536 ? dpm_fps_str_bucket_workspace_bytes(B, N) : 0;
+    tree = tree > strb ? tree : strb;
     return bucket > tree ? bucket : tree;
 }
 
@@ -743,9 +752,23 @@ extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N
                           dpm_stream_t stream) {
     DPM_CHECK_ARG(xyz && lengths && idx && new_xyz && new_lengths);
     DPM_CHECK_ARG(B >= 1 && N >= 1 && K >= 1);
-    DPM_CHECK_ARG(algo >= 0 && algo <= 4);
+    DPM_CHECK_ARG(algo >= 0 && algo <= 5);
     hipStream_t st = (hipStream_t)stream;
-    if (algo == 0) algo = (N > 16384) ? 2 : 1;  // 2 has the shortest chain (1.2 us per pick); 4 the fewest instructions
+    if (algo == 0) algo = (N > 16384 && N <= 65536) ? 5 : (N > 16384 ? 2 : 1);  // 5: shortest chain (1.05 us per pick); 4: fewest instructions
+    if (algo == 5) {  // the bucket kernel over the Sort-Tile-Recursive packing of fps_tree.hip (fewer buckets survive a round)
+        DPM_CHECK_ARG(workspace != nullptr);
+        if (N <= 16384 || N > 65536) return DPM_EUNSUPPORTED;
+        const int slots = 65536;
+        uintptr_t p = (((uintptr_t)workspace + 255) & ~(uintptr_t)255) + 256;
+        float4 *pts = (float4 *)p;
+        float *closest = (float *)(pts + (size_t)B * slots);
+        float4 *tmp = (float4 *)(((uintptr_t)(closest + (size_t)B * slots) + 255) & ~(uintptr_t)255);
+        const int rc = dpm_fps_str_bucket_sort(xyz, lengths, B, N, pts, closest, tmp, st);
+        if (rc != DPM_OK) return rc;
+        hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
+                           new_lengths, slots);
+        return dpm_launch_status();
+    }
     if (algo == 4) {  // one wave per frame over a two-level box tree (fps_tree.hip)
         DPM_CHECK_ARG(workspace != nullptr);
         if (N <= 16384 || N > 65536) return DPM_EUNSUPPORTED;
@@ -766,7 +789,7 @@ extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N
                                new_xyz, new_lengths);
         else
             hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx,
-                               new_xyz, new_lengths);
+                               new_xyz, new_lengths, 0);
         return dpm_launch_status();
     }
     float *ws = (float *)workspace;

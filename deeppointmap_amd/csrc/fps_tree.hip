@@ -73,17 +73,33 @@ __device__ __forceinline__ void str_shape(int len, int &nsx, int &lps) {
 // ------------------------------------------------------------------------------------------
 // sort: Sort-Tile-Recursive packing of one frame per workgroup
 // ------------------------------------------------------------------------------------------
+// BUCKETS = true writes the layout of fps.hip's bucket kernel instead (algo 5): points (x, y, z, original index) +
+// a separate `closest` array (+inf; -1 in unused slots, whose index field is INT_MAX), TL * LEAF slots per frame.
+template <bool BUCKETS>
 __global__ __launch_bounds__(SB) void fps_tree_sort_kernel(const float *__restrict__ xyz_all,
-                                                           const int32_t *__restrict__ lengths, int N, char *ws) {
+                                                           const int32_t *__restrict__ lengths, int N, char *ws,
+                                                           float4 *__restrict__ bpts_all, float *__restrict__ bclosest_all,
+                                                           float4 *__restrict__ btmp_all) {
     __shared__ int s_hist[MAXSLAB * YB];  // 64 KB; the x pass uses the first XB counters
     __shared__ float s_red[4][SB / 64];
     __shared__ int s_wsum[SB / 64];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float *xyz = xyz_all + (size_t)b * N * 3;
-    const FrameWs f = frame_ws(ws, b, N);
+    FrameWs f;
+    float *bclosest = nullptr;
+    if (BUCKETS) {
+        f.pts = bpts_all + (size_t)b * TL * LEAF, f.tmp = btmp_all + (size_t)b * N, bclosest = bclosest_all + (size_t)b * TL * LEAF;
+        f.orig = nullptr, f.box = f.lmax = nullptr, f.best = nullptr;
+    } else {
+        f = frame_ws(ws, b, N);
+    }
     const int len = min(max(lengths[b], 0), N);
+    if (len == 0 && !BUCKETS) return;
+    for (int i = t; i < TL * LEAF; i += SB) {
+        f.pts[i] = make_float4(0.f, 0.f, 0.f, BUCKETS ? __int_as_float(0x7fffffff) : -1.f);
+        if (BUCKETS) bclosest[i] = -1.f;
+    }
     if (len == 0) return;
-    for (int i = t; i < TL * LEAF; i += SB) f.pts[i] = make_float4(0.f, 0.f, 0.f, -1.f);
 
     float lox = __builtin_inff(), loy = __builtin_inff(), hix = -__builtin_inff(), hiy = -__builtin_inff();
     for (int i = t; i < len; i += SB) {
@@ -178,9 +194,14 @@ __global__ __launch_bounds__(SB) void fps_tree_sort_kernel(const float *__restri
         const int tile = j >> 6;
         const int leaf = (((slab >> 2) * 8 + (tile >> 2)) << 4) + ((slab & 3) << 2) + (tile & 3);
         const int q = leaf * LEAF + (j & 63);
-        // closest distance after the first pick: min(+inf, d) = d
-        f.pts[q] = make_float4(p.x, p.y, p.z, sqdist(s0x, s0y, s0z, p.x, p.y, p.z));
-        f.orig[q] = __float_as_int(p.w);
+        if (BUCKETS) {
+            f.pts[q] = p;  // (x, y, z, original index)
+            bclosest[q] = __builtin_inff();
+        } else {
+            // closest distance after the first pick: min(+inf, d) = d
+            f.pts[q] = make_float4(p.x, p.y, p.z, sqdist(s0x, s0y, s0z, p.x, p.y, p.z));
+            f.orig[q] = __float_as_int(p.w);
+        }
     }
 }
 
@@ -431,8 +452,21 @@ int dpm_fps_tree_launch(const float *xyz, const int32_t *lengths, int B, int N, 
 #ifdef DPM_FPS_STATS
     (void)hipMemsetAsync(ws - 256, 0, 256, st);
 #endif
-    hipLaunchKernelGGL(fps_tree_sort_kernel, dim3(B), dim3(SB), 0, st, xyz, lengths, N, ws);
+    hipLaunchKernelGGL(fps_tree_sort_kernel<false>, dim3(B), dim3(SB), 0, st, xyz, lengths, N, ws, (float4 *)nullptr,
+                       (float *)nullptr, (float4 *)nullptr);
     hipLaunchKernelGGL(fps_tree_leaf_kernel, dim3(B * 4), dim3(256), 0, st, lengths, N, ws);
     hipLaunchKernelGGL(fps_tree_kernel, dim3(B), dim3(64), 0, st, xyz, lengths, N, K, ws, idx, new_xyz, new_lengths);
+    return dpm_launch_status();
+}
+
+// algo 5: the Sort-Tile-Recursive packing for fps.hip's bucket kernel (bucket = leaf; a 4 x 4 block of neighbouring
+// leaves lands on 16 different waves).  Workspace: TL * LEAF float4 + TL * LEAF float per frame, then N float4 scratch.
+size_t dpm_fps_str_bucket_workspace_bytes(int B, int N) {
+    return (size_t)B * ((size_t)TL * LEAF * (sizeof(float4) + sizeof(float)) + (size_t)N * sizeof(float4)) + 1024;
+}
+int dpm_fps_str_bucket_sort(const float *xyz, const int32_t *lengths, int B, int N, float4 *pts, float *closest, float4 *tmp,
+                            hipStream_t st) {
+    if (N > TL * LEAF) return DPM_EUNSUPPORTED;
+    hipLaunchKernelGGL(fps_tree_sort_kernel<true>, dim3(B), dim3(SB), 0, st, xyz, lengths, N, (char *)nullptr, pts, closest, tmp);
     return dpm_launch_status();
 }

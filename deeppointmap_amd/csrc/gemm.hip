@@ -178,11 +178,10 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
 
 // GEMM + LayerNorm in one kernel for layers whose output row fits one block (Cout = BN in {32, 64, 128, 256}: every
 // Conv1d / Linear of the path that is followed by a LayerNorm except the widest expansions): out = act(LN(X W^T + bias +
-// pre) * gamma + beta + post).  Same main loop as above (K-tile 32, register prefetch); the epilogue keeps the
-// accumulators in registers: a lane owns 4 consecutive columns of one row per 16x16 block, the row statistics meet
-// through two lane shuffles (the four 16-lane groups of a wave hold the same rows) and one LDS exchange across the
-// waves that share a row (mean first, then the centred squares: the two-pass form of layernorm_vec_kernel).  Saves the
-// separate LayerNorm launch and the round trip of the pre-norm activations through HBM.
+// pre) * gamma + beta + post).  Same main loop as above (K-tile 32, register prefetch); the epilogue stages the tile in
+// LDS and normalises it row by row with the lane-group arithmetic of layernorm_vec_kernel (two-pass mean / variance),
+// so bias, residuals and output move as whole rows.  Saves the separate LayerNorm launch and the round trip of the
+// pre-norm activations through HBM.
 template <int BM, int BN, int WGM, int WGN, bool KFULL>
 __global__ __launch_bounds__(256) void gemm_ln_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W, int ldw,
                                                       const float *__restrict__ bias, const float *__restrict__ pre,
@@ -192,8 +191,9 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const float *__restrict__ 
     constexpr int KT = 32, LDS_LD = KT + 2, LPR = KT / 4, RPP = 256 / LPR;
     constexpr int WM = BM / WGM, WN = BN / WGN, MB = WM / 16, NB = WN / 16, PX = BM / RPP, PW = BN / RPP;
     static_assert(WGM * WGN == 4 && MB >= 1 && NB >= 1 && PX >= 1 && PW >= 1, "tile shape");
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
-    __shared__ float s_red[2][WGN][BM];
+    constexpr int LDC = BN + 4;  // row stride of the staged output tile
+    constexpr int SMEM = (BM + BN) * LDS_LD > BM * LDC ? (BM + BN) * LDS_LD : BM * LDC;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float (*Xs)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(smem);
     float (*Ws)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(smem + BM * LDS_LD);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w / WGN, wn = w % WGN;
@@ -250,76 +250,45 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const float *__restrict__ 
         }
         __syncthreads();
     }
-    // ---- epilogue: bias + pre, row statistics, affine, post, activation
-    const int cg = (lane >> 4) * 4;  // first of this lane's 4 columns inside a 16-column block
-    float rsum[MB];
+    // ---- epilogue: the tile goes through LDS (the operand tiles are dead after the loop's last barrier) and is then
+    //      walked ROW-wise: G = BN / 4 lanes hold one row (a float4 each), so bias / pre / post / out are whole-row
+    //      accesses and the two LayerNorm sums are lane-group reductions -- the arithmetic of layernorm_vec_kernel
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
-        const int r = min(row0 + wm * WM + i * 16 + (lane & 15), R - 1);
-        float sacc = 0.f;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int c = wn * WN + j * 16 + cg;
-            const float4 bv = bias ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pre) pv = *reinterpret_cast<const float4 *>(pre + (size_t)r * BN + c);
-            acc[i][j][0] += bv.x + pv.x, acc[i][j][1] += bv.y + pv.y, acc[i][j][2] += bv.z + pv.z, acc[i][j][3] += bv.w + pv.w;
-            sacc += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-        }
-        sacc += __shfl_xor(sacc, 16, 64);
-        sacc += __shfl_xor(sacc, 32, 64);
-        rsum[i] = sacc;
-        if (WGN > 1 && lane < 16) s_red[0][wn][wm * WM + i * 16 + lane] = sacc;
-    }
-    if (WGN > 1) __syncthreads();
-    float mu[MB], rstd[MB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i) {
-        float s_ = rsum[i];
-        if (WGN > 1) {
-            s_ = 0.f;
-#pragma unroll
-            for (int q = 0; q < WGN; ++q) s_ += s_red[0][q][wm * WM + i * 16 + (lane & 15)];
-        }
-        mu[i] = s_ / (float)BN;
-        float sq = 0.f;
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j)
+            *reinterpret_cast<float4 *>(&smem[(wm * WM + i * 16 + (lane & 15)) * LDC + wn * WN + j * 16 + (lane >> 4) * 4]) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    __syncthreads();
+    constexpr int G = BN / 4, RPS = 256 / G;
+    const int cr = t / G, cc = (t % G) * 4;
+    const float4 bv = bias ? *reinterpret_cast<const float4 *>(bias + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g4 = *reinterpret_cast<const float4 *>(gamma + cc), b4 = *reinterpret_cast<const float4 *>(beta + cc);
+    auto gsum = [](float v) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[i][j][q] -= mu[i];
-                sq = fmaf(acc[i][j][q], acc[i][j][q], sq);
-            }
-        sq += __shfl_xor(sq, 16, 64);
-        sq += __shfl_xor(sq, 32, 64);
-        rstd[i] = sq;
-        if (WGN > 1 && lane < 16) s_red[1][wn][wm * WM + i * 16 + lane] = sq;
-    }
-    if (WGN > 1) __syncthreads();
-#pragma unroll
-    for (int i = 0; i < MB; ++i) {
-        float s_ = rstd[i];
-        if (WGN > 1) {
-            s_ = 0.f;
-#pragma unroll
-            for (int q = 0; q < WGN; ++q) s_ += s_red[1][q][wm * WM + i * 16 + (lane & 15)];
+        for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        return v;
+    };
+#pragma unroll 4
+    for (int p = 0; p < BM / RPS; ++p) {
+        const int r = row0 + p * RPS + cr, rr = min(r, R - 1);
+        float4 v = *reinterpret_cast<const float4 *>(&smem[(p * RPS + cr) * LDC + cc]);
+        v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+        if (pre) {
+            const float4 pv = *reinterpret_cast<const float4 *>(pre + (size_t)rr * BN + cc);
+            v.x += pv.x, v.y += pv.y, v.z += pv.z, v.w += pv.w;
         }
-        const float rs = rsqrtf(s_ / (float)BN + 1e-5f);
-        const int r = row0 + wm * WM + i * 16 + (lane & 15);
-        if (r >= R) continue;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int c = wn * WN + j * 16 + cg;
-            const float4 g4 = *reinterpret_cast<const float4 *>(gamma + c), b4 = *reinterpret_cast<const float4 *>(beta + c);
-            float4 o = make_float4(fmaf(acc[i][j][0] * rs, g4.x, b4.x), fmaf(acc[i][j][1] * rs, g4.y, b4.y),
-                                   fmaf(acc[i][j][2] * rs, g4.z, b4.z), fmaf(acc[i][j][3] * rs, g4.w, b4.w));
-            if (post) {
-                const float4 pv = *reinterpret_cast<const float4 *>(post + (size_t)r * BN + c);
-                o.x += pv.x, o.y += pv.y, o.z += pv.z, o.w += pv.w;
-            }
-            o.x = apply_act(o.x, act), o.y = apply_act(o.y, act), o.z = apply_act(o.z, act), o.w = apply_act(o.w, act);
-            *reinterpret_cast<float4 *>(out + (size_t)r * ldo + c) = o;
+        const float mu = gsum((v.x + v.y) + (v.z + v.w)) / (float)BN;
+        v.x -= mu, v.y -= mu, v.z -= mu, v.w -= mu;
+        const float rs = rsqrtf(gsum(fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)))) / (float)BN + 1e-5f);
+        float4 o = make_float4(fmaf(v.x * rs, g4.x, b4.x), fmaf(v.y * rs, g4.y, b4.y), fmaf(v.z * rs, g4.z, b4.z),
+                               fmaf(v.w * rs, g4.w, b4.w));
+        if (post) {
+            const float4 pv = *reinterpret_cast<const float4 *>(post + (size_t)rr * BN + cc);
+            o.x += pv.x, o.y += pv.y, o.z += pv.z, o.w += pv.w;
         }
+        o.x = apply_act(o.x, act), o.y = apply_act(o.y, act), o.z = apply_act(o.z, act), o.w = apply_act(o.w, act);
+        if (r < R) *reinterpret_cast<float4 *>(out + (size_t)r * ldo + cc) = o;
     }
 }
 

@@ -180,6 +180,16 @@ int dpm_linear_layernorm(const float *x, int ldx, const float *W, int ldw, const
                          const float *gamma, const float *beta, const float *post, float *out, int ldo, int R, int Cin,
                          int Cout, int act, dpm_stream_t stream);
 
+/* The same Conv1d(k=1)/nn.Linear contraction through the bf16 matrix pipe with fp32-level accuracy: each fp32 operand
+ * is split exactly into three bf16 terms and the product is formed from the six term pairs above 2^-24 of its magnitude
+ * (csrc/gemm_bf16x3.hip).  dpm_split_bf16x3 prepares a weight once: planes = 3 x n bf16 (hi | mid | lo);
+ * dpm_linear_bf16x3 takes it with row stride ldw and plane stride plane_stride (elements).  Cin % 32 == 0, Cout % 4 == 0;
+ * DPM_EUNSUPPORTED otherwise (run dpm_linear). */
+int dpm_split_bf16x3(const float *W, long long n, uint16_t *planes, dpm_stream_t stream);
+int dpm_linear_bf16x3(const float *x, int ldx, const uint16_t *w_planes, int ldw, long long plane_stride, const float *bias,
+                      const float *residual, int ldr, float *out, int ldo, int R, int Cin, int Cout, int act,
+                      dpm_stream_t stream);
+
 /* FeaturePropagation interpolation (network/encoder/pointnext.py:199-216): for each fine point
  * the 3 nearest valid coarse points (expanded-form distance), w_j = (1/max(d_j,1e-8))/sum;
  * out[b,n,:] = cat[fea1[b,n,:D1], sum_j w_j fea2[b,idx_j,:D2]].  S==1 broadcasts fea2. */
