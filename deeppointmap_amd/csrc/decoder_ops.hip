@@ -866,9 +866,11 @@ __global__ __launch_bounds__(KB) void corr_kabsch_kernel(
         }
         ge = block_sum(ge, s_cnt);
         if (ge > kk && !(vmin > 0.5f)) {  // a tie straddles the boundary and the 0.5 rule does not decide it
-            if (t == 0) {
-                if (kk * 64 <= n) vi_heap_select<true>(s_vi, 0, kk, n);
-                else vi_nth_element<true>(s_vi, n, kk - 1);
+            if (kk * 64 <= n) {
+                if (t == 0) vi_heap_select<true>(s_vi, 0, kk, n);
+            } else if (t < 64) {
+                LdsU16 sc = (LdsU16)(s_vi + 2 * k);  // scratch behind the 2k pairs: two lists of n 16-bit positions
+                vi_nth_element_wave<true>((LdsVI)s_vi, n, kk - 1, sc, sc + 2 * k);  // one wave, a partition round per pass
             }
             __syncthreads();
             for (int p = t; p < n; p += KB)
@@ -1158,8 +1160,13 @@ extern "C" int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int l
     DPM_CHECK_ARG(src_xyz && dst_xyz && conf && workspace && result && batch >= 1);
     DPM_CHECK_ARG(!offsets || (src_idx && dst_idx));
     DPM_CHECK_ARG(k >= 1 && ld_src >= 3 && ld_dst >= 3 && num_iter >= 1 && (!header || header_stride >= RES_HDR));
-    if (k > 8192) return DPM_EUNSUPPORTED;  // (value, index) of the 2k weights live in LDS: 16 B per pair
-    hipLaunchKernelGGL(corr_kabsch_kernel, dim3(batch), dim3(KB), sizeof(VI) * 2 * (size_t)k, (hipStream_t)stream, offsets, src_xyz, ld_src,
+    if (k > 6000) return DPM_EUNSUPPORTED;  // the 2k weights + replay scratch live in LDS: 24 B per pair
+    const size_t kabsch_lds = (sizeof(VI) + 4) * 2 * (size_t)k;
+    if (kabsch_lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)corr_kabsch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kabsch_lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(corr_kabsch_kernel, dim3(batch), dim3(KB), kabsch_lds, (hipStream_t)stream, offsets, src_xyz, ld_src,
                        stride_src, dst_xyz, ld_dst, stride_dst, src_idx, dst_idx, conf, k,
                        (float)(eps_offset * eps_offset), num_iter, (float)std_ratio, (float *)workspace, result, header,
                        header_stride);

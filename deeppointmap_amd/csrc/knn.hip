@@ -269,7 +269,8 @@ __device__ void nth_select_exact(const float *__restrict__ pts, int len, int N, 
         row[i].v = d, row[i].i = i;
     }
     wave_mem_sync();
-    if (lane == 0) vi_nth_element<false>(row, N, K - 1);
+    LdsU16 sc = (LdsU16)(row + N);  // scratch behind the row: two lists of N 16-bit positions
+    vi_nth_element_wave<false>((LdsVI)row, N, K - 1, sc, sc + N);  // the whole wave: a partition round per pass
     wave_mem_sync();
     if (lane < K) hv[lane] = row[lane].v, hi[lane] = row[lane].i;
     wave_mem_sync();
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
         if (s0 + j >= S) break;
         finish(c[j], pts, len, N, K, r2, (LdsF)s_d[w][j], (LdsI)s_i[w][j], (LdsF)s_td[w], (LdsI)s_ti[w],
                idx_all + ((size_t)b * S + (s0 + j)) * K, nullptr, nullptr, 0,
-               nth_rows ? s_nth + (size_t)w * N : nullptr);
+               nth_rows ? (VI *)((char *)s_nth + (size_t)w * N * (sizeof(VI) + 4)) : nullptr);
     }
 }
 
@@ -1132,7 +1133,7 @@ int launch_grid_search(const float *points, const int32_t *lengths, const float 
         hipLaunchKernelGGL(knn_tie_kernel, dim3(2048), dim3(TIE_T), 0, st, points, lengths, centers, N, S, K, r2,
                            w.tie_count, w.tie_rows, idx);
     else  // nth_element regime (N < 64 K <= 2048)
-        hipLaunchKernelGGL(knn_tie_nth_kernel, dim3(1024), dim3(64), sizeof(VI) * (size_t)N, st, points, lengths, centers, N,
+        hipLaunchKernelGGL(knn_tie_nth_kernel, dim3(1024), dim3(64), (sizeof(VI) + 4) * (size_t)N, st, points, lengths, centers, N,
                            S, K, r2, w.tie_count, w.tie_rows, idx);
     return dpm_launch_status();
 }
@@ -1154,7 +1155,7 @@ extern "C" int dpm_knn_hybrid_reuse(const float *points, const int32_t *lengths,
     }
     const int nth_rows = (long long)K * 64 > (long long)N;  // torch.topk's nth_element regime: tied rows are replayed
     hipLaunchKernelGGL(knn_hybrid_kernel, dim3(dpm_cdiv(S, WPB * CPW), B), dim3(WPB * 64),
-                       nth_rows ? sizeof(VI) * (size_t)WPB * N : 0, st, points, lengths, centers, N, S, K, r2, idx, reuse_idx,
+                       nth_rows ? (sizeof(VI) + 4) * (size_t)WPB * N : 0, st, points, lengths, centers, N, S, K, r2, idx, reuse_idx,
                        center_src, nth_rows);
     return dpm_launch_status();
 }
