@@ -48,7 +48,7 @@ def pmc_traffic_bytes(frames_per_launch: int):
         if j.get("frames_per_launch") != frames_per_launch:
             return None
         tot = 0
-        for k in ("fps_bucket_kernel", "fps_bucket_sort_kernel"):
+        for k in ("fps_bucket_kernel", "fps_tree_sort_kernel"):
             tot += (2 * j[k]["FETCH_SIZE_KB"] + j[k]["WRITE_SIZE_KB"]) * 1024
         return int(tot)
     except Exception:
@@ -333,7 +333,7 @@ def main():
                        "parallelism": f"frame-sharded x{world}, one RCCL gather of descriptors+edges per step",
                        "pipeline": "none" if args.no_pipeline else "HIP-stream pipeline: geometry (staging+FPS chain) of batches i, i-1 on two alternating streams | features of batch i-2 | registration+information matrices of batch i-3",
                        "weights": "procedural (deeppointmap_amd/weights.py)"},
-            "roofline": {"kernel": "fps_bucket_sort_kernel+fps_bucket_kernel (stage-0 farthest point sampling)",
+            "roofline": {"kernel": "fps_tree_sort_kernel<buckets>+fps_bucket_kernel (stage-0 farthest point sampling, Sort-Tile-Recursive packing)",
                          "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK / 1e9), 6), "traffic": pmc_traffic_bytes(F),
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -345,7 +345,7 @@ def main():
                                  "in flight on alternating streams; "
                                  "FPS is a chain of 4095 dependent argmax rounds per frame, one CU per frame: latency-"
                                  "bound by construction (us_per_round is the figure that matters); traffic > algorithmic "
-                                 "bytes because each round re-reads the ~12 buckets the new point can change -- the "
+                                 "bytes because each round re-reads the ~7 buckets the new point can change -- the "
                                  "reference's loop re-reads the WHOLE frame every round (4095 x 65536 x 16 B = 4.3 GB "
                                  "per frame, 275 GB per launch), the bucket pruning cuts that ~85x; see DESIGN.md"},
         }

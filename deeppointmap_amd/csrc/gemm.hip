@@ -191,8 +191,10 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const float *__restrict__ 
     constexpr int KT = 32, LDS_LD = KT + 2, LPR = KT / 4, RPP = 256 / LPR;
     constexpr int WM = BM / WGM, WN = BN / WGN, MB = WM / 16, NB = WN / 16, PX = BM / RPP, PW = BN / RPP;
     static_assert(WGM * WGN == 4 && MB >= 1 && NB >= 1 && PX >= 1 && PW >= 1, "tile shape");
-    constexpr int LDC = BN + 4;  // row stride of the staged output tile
-    constexpr int SMEM = (BM + BN) * LDS_LD > BM * LDC ? (BM + BN) * LDS_LD : BM * LDC;
+    constexpr int LDC = BN + 4;                  // row stride of the staged output tile
+    constexpr int CH = BN >= 128 ? 32 : BM;       // rows staged at a time
+    static_assert(CH % 16 == 0 && BM % CH == 0 && CH % (256 / (BN / 4)) == 0 && CH * LDC <= (BM + BN) * LDS_LD, "epilogue staging");
+    constexpr int SMEM = (BM + BN) * LDS_LD;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float (*Xs)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(smem);
     float (*Ws)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(smem + BM * LDS_LD);
@@ -250,16 +252,10 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const float *__restrict__ 
         }
         __syncthreads();
     }
-    // ---- epilogue: the tile goes through LDS (the operand tiles are dead after the loop's last barrier) and is then
-    //      walked ROW-wise: G = BN / 4 lanes hold one row (a float4 each), so bias / pre / post / out are whole-row
-    //      accesses and the two LayerNorm sums are lane-group reductions -- the arithmetic of layernorm_vec_kernel
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            *reinterpret_cast<float4 *>(&smem[(wm * WM + i * 16 + (lane & 15)) * LDC + wn * WN + j * 16 + (lane >> 4) * 4]) =
-                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    __syncthreads();
+    // ---- epilogue: the tile goes through LDS (the operand tiles are dead after the loop's last barrier), CH rows at a
+    //      time so that it fits the operand tiles' footprint, and is walked ROW-wise: G = BN / 4 lanes hold one row (a
+    //      float4 each), so bias / pre / post / out are whole-row accesses and the two LayerNorm sums are lane-group
+    //      reductions -- the arithmetic of layernorm_vec_kernel
     constexpr int G = BN / 4, RPS = 256 / G;
     const int cr = t / G, cc = (t % G) * 4;
     const float4 bv = bias ? *reinterpret_cast<const float4 *>(bias + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -269,26 +265,40 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const float *__restrict__ 
         for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         return v;
     };
+#pragma unroll
+    for (int ch = 0; ch < BM / CH; ++ch) {
+        if (ch) __syncthreads();  // the previous chunk has been read
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int rl = wm * WM + i * 16;  // first tile row of this 16-row block (wave-uniform)
+            if (rl / CH != ch) continue;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                *reinterpret_cast<float4 *>(&smem[(rl - ch * CH + (lane & 15)) * LDC + wn * WN + j * 16 + (lane >> 4) * 4]) =
+                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+        __syncthreads();
 #pragma unroll 4
-    for (int p = 0; p < BM / RPS; ++p) {
-        const int r = row0 + p * RPS + cr, rr = min(r, R - 1);
-        float4 v = *reinterpret_cast<const float4 *>(&smem[(p * RPS + cr) * LDC + cc]);
-        v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
-        if (pre) {
-            const float4 pv = *reinterpret_cast<const float4 *>(pre + (size_t)rr * BN + cc);
-            v.x += pv.x, v.y += pv.y, v.z += pv.z, v.w += pv.w;
+        for (int p = 0; p < CH / RPS; ++p) {
+            const int r = row0 + ch * CH + p * RPS + cr, rr = min(r, R - 1);
+            float4 v = *reinterpret_cast<const float4 *>(&smem[(p * RPS + cr) * LDC + cc]);
+            v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+            if (pre) {
+                const float4 pv = *reinterpret_cast<const float4 *>(pre + (size_t)rr * BN + cc);
+                v.x += pv.x, v.y += pv.y, v.z += pv.z, v.w += pv.w;
+            }
+            const float mu = gsum((v.x + v.y) + (v.z + v.w)) / (float)BN;
+            v.x -= mu, v.y -= mu, v.z -= mu, v.w -= mu;
+            const float rs = rsqrtf(gsum(fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)))) / (float)BN + 1e-5f);
+            float4 o = make_float4(fmaf(v.x * rs, g4.x, b4.x), fmaf(v.y * rs, g4.y, b4.y), fmaf(v.z * rs, g4.z, b4.z),
+                                   fmaf(v.w * rs, g4.w, b4.w));
+            if (post) {
+                const float4 pv = *reinterpret_cast<const float4 *>(post + (size_t)rr * BN + cc);
+                o.x += pv.x, o.y += pv.y, o.z += pv.z, o.w += pv.w;
+            }
+            o.x = apply_act(o.x, act), o.y = apply_act(o.y, act), o.z = apply_act(o.z, act), o.w = apply_act(o.w, act);
+            if (r < R) *reinterpret_cast<float4 *>(out + (size_t)r * ldo + cc) = o;
         }
-        const float mu = gsum((v.x + v.y) + (v.z + v.w)) / (float)BN;
-        v.x -= mu, v.y -= mu, v.z -= mu, v.w -= mu;
-        const float rs = rsqrtf(gsum(fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)))) / (float)BN + 1e-5f);
-        float4 o = make_float4(fmaf(v.x * rs, g4.x, b4.x), fmaf(v.y * rs, g4.y, b4.y), fmaf(v.z * rs, g4.z, b4.z),
-                               fmaf(v.w * rs, g4.w, b4.w));
-        if (post) {
-            const float4 pv = *reinterpret_cast<const float4 *>(post + (size_t)rr * BN + cc);
-            o.x += pv.x, o.y += pv.y, o.z += pv.z, o.w += pv.w;
-        }
-        o.x = apply_act(o.x, act), o.y = apply_act(o.y, act), o.z = apply_act(o.z, act), o.w = apply_act(o.w, act);
-        if (r < R) *reinterpret_cast<float4 *>(out + (size_t)r * ldo + cc) = o;
     }
 }
 
