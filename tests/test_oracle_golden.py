@@ -58,7 +58,7 @@ def test_encoder_reduced_per_stage(fixture, cfg_reduced, sd_enc):
     assert np.array_equal(coor.numpy(), g["coor"]) and np.array_equal(mask.numpy(), g["mask"])
     for k, v in g.items():
         if k.endswith(".idx"):
-            assert idx_rows_equal_as_sets(tr[k].numpy(), v).mean() > 0.999, k
+            assert idx_rows_equal_as_sets(tr[k].numpy(), v).all(), k
         elif k.endswith(".out"):
             np.testing.assert_allclose(tr[k].numpy(), v, rtol=0, atol=2e-4, err_msg=k)
     np.testing.assert_allclose(fea.numpy(), g["fea"], rtol=0, atol=2e-4)
