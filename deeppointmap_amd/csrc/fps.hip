@@ -445,7 +445,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_spec_kernel(const float *__rest
                                                              float *__restrict__ closest_all,
                                                              int32_t *__restrict__ idx_all,
                                                              float *__restrict__ new_xyz_all,
-                                                             int32_t *__restrict__ new_len) {
+                                                             int32_t *__restrict__ new_len, int slots) {
     constexpr int NW = FB / 64;
     constexpr int OB = 2048;   // picks buffered in LDS between flushes to global memory
     static_assert(NW * KC <= 64, "one lane per exchanged candidate");
@@ -458,12 +458,14 @@ __global__ __launch_bounds__(FB) void fps_bucket_spec_kernel(const float *__rest
 
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float *xyz = xyz_all + (size_t)b * N * 3;
-    const float4 *pts = pts_all + (size_t)b * N;
-    float *closest = closest_all + (size_t)b * N;
+    const size_t fstride = slots ? (size_t)slots : (size_t)N;  // slots != 0: the Sort-Tile-Recursive packing (see fps_bucket_kernel)
+    const float4 *pts = pts_all + (size_t)b * fstride;
+    float *closest = closest_all + (size_t)b * fstride;
     int32_t *idx = idx_all + (size_t)b * K;
     float *new_xyz = new_xyz_all + (size_t)b * K * 3;
-    const int len = min(max(lengths[b], 0), N);
-    const int kn = min(len, K);
+    const int true_len = min(max(lengths[b], 0), N);
+    const int kn = min(true_len, K);
+    const int len = slots ? (true_len > 0 ? slots : 0) : true_len;
     const int nb = (len + 63) >> 6;
     const bool mine = lane * NW + w < nb;
 
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_spec_kernel(const float *__rest
         float x0 = __builtin_inff(), y0 = x0, z0 = x0, x1 = -x0, y1 = -x0, z1 = -x0;
         if (q < len) {
             const float4 p = pts[q];
-            x0 = x1 = p.x, y0 = y1 = p.y, z0 = z1 = p.z;
+            if (__float_as_int(p.w) != 0x7fffffff) x0 = x1 = p.x, y0 = y1 = p.y, z0 = z1 = p.z;
         }
         x0 = -wave_max_dpp(-x0), y0 = -wave_max_dpp(-y0), z0 = -wave_max_dpp(-z0);
         x1 = wave_max_dpp(x1), y1 = wave_max_dpp(y1), z1 = wave_max_dpp(z1);
@@ -752,10 +754,10 @@ extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N
                           dpm_stream_t stream) {
     DPM_CHECK_ARG(xyz && lengths && idx && new_xyz && new_lengths);
     DPM_CHECK_ARG(B >= 1 && N >= 1 && K >= 1);
-    DPM_CHECK_ARG(algo >= 0 && algo <= 5);
+    DPM_CHECK_ARG(algo >= 0 && algo <= 7);
     hipStream_t st = (hipStream_t)stream;
     if (algo == 0) algo = (N > 16384 && N <= 65536) ? 5 : (N > 16384 ? 2 : 1);  // 5: shortest chain (1.05 us per pick); 4: fewest instructions
-    if (algo == 5) {  // the bucket kernel over the Sort-Tile-Recursive packing of fps_tree.hip (fewer buckets survive a round)
+    if (algo >= 5) {  // (6 / 7: the speculative multi-pick kernel, two / three picks per round) the bucket kernel over the Sort-Tile-Recursive packing of fps_tree.hip (fewer buckets survive a round)
         DPM_CHECK_ARG(workspace != nullptr);
         if (N <= 16384 || N > 65536) return DPM_EUNSUPPORTED;
         const int slots = 65536;
@@ -765,8 +767,15 @@ extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N
         float4 *tmp = (float4 *)(((uintptr_t)(closest + (size_t)B * slots) + 255) & ~(uintptr_t)255);
         const int rc = dpm_fps_str_bucket_sort(xyz, lengths, B, N, pts, closest, tmp, st);
         if (rc != DPM_OK) return rc;
-        hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
-                           new_lengths, slots);
+        if (algo == 6)
+            hipLaunchKernelGGL((fps_bucket_spec_kernel<2, 4>), dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
+                               new_lengths, slots);
+        else if (algo == 7)
+            hipLaunchKernelGGL((fps_bucket_spec_kernel<3, 4>), dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
+                               new_lengths, slots);
+        else
+            hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
+                               new_lengths, slots);
         return dpm_launch_status();
     }
     if (algo == 4) {  // one wave per frame over a two-level box tree (fps_tree.hip)
@@ -786,7 +795,7 @@ extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N
         hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, pts, closest);
         if (algo == 3)  // experimental: two picks per round (see the kernel's header); exact, not yet faster
             hipLaunchKernelGGL((fps_bucket_spec_kernel<2, 4>), dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx,
-                               new_xyz, new_lengths);
+                               new_xyz, new_lengths, 0);
         else
             hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx,
                                new_xyz, new_lengths, 0);

@@ -7,7 +7,7 @@ pts, _ = synthetic.frames(64, 65536)
 xyz = pts.transpose(1, 2).contiguous().cuda()
 lens = torch.full((64,), 65536, dtype=torch.int32, device="cuda")
 ref = None
-for algo in (2, 3, 4, 5):
+for algo in (2, 3, 4, 5, 6, 7):
     for _ in range(2):
         out = ops.fps(xyz, lens, 4096, algo=algo)
     torch.cuda.synchronize()
