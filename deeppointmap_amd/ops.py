@@ -382,6 +382,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int
 
 
 FUSED_LN_WIDTHS = (32, 64, 128, 256)  # dpm_linear_layernorm: the output row must fit one workgroup's tile
+FUSED_LN_MIN_ROWS = 16384             # ... and there must be a workgroup (64 rows) for every compute unit
 
 
 def linear_layernorm(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
@@ -391,8 +392,11 @@ def linear_layernorm(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tens
     to the summation order of the row statistics)."""
     Cout, Cin = W.shape[0], W.shape[1]
     x2 = x.reshape(-1, x.shape[-1])
-    if (Cout in FUSED_LN_WIDTHS and W.is_contiguous() and x2.is_contiguous() and x.dtype == torch.float32 and Cin % 4 == 0
-            and os.environ.get("DPM_NO_FUSED_LN") != "1"):
+    # the fused kernel owns whole output rows (64 rows per workgroup): below FUSED_LN_MIN_ROWS it leaves most of the 256
+    # compute units idle and the two-kernel form is 1.5-2.8x faster (scripts/gemm_ln_shapes.py: 4096 x 1024 -> 256 takes
+    # 86 us fused, 31 us as GEMM + LayerNorm)
+    if (Cout in FUSED_LN_WIDTHS and x2.shape[0] >= FUSED_LN_MIN_ROWS and W.is_contiguous() and x2.is_contiguous()
+            and x.dtype == torch.float32 and Cin % 4 == 0 and os.environ.get("DPM_NO_FUSED_LN") != "1"):
         _chk(W, torch.float32, "W")
         out = torch.empty(*x.shape[:-1], Cout, device=x.device, dtype=torch.float32)
         for n, t in (("pre", pre), ("post", post)):

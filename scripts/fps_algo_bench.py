@@ -3,9 +3,10 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deeppointmap_amd import synthetic, ops
-pts, _ = synthetic.frames(64, 65536)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64  # 1: the latency of a single frame
+pts, _ = synthetic.frames(B, 65536)
 xyz = pts.transpose(1, 2).contiguous().cuda()
-lens = torch.full((64,), 65536, dtype=torch.int32, device="cuda")
+lens = torch.full((B,), 65536, dtype=torch.int32, device="cuda")
 ref = None
 for algo in (2, 3, 4, 5, 6, 7):
     for _ in range(2):
@@ -19,4 +20,4 @@ for algo in (2, 3, 4, 5, 6, 7):
     same = "" if ref is None else f"  identical to algo 2: {torch.equal(out[0], ref)}"
     ref = out[0] if ref is None else ref
     ms = e0.elapsed_time(e1) / 3
-    print(f"algo {algo}: {ms:.3f} ms for 64 frames, {ms * 1e3 / 4095:.3f} us per pick{same}")
+    print(f"algo {algo}: {ms:.3f} ms for {B} frames, {ms * 1e3 / 4095:.3f} us per pick{same}")

@@ -271,6 +271,30 @@ def test_linear_layernorm_interp_vs_torch(ops):
         torch.testing.assert_close(y, want, rtol=1e-5, atol=2e-5)
 
 
+def test_fused_linear_layernorm_kernel_vs_torch(ops, monkeypatch):
+    """dpm_linear_layernorm (GEMM with the LayerNorm in its epilogue) at every fused width, ragged row counts, with and
+    without the pre / post residuals -- the row threshold of ops.linear_layernorm lifted so that small inputs reach it --
+    and the two-kernel form the wrapper takes below the threshold, both against an fp64 reference."""
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    for min_rows in (0, 1 << 30):
+        monkeypatch.setattr(ops, "FUSED_LN_MIN_ROWS", min_rows)
+        for R, Cin, Cout, relu, use_pre, use_post in [(1000, 64, 32, True, False, False), (130, 128, 64, False, True, False),
+                                                     (257, 256, 128, True, True, True), (4096, 1024, 256, True, False, True),
+                                                     (65, 32, 256, False, False, False), (20000, 256, 256, True, True, False)]:
+            x = torch.randn(R, Cin, device=DEV, generator=gen)
+            W = torch.randn(Cout, Cin, device=DEV, generator=gen) / Cin ** 0.5
+            b, gm, bt = (torch.randn(Cout, device=DEV, generator=gen) for _ in range(3))
+            pre = torch.randn(R, Cout, device=DEV, generator=gen) if use_pre else None
+            post = torch.randn(R, Cout, device=DEV, generator=gen) if use_post else None
+            y = ops.linear_layernorm(x, W, b, gm, bt, act=ops.ACT_RELU if relu else ops.ACT_NONE, pre=pre, post=post)
+            z = x.double() @ W.double().t() + b.double()
+            z = z + pre.double() if use_pre else z
+            z = torch.nn.functional.layer_norm(z, (Cout,), gm.double(), bt.double(), 1e-5)
+            z = z + post.double() if use_post else z
+            want = (torch.relu(z) if relu else z).float()
+            torch.testing.assert_close(y, want, rtol=2e-5, atol=5e-5)
+
+
 def test_linear_large_tiles_vs_torch(ops):
     """The shapes that take the 128x128 persistent kernel (K >= 1024, >= 512 output tiles) and the 64x64 kernel's
     staged epilogue with ragged edges, against an fp64 product."""
