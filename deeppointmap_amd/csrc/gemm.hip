@@ -260,9 +260,12 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const float *__restrict__ 
     const int cr = t / G, cc = (t % G) * 4;
     const float4 bv = bias ? *reinterpret_cast<const float4 *>(bias + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 g4 = *reinterpret_cast<const float4 *>(gamma + cc), b4 = *reinterpret_cast<const float4 *>(beta + cc);
+    // neighbours first, like layernorm_vec_kernel's group_sum: the same association of the additions, so this kernel and
+    // the GEMM kernel followed by the LayerNorm kernel give bit-identical rows (ops.linear_layernorm picks between them
+    // by row count, and a frame's result must not depend on the batch it travels in)
     auto gsum = [](float v) {
 #pragma unroll
-        for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, 64);
         return v;
     };
 #pragma unroll

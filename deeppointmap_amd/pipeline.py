@@ -160,7 +160,8 @@ class HotPath:
     #   stage F (caller's stream): features of batch i-depth -- kNN, grouped MLPs, GEMMs -> descriptors
     #   stage R (stream B): registration of the batch before that -- decoder + information matrices
     # The stages touch disjoint data, so they overlap on the chip; flush() drains the pipe, so K submits + flush
-    # contain exactly K batches of work.
+    # contain exactly K batches of work.  A finished batch is handed out one submit after its registration was enqueued
+    # (`_hand_out`), so the caller's stream never waits for work that has only just been queued.
     @torch.no_grad()
     def submit(self, points: torch.Tensor, padding: torch.Tensor, pcd_m: Optional[torch.Tensor]):
         """Enqueue a batch; returns the (desc, table) of an earlier batch once the pipe is full (None while it
@@ -254,8 +255,18 @@ class HotPath:
             _, table = self.register(desc, pcd_m, pairs, materialize=False, pair_index=index, grids=grids, halo_pcd=halo_pcd)
             done = sb.record_event()
         table.record_stream(main)
-        main.wait_event(done)  # the caller's stream sees finished results (e.g. for the RCCL gather)
-        return desc[:F], table
+        # Results are handed out ONE call later (`_hand_out`): the caller's stream -- which is also the feature stage's --
+        # then waits for a registration that finished long ago instead of stalling the next batch's features behind the
+        # one that has just been enqueued (the stages would run in lock-step, each step ending with one of them alone).
+        out, self._pending["out"] = self._pending.get("out"), (desc[:F], table, done)
+        return self._hand_out(out)
+
+    def _hand_out(self, out):
+        if out is None:
+            return None
+        desc, table, done = out
+        torch.cuda.current_stream(self.encoder.device).wait_event(done)  # the caller's stream sees finished results
+        return desc, table
 
     @torch.no_grad()
     def flush(self):
@@ -271,5 +282,10 @@ class HotPath:
                 out.append(r)
         if self._pending["reg"] is not None:
             reg, self._pending["reg"] = self._pending["reg"], None
-            out.append(self._register_on_b(reg))
+            r = self._register_on_b(reg)
+            if r is not None:
+                out.append(r)
+        last, self._pending["out"] = self._pending.get("out"), None
+        if last is not None:
+            out.append(self._hand_out(last))
         return out
