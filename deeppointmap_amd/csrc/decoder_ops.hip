@@ -80,12 +80,15 @@ __device__ __forceinline__ float rows4_sum(float v) {
 // end -- and it ends up with 2 x 4 consecutive output channels of that query: two 16-byte stores.
 // QT = query groups of 16 per wave: with two, every K / V fragment read from LDS feeds two MFMAs and a block covers
 // 128 queries, so the fetch of the first K / V tile (a block lives for only N / 64 tiles) is paid half as often.
-template <bool VEC, int QT>
+// MASK: key_mask (batch, N) bytes, non-zero = the key is padding (nn.MultiheadAttention's key_padding_mask): its score is
+// -inf like a key beyond N.  A sequence whose keys are ALL masked gives NaN rows, as in the reference.
+template <bool VEC, int QT, bool MASK = false>
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
                                                         const float *__restrict__ Kp, int ldk, long long sk,
                                                         const float *__restrict__ V, int ldv, long long sv,
                                                         float *__restrict__ O, int ldo, long long so, int M,
-                                                        int N, float scale, int kv_shift) {
+                                                        int N, float scale, int kv_shift,
+                                                        const uint8_t *__restrict__ key_mask = nullptr) {
     constexpr int TK = 64;                 // keys per tile
     __shared__ __attribute__((aligned(16))) float Ks[TK][HD + 2];  // A operand of S^T: A[i=key][k=d] = Ks[key][d]
     // A operand of O^T: A[i=d][k=key] = Vs[key][d].  Row stride 36: 16-byte aligned rows, and the four lane groups of
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     if (bk >= (int)gridDim.z) bk -= (int)gridDim.z;
     const float *Kb = Kp + (size_t)bk * sk + h * HD;
     const float *Vb = V + (size_t)bk * sv + h * HD;
+    const uint8_t *km = MASK ? key_mask + (size_t)bk * N : nullptr;
 
     // Q^T fragments (B operand: B[k=lane>>4][j=lane&15] = Q[query lane&15][d = 4 ks + (lane>>4)]), pre-scaled
     float qa[QT][HD / 4];
@@ -173,18 +177,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (n0 + j * 16 + g * 4 + q >= N) sacc[u][j][q] = -__builtin_inff();
+                    const int n = n0 + j * 16 + g * 4 + q;
+                    if (n >= N || (MASK && km[min(n, N - 1)])) sacc[u][j][q] = -__builtin_inff();
                     mx = fmaxf(mx, sacc[u][j][q]);
                 }
             mx = rows4_max(mx);
             const float nm = fmaxf(mrow[u], mx);
-            const float corr = __expf(mrow[u] - nm);  // exp(-inf) = 0 on the first tile
+            // exp(-inf) = 0 on the first tile; with masks a whole tile may be padding while the running max is still -inf:
+            // nothing has been accumulated then, the factor is irrelevant (and -inf - -inf would be NaN)
+            const float corr = (MASK && nm == -__builtin_inff()) ? 1.f : __expf(mrow[u] - nm);
             float ps = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float pv = __expf(sacc[u][j][q] - nm);
+                    const float pv = (MASK && nm == -__builtin_inff()) ? 0.f : __expf(sacc[u][j][q] - nm);
                     sacc[u][j][q] = pv;
                     ps += pv;
                 }
@@ -1051,9 +1058,10 @@ extern "C" int dpm_posemb(const float *xyz, int ld, const float *dim_t, int F, i
     return dpm_launch_status();
 }
 
-extern "C" int dpm_attention_shifted(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
-                                     const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B,
-                                     int M, int N, int heads, int head_dim, int kv_shift, dpm_stream_t stream) {
+extern "C" int dpm_attention_masked(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                                    const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B,
+                                    int M, int N, int heads, int head_dim, int kv_shift, const uint8_t *key_mask,
+                                    dpm_stream_t stream) {
     DPM_CHECK_ARG(Q && K && V && out && B >= 1 && M >= 1 && N >= 1 && heads >= 1 && kv_shift >= 0 && kv_shift < B);
     if (head_dim != HD) return DPM_EUNSUPPORTED;
     const bool vec = ldk % 4 == 0 && ldv % 4 == 0 && sk % 4 == 0 && sv % 4 == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0 &&
@@ -1065,12 +1073,28 @@ extern "C" int dpm_attention_shifted(const float *Q, int ldq, long long sq, cons
     hipLaunchKernelGGL((attention_kernel<V, QT>), dim3(dpm_cdiv(M, 64 * QT), heads, B), dim3(256), 0, (hipStream_t)stream, \
                        Q, ldq, sq, K, ldk, sk, V_, ldv, sv, out, ldo, so, M, N, scale, kv_shift)
     const float *V_ = V;
+    if (key_mask) {
+        if (vec)
+            hipLaunchKernelGGL((attention_kernel<true, 1, true>), dim3(dpm_cdiv(M, 64), heads, B), dim3(256), 0, (hipStream_t)stream,
+                               Q, ldq, sq, K, ldk, sk, V, ldv, sv, out, ldo, so, M, N, scale, kv_shift, key_mask);
+        else
+            hipLaunchKernelGGL((attention_kernel<false, 1, true>), dim3(dpm_cdiv(M, 64), heads, B), dim3(256), 0, (hipStream_t)stream,
+                               Q, ldq, sq, K, ldk, sk, V, ldv, sv, out, ldo, so, M, N, scale, kv_shift, key_mask);
+        return dpm_launch_status();
+    }
     if (vec && wide) DPM_ATT(true, 2);
     else if (vec) DPM_ATT(true, 1);
     else if (wide) DPM_ATT(false, 2);
     else DPM_ATT(false, 1);
 #undef DPM_ATT
     return dpm_launch_status();
+}
+
+extern "C" int dpm_attention_shifted(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                                     const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B,
+                                     int M, int N, int heads, int head_dim, int kv_shift, dpm_stream_t stream) {
+    return dpm_attention_masked(Q, ldq, sq, K, ldk, sk, V, ldv, sv, out, ldo, so, B, M, N, heads, head_dim, kv_shift, nullptr,
+                                stream);
 }
 
 extern "C" int dpm_attention(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,

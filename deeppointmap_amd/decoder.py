@@ -7,8 +7,9 @@ contracts:
      (decoder.py:91-127); 3-D inputs give the batched return shapes of the reference.
   * `loop_detection_forward(src (C,131,M), dst (C,131,N)) -> (C,)` (decoder.py:129-143).
   * `forward` is training-only in the reference (decoder.py:34-38) and raises here as it does there.
-Every inference call site of the reference passes no padding masks (odometry.py:108-110,
-mapping.py:153-155, loop_closure.py:170-174,239-242); masks are therefore rejected explicitly.
+Padding masks ((B,M) / (B,N) bool, True = padding) are the key_padding_mask of every attention block and nothing else
+(descriptor_attention.py:33-42), as in the reference; no inference call site of the reference passes any
+(odometry.py:108-110, mapping.py:153-155, loop_closure.py:170-174,239-242).
 
 All arithmetic runs in libdpm_hip.so; the module is re-entrant (no per-call state on self), so
 the three SLAM threads of the reference can share one instance (system/core.py:55-57).
@@ -71,40 +72,52 @@ class Decoder(ParamTree):
             raise ValueError(f"descriptor must have {self.in_channel + 3} rows, got {C}")
         return ops.to_channel_first(d).view(B * M, C), B, M
 
-    def _self_attn(self, pre: str, xp, B, M, norm: str = None, post=None):
-        """x + MHA(x, x, x) (norm None) or LN_norm(x + MHA(x, x, x)) + post, the out-projection carrying the norm"""
+    def _self_attn(self, pre: str, xp, B, M, norm: str = None, post=None, mask=None):
+        """x + MHA(x, x, x) (norm None) or LN_norm(x + MHA(x, x, x)) + post, the out-projection carrying the norm;
+        mask (B,M) uint8 = key_padding_mask"""
         E = self.model_channel
         qkv = ops.linear(xp, self.p(pre + ".in_proj_weight"), self.p(pre + ".in_proj_bias"))
-        a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, M, M, HEADS)
+        a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, M, M, HEADS, key_mask=mask)
         if norm is not None:
             return self._lin_ln(pre + ".out_proj", norm, a, xp, post)
         return ops.linear(a, self.p(pre + ".out_proj.weight"), self.p(pre + ".out_proj.bias"), residual=xp)
 
-    def _cross_attn(self, pre: str, xq, xkv, B, M, N, norm: str = None):
+    def _cross_attn(self, pre: str, xq, xkv, B, M, N, norm: str = None, mask=None):
+        """mask (B,N) uint8: key_padding_mask of the key / value side"""
         E = self.model_channel
         w, b = self.p(pre + ".in_proj_weight"), self.p(pre + ".in_proj_bias")
         q = ops.linear(xq, w[:E], b[:E])
         kv = ops.linear(xkv, w[E:], b[E:])
-        a = ops.attention(q, kv[:, :E], kv[:, E:], B, M, N, HEADS)
+        a = ops.attention(q, kv[:, :E], kv[:, E:], B, M, N, HEADS, key_mask=mask)
         if norm is not None:
             return self._lin_ln(pre + ".out_proj", norm, a, xq)
         return ops.linear(a, self.p(pre + ".out_proj.weight"), self.p(pre + ".out_proj.bias"), residual=xq)
 
     def _descriptor_attention_forward(self, src_descriptor, dst_descriptor, src_padding_mask=None,
                                       dst_padding_mask=None):
-        """-> (x (B*M,256), xyz_s (B*M,3) view, y (B*N,256), xyz_d view, B, M, N)   decoder.py:145-162."""
-        if src_padding_mask is not None or dst_padding_mask is not None:
-            raise NotImplementedError("padding masks are not used by any inference call site of the reference "
-                                      "and are not implemented")
+        """-> (x (B*M,256), xyz_s (B*M,3) view, y (B*N,256), xyz_d view, B, M, N)   decoder.py:145-162.
+        The padding masks (B,M) / (B,N) bool, True = padding, are the attention blocks' key_padding_mask and nothing else
+        (descriptor_attention.py:33-42): padded tokens are still projected, normalised and offered to the pairing, as
+        in the reference."""
         dev = self.device
         ts, B, M = self._stage(src_descriptor, dev)
         td, B2, N = self._stage(dst_descriptor, dev)
         if B != B2:
             raise ValueError("src and dst batch sizes differ")
+        ms = md = None
+        if src_padding_mask is not None or dst_padding_mask is not None:
+            def as_mask(m, L):
+                if m is None:
+                    return torch.zeros(B, L, dtype=torch.uint8, device=dev)
+                m = m.to(dev)
+                if tuple(m.shape) != (B, L) or m.dtype != torch.bool:
+                    raise ValueError(f"padding mask must be a bool tensor of shape ({B}, {L})")
+                return m.contiguous().view(torch.uint8)
+            ms, md = as_mask(src_padding_mask, M), as_mask(dst_padding_mask, N)
         C, E = self.in_channel, self.model_channel
         xyz_s, xyz_d = ts[:, C:C + 3], td[:, C:C + 3]
         if M == N:
-            x, y = self._attention_layers_joint(ts, td, B, M)
+            x, y = self._attention_layers_joint(ts, td, B, M, mask=None if ms is None else torch.cat([ms, md]))
             return x, xyz_s, y, xyz_d, B, M, N
         ps, pd = ops.posemb(xyz_s, self._dimt(dev), E), ops.posemb(xyz_d, self._dimt(dev), E)
         # x + pos enters every layer: fold the addition into the producing kernel's epilogue
@@ -114,11 +127,11 @@ class Decoder(ParamTree):
             pre = f"descriptor_attention.{l}"
             last = l == self.attention_layers - 1
             # self attention: LN1(x + attn(x)), then + pos for the cross block   (descriptor_attention.py:31-40)
-            x1 = self._self_attn(pre + ".self_attn", xp, B, M, norm=pre + ".norm1", post=ps)
-            y1 = self._self_attn(pre + ".self_attn", yp, B, N, norm=pre + ".norm1", post=pd)
+            x1 = self._self_attn(pre + ".self_attn", xp, B, M, norm=pre + ".norm1", post=ps, mask=ms)
+            y1 = self._self_attn(pre + ".self_attn", yp, B, N, norm=pre + ".norm1", post=pd, mask=md)
             # cross attention, both directions read the pre-update tensors      (descriptor_attention.py:41-44)
-            x2 = self._cross_attn(pre + ".cross_attn", x1, y1, B, M, N, norm=pre + ".norm2")
-            y2 = self._cross_attn(pre + ".cross_attn", y1, x1, B, N, M, norm=pre + ".norm2")
+            x2 = self._cross_attn(pre + ".cross_attn", x1, y1, B, M, N, norm=pre + ".norm2", mask=md)
+            y2 = self._cross_attn(pre + ".cross_attn", y1, x1, B, N, M, norm=pre + ".norm2", mask=ms)
             # MLP: LN3(mlp(x) + x); the next layer starts with + pos            (descriptor_attention.py:47-48)
             xp = self._lin_ln(pre + ".mlp.2", pre + ".norm3", self._lin(pre + ".mlp.0", x2, ops.ACT_RELU), x2,
                               None if last else ps)
@@ -126,12 +139,14 @@ class Decoder(ParamTree):
                               None if last else pd)
         return xp, xyz_s, yp, xyz_d, B, M, N
 
-    def _attention_layers_joint(self, ts, td, B, M, frames=None):
+    def _attention_layers_joint(self, ts, td, B, M, frames=None, mask=None):
         """Same arithmetic as the two-sided loop above for M == N, with the source and target tokens stacked into one
         (2*B*M)-row matrix: the layers share their weights between the two sides (descriptor_attention.py:31-48), so
         every projection / LayerNorm / MLP is ONE launch over all rows, self attention is one launch over 2B
         sequences, and only cross attention needs one launch per direction (queries of one half, keys/values of the
         other).  Row-wise kernels give bit-identical rows whatever the row count, so the results equal the split path.
+
+        mask (2B,M) uint8: key_padding_mask of the stacked sequences (sources then targets).
 
         frames = (tu (U*M,131), sidx, didx): the pairs are (frame sidx[p], frame didx[p]) of U distinct frames.
         Everything up to and including the FIRST self-attention block depends on a frame alone, so it runs once per
@@ -160,12 +175,12 @@ class Decoder(ParamTree):
             if l == 0 and z1_first is not None:
                 z1 = z1_first
             else:
-                z1 = self._self_attn(pre + ".self_attn", zp, 2 * B, M, norm=pre + ".norm1", post=pos)
+                z1 = self._self_attn(pre + ".self_attn", zp, 2 * B, M, norm=pre + ".norm1", post=pos, mask=mask)
             ca = pre + ".cross_attn"
             qkv = ops.linear(z1, self.p(ca + ".in_proj_weight"), self.p(ca + ".in_proj_bias"))  # q | k | v of every token
             # both directions in one launch: sequence b (source of pair b, or target of pair b - B) reads the keys and
             # values of sequence (b + B) mod 2B, its partner
-            a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], 2 * B, M, M, HEADS, kv_shift=B)
+            a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], 2 * B, M, M, HEADS, kv_shift=B, key_mask=mask)
             z2 = self._lin_ln(ca + ".out_proj", pre + ".norm2", a, z1)
             zp = self._lin_ln(pre + ".mlp.2", pre + ".norm3", self._lin(pre + ".mlp.0", z2, ops.ACT_RELU), z2,
                               None if last else pos)
@@ -188,7 +203,8 @@ class Decoder(ParamTree):
             raise ValueError(f"Argument `num_sample` with value {num_sample} is not supported")
         return k // 2
 
-    def _register(self, src_descriptor, dst_descriptor, num_sample, header_out=None, trace: dict = None, pairs=None):
+    def _register(self, src_descriptor, dst_descriptor, num_sample, header_out=None, trace: dict = None, pairs=None,
+                  masks=(None, None)):
         """Batched core: (B,131,M), (B,131,N) -> result (B, 20+2k) on the device, nothing synchronises.
         Pairs are independent, so every kernel runs all B of them at once."""
         if pairs is not None:   # src_descriptor holds the U distinct frames, pairs = (sidx, didx) int32 on the device
@@ -202,7 +218,7 @@ class Decoder(ParamTree):
             xyz_sd = ops.gather_frames(tu, order, M, 3, ld=C + 3, offset=C).view(2 * B * M, 3)
             xyz_s, xyz_d = xyz_sd[:B * M], xyz_sd[B * M:]
         else:
-            x, xyz_s, y, xyz_d, B, M, N = self._descriptor_attention_forward(src_descriptor, dst_descriptor)
+            x, xyz_s, y, xyz_d, B, M, N = self._descriptor_attention_forward(src_descriptor, dst_descriptor, *masks)
         E = self.model_channel
         k = self._num_pairs(num_sample, M, N)
         # similarity head -> L2 normalise -> M x N similarity -> dual softmax -> top-k   (decoder.py:181-191)
@@ -264,15 +280,13 @@ class Decoder(ParamTree):
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("deeppointmap_amd.Decoder runs on the GPU only (there is no CPU fallback)")
-        if src_padding_mask is not None or dst_padding_mask is not None:
-            raise NotImplementedError("padding masks are not used by any inference call site of the reference "
-                                      "and are not implemented")
         batch = not (src_descriptor.ndim == 2 and dst_descriptor.ndim == 2)
         if not batch:
             src_descriptor, dst_descriptor = src_descriptor.unsqueeze(0), dst_descriptor.unsqueeze(0)
         assert src_descriptor.shape[0] == 1, "batch size in inference must be 1"
         with torch.cuda.device(dev):
-            res = self._register(src_descriptor, dst_descriptor, num_sample, header_out, trace)[0]
+            res = self._register(src_descriptor, dst_descriptor, num_sample, header_out, trace,
+                                 masks=(src_padding_mask, dst_padding_mask))[0]
             head = res[:ops.RES_HDR].cpu()  # the one host sync of the call: rmse is a python float in the contract
         n_in, rmse = int(head[14]), float(head[12])
         R, T, cf = res[0:9].view(3, 3), res[9:12].view(3, 1), res[ops.RES_HDR:ops.RES_HDR + n_in]

@@ -447,10 +447,11 @@ def posemb(xyz_rows: torch.Tensor, dim_t: torch.Tensor, emb_dim: int) -> torch.T
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, M: int, N: int, heads: int = 8,
-              out: Optional[torch.Tensor] = None, kv_shift: int = 0):
+              out: Optional[torch.Tensor] = None, kv_shift: int = 0, key_mask: Optional[torch.Tensor] = None):
     """q (B*M,E) / k,v (B*N,E) row views (column slices of wider buffers allowed) -> (B*M,E)
     (written into `out`, a contiguous (B*M,E) tensor or row range of one, when given).
-    kv_shift: sequence b attends the keys / values of sequence (b + kv_shift) mod B."""
+    kv_shift: sequence b attends the keys / values of sequence (b + kv_shift) mod B.
+    key_mask (B,N) uint8, non-zero = padding key (nn.MultiheadAttention's key_padding_mask), indexed like the keys."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _rows2d(t, n)
     E = q.shape[1]
@@ -458,9 +459,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, M: int,
         out = torch.empty(B * M, E, device=q.device, dtype=torch.float32)
     elif tuple(out.shape) != (B * M, E) or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError("out must be a contiguous fp32 (B*M, E) tensor")
-    _lib.check(_lib.load().dpm_attention_shifted(_ptr(q), q.stride(0), M * q.stride(0), _ptr(k), k.stride(0),
-                                                 N * k.stride(0), _ptr(v), v.stride(0), N * v.stride(0), _ptr(out), E,
-                                                 M * E, B, M, N, heads, E // heads, int(kv_shift), _stream(q)),
+    if key_mask is not None:
+        _chk(key_mask, torch.uint8, "key_mask")
+        if tuple(key_mask.shape) != (B, N):
+            raise ValueError(f"key_mask must be ({B}, {N}), got {tuple(key_mask.shape)}")
+    _lib.check(_lib.load().dpm_attention_masked(_ptr(q), q.stride(0), M * q.stride(0), _ptr(k), k.stride(0),
+                                                N * k.stride(0), _ptr(v), v.stride(0), N * v.stride(0), _ptr(out), E,
+                                                M * E, B, M, N, heads, E // heads, int(kv_shift), _ptr(key_mask), _stream(q)),
                "dpm_attention")
     return out
 

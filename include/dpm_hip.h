@@ -220,6 +220,13 @@ int dpm_attention_shifted(const float *Q, int ldq, long long sq, const float *K,
                           const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
                           int N, int heads, int head_dim, int kv_shift, dpm_stream_t stream);
 
+/* ... and with nn.MultiheadAttention's key_padding_mask (descriptor_attention.py:33-42): key_mask (B,N) bytes, non-zero
+ * = key n of sequence b is padding and takes no part in the softmax (sequence b reads row (b + kv_shift) mod B of the
+ * mask, like its keys); NULL = no mask. */
+int dpm_attention_masked(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                         const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
+                         int N, int heads, int head_dim, int kv_shift, const uint8_t *key_mask, dpm_stream_t stream);
+
 /* F.normalize(x, p=2, dim=-1) (decoder.py:185): x / max(||x||, 1e-12), rows (R,C). */
 int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stream);
 

@@ -267,8 +267,9 @@ def position_embedding(xyz: Tensor, emb_dim: int = 256, temperature: float = 100
 # ----------------------------------------------------------------------------------------------
 # a12  descriptor attention                              descriptor_attention.py:24-51, decoder.py:145-162
 # ----------------------------------------------------------------------------------------------
-def _mha(sd: SD, prefix: str, q_in: Tensor, kv_in: Tensor, heads: int = 8) -> Tensor:
-    """nn.MultiheadAttention(batch_first) with key=value=kv_in, no masks, dropout 0."""
+def _mha(sd: SD, prefix: str, q_in: Tensor, kv_in: Tensor, heads: int = 8, key_padding_mask: Optional[Tensor] = None) -> Tensor:
+    """nn.MultiheadAttention(batch_first) with key=value=kv_in, dropout 0; key_padding_mask (B,N) bool, True = the key
+    takes no part in the softmax (descriptor_attention.py:33-42)."""
     E = q_in.shape[-1]
     w, b = sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"]
     q = F.linear(q_in, w[:E], b[:E])
@@ -280,19 +281,23 @@ def _mha(sd: SD, prefix: str, q_in: Tensor, kv_in: Tensor, heads: int = 8) -> Te
     q = q.view(B, M, heads, hd).transpose(1, 2)
     k = k.view(B, N, heads, hd).transpose(1, 2)
     v = v.view(B, N, heads, hd).transpose(1, 2)
-    a = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
+    scores = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    if key_padding_mask is not None:
+        scores = scores.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+    a = torch.softmax(scores, dim=-1)
     o = (a @ v).transpose(1, 2).reshape(B, M, E)
     return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
 
 
-def attention_layer(sd: SD, prefix: str, x: Tensor, y: Tensor, px: Tensor, py: Tensor) -> Tuple[Tensor, Tensor]:
-    """x (B,M,256), y (B,N,256) token-major; both cross calls read the pre-update x, y."""
+def attention_layer(sd: SD, prefix: str, x: Tensor, y: Tensor, px: Tensor, py: Tensor,
+                    mx: Optional[Tensor] = None, my: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """x (B,M,256), y (B,N,256) token-major; both cross calls read the pre-update x, y; mx / my: padding masks."""
     x, y = x + px, y + py
-    x = _ln(sd, prefix + ".norm1", x + _mha(sd, prefix + ".self_attn", x, x))
-    y = _ln(sd, prefix + ".norm1", y + _mha(sd, prefix + ".self_attn", y, y))
+    x = _ln(sd, prefix + ".norm1", x + _mha(sd, prefix + ".self_attn", x, x, key_padding_mask=mx))
+    y = _ln(sd, prefix + ".norm1", y + _mha(sd, prefix + ".self_attn", y, y, key_padding_mask=my))
     x, y = x + px, y + py
-    xo = _mha(sd, prefix + ".cross_attn", x, y)
-    yo = _mha(sd, prefix + ".cross_attn", y, x)
+    xo = _mha(sd, prefix + ".cross_attn", x, y, key_padding_mask=my)
+    yo = _mha(sd, prefix + ".cross_attn", y, x, key_padding_mask=mx)
     x = _ln(sd, prefix + ".norm2", x + xo)
     y = _ln(sd, prefix + ".norm2", y + yo)
 
@@ -305,7 +310,8 @@ def attention_layer(sd: SD, prefix: str, x: Tensor, y: Tensor, px: Tensor, py: T
     return x, y
 
 
-def descriptor_attention(sd: SD, cfg, src: Tensor, dst: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+def descriptor_attention(sd: SD, cfg, src: Tensor, dst: Tensor, src_padding_mask: Optional[Tensor] = None,
+                         dst_padding_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """src (B,131,M), dst (B,131,N) -> token-major (fea_s (B,M,256), xyz_s (B,M,3), fea_d, xyz_d)."""
     sf, sx = src[:, :-3].transpose(1, 2), src[:, -3:].transpose(1, 2)
     df, dx = dst[:, :-3].transpose(1, 2), dst[:, -3:].transpose(1, 2)
@@ -313,7 +319,7 @@ def descriptor_attention(sd: SD, cfg, src: Tensor, dst: Tensor) -> Tuple[Tensor,
     ps, pd = position_embedding(sx, E), position_embedding(dx, E)
     x, y = _lin(sd, "projection", sf), _lin(sd, "projection", df)
     for l in range(cfg.decoder.attention_layers):
-        x, y = attention_layer(sd, f"descriptor_attention.{l}", x, y, ps, pd)
+        x, y = attention_layer(sd, f"descriptor_attention.{l}", x, y, ps, pd, src_padding_mask, dst_padding_mask)
     return x, sx, y, dx
 
 
@@ -412,9 +418,10 @@ def solve_svd(w: Tensor, src: Tensor, dst: Tensor, num_iter: int = 3, std_ratio:
 # ----------------------------------------------------------------------------------------------
 # a16 / a17  public decoder calls                          decoder.py:91-143, heads.py:45-69
 # ----------------------------------------------------------------------------------------------
-def registration_forward(sd: SD, cfg, src_desc: Tensor, dst_desc: Tensor, num_sample=0.5, trace=None):
-    """(131,M),(131,N) -> (R (3,3), T (3,1), conf (n_inlier,), rmse float)."""
-    x, ps, y, pd = descriptor_attention(sd, cfg, src_desc.unsqueeze(0), dst_desc.unsqueeze(0))
+def registration_forward(sd: SD, cfg, src_desc: Tensor, dst_desc: Tensor, num_sample=0.5, trace=None,
+                         src_padding_mask: Optional[Tensor] = None, dst_padding_mask: Optional[Tensor] = None):
+    """(131,M),(131,N) -> (R (3,3), T (3,1), conf (n_inlier,), rmse float); padding masks (1,M) / (1,N) bool."""
+    x, ps, y, pd = descriptor_attention(sd, cfg, src_desc.unsqueeze(0), dst_desc.unsqueeze(0), src_padding_mask, dst_padding_mask)
     si, di, conf = descriptor_pairing(sd, cfg, x, y, num_sample)
     src, dst, w = correspondence_sets(sd, cfg, x[0, si], ps[0, si], y[0, di], pd[0, di], conf)
     margins = [] if trace is not None else None
@@ -424,11 +431,12 @@ def registration_forward(sd: SD, cfg, src_desc: Tensor, dst_desc: Tensor, num_sa
     return R, T, w[inl], rmse
 
 
-def loop_detection_forward(sd: SD, cfg, src_desc: Tensor, dst_desc: Tensor) -> Tensor:
+def loop_detection_forward(sd: SD, cfg, src_desc: Tensor, dst_desc: Tensor, src_padding_mask: Optional[Tensor] = None,
+                           dst_padding_mask: Optional[Tensor] = None) -> Tensor:
     """(C,131,M),(C,131,N) -> (C,) loop probabilities."""
     if src_desc.ndim == 2:
         src_desc, dst_desc = src_desc.unsqueeze(0), dst_desc.unsqueeze(0)
-    x, _, y, _ = descriptor_attention(sd, cfg, src_desc, dst_desc)
+    x, _, y, _ = descriptor_attention(sd, cfg, src_desc, dst_desc, src_padding_mask, dst_padding_mask)
     fx = _head2(sd, "loop_head.mlp", x).mean(dim=1)
     fy = _head2(sd, "loop_head.mlp", y).mean(dim=1)
     h = torch.relu(_lin(sd, "loop_head.projection.0", torch.cat([fx, fy], dim=-1)))

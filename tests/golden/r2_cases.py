@@ -95,3 +95,31 @@ def converged_cases():
                          R @ xyz + t + 0.02 * torch.randn(3, 256, generator=g)], 0)[:, perm].contiguous()
         out[name] = (src, dst, R, t)
     return out
+
+
+# ---- padding masks (key_padding_mask of the attention blocks) ----------------------------------------------------------
+def masked_cases():
+    """name -> (src (B,131,M), dst (B,131,N), src_mask (B,M) bool or None, dst_mask (B,N) bool or None): key-frame
+    descriptors of the pool above whose tail tokens are padding (zero columns, mask True), as a collated batch of
+    ragged descriptor sets would look.  'reg_256' and 'reg_1024x256' are registrations (B = 1; equal and unequal
+    token counts take different launch paths), 'loop4' a loop-detection batch with a different padding per row."""
+    kps, _ = keyframe_pool()
+
+    def pad(desc, n):
+        d, m = desc.clone(), torch.zeros(desc.shape[1], dtype=torch.bool)
+        if n:
+            d[:, -n:] = 0.0
+            m[-n:] = True
+        return d, m
+
+    s, ms = pad(kps[3], 40)
+    d, md = pad(kps[4], 25)
+    big, mb = pad(torch.cat([kps[0], kps[1], kps[2], kps[5]], dim=1), 100)
+    rows = [pad(kps[i], n) for i, n in ((6, 0), (7, 64), (8, 200), (9, 1))]
+    rows_d = [pad(kps[i], n) for i, n in ((10, 30), (10, 0), (11, 128), (12, 255))]
+    return {
+        "reg_256": (s[None], d[None], ms[None], md[None]),
+        "reg_1024x256": (big[None], kps[13][None].clone(), mb[None], None),
+        "loop4": (torch.stack([r[0] for r in rows]), torch.stack([r[0] for r in rows_d]),
+                  torch.stack([r[1] for r in rows]), torch.stack([r[1] for r in rows_d])),
+    }

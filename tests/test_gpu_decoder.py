@@ -161,8 +161,10 @@ def test_registration_argument_errors(dec):
         dec.registration_forward(d, d, num_sample="half")
     with pytest.raises(AssertionError):
         dec.forward(d, d)  # training-only in the reference (decoder.py:37)
-    with pytest.raises(NotImplementedError):
-        dec.registration_forward(d, d, src_padding_mask=torch.zeros(1, 16, dtype=torch.bool))
+    with pytest.raises(ValueError):  # masks are (B, tokens) bool (tests/test_round2_fixtures.py holds their arithmetic)
+        dec.registration_forward(d, d, src_padding_mask=torch.zeros(1, 15, dtype=torch.bool))
+    with pytest.raises(ValueError):
+        dec.registration_forward(d, d, src_padding_mask=torch.zeros(1, 16, dtype=torch.uint8))
 
 
 def test_loop_detection_vs_reference(dec):

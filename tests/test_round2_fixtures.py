@@ -137,3 +137,52 @@ def test_hip_map_sized_registrations_vs_reference(cfg_full):
     D = kps[r2_cases.LOOP_DST].unsqueeze(0).repeat(S.shape[0], 1, 1)
     assert S.shape[0] == 16
     np.testing.assert_allclose(dec.loop_detection_forward(S, D).cpu().numpy(), g["loop16.prob"], atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# padding masks: nn.MultiheadAttention's key_padding_mask in every attention block (descriptor_attention.py:33-42)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_oracle_padding_masks_vs_reference(cfg_full, sd_dec):
+    g = load_golden("masked.npz")
+    for name, (src, dst, ms, md) in r2_cases.masked_cases().items():
+        if name.startswith("reg"):
+            R, T_, conf, rmse = O.registration_forward(sd_dec, cfg_full, src[0], dst[0], 0.5, src_padding_mask=ms, dst_padding_mask=md)
+            assert float((T_ - T(g[name + ".T"])).norm()) < TOL_T and rot_angle(R, g[name + ".R"]) < TOL_R, name
+            assert conf.numel() == int(g[name + ".n_conf"]) and abs(rmse - float(g[name + ".rmse"])) < 1e-4
+        else:
+            prob = O.loop_detection_forward(sd_dec, cfg_full, src, dst, ms, md)
+            np.testing.assert_allclose(prob.numpy(), g[name + ".prob"], atol=2e-6)
+    src, dst, ms, md = r2_cases.masked_cases()["reg_256"]
+    x, _, y, _ = O.descriptor_attention(sd_dec, cfg_full, src, dst, ms, md)
+    np.testing.assert_allclose(x[0].t().numpy(), g["reg_256.src_corr"], atol=2e-4)
+    # and the masks matter: without them the same inputs give a different answer
+    x0, _, _, _ = O.descriptor_attention(sd_dec, cfg_full, src, dst)
+    assert float((x0 - x).abs().max()) > 1e-2
+
+
+@pytest.mark.gpu
+def test_hip_padding_masks_vs_reference(cfg_full):
+    from deeppointmap_amd.decoder import Decoder
+    from deeppointmap_amd.registration import simvec_to_num
+    from deeppointmap_amd.weights import init_procedural
+    g = load_golden("masked.npz")
+    dec = init_procedural(Decoder(cfg_full)).to(DEV)
+    for name, (src, dst, ms, md) in r2_cases.masked_cases().items():
+        if name.startswith("reg"):
+            tr = {}
+            R, T_, conf, rmse = dec.registration_forward(src[0], dst[0], ms, md, num_sample=0.5, trace=tr)
+            if name + ".src_corr" in g:
+                M, N = src.shape[2], dst.shape[2]
+                np.testing.assert_allclose(tr["x"].view(M, -1).t().cpu().numpy(), g[name + ".src_corr"], atol=3e-4)
+                np.testing.assert_allclose(tr["y"].view(N, -1).t().cpu().numpy(), g[name + ".dst_corr"], atol=3e-4)
+            dT, dR = float((T_.cpu() - T(g[name + ".T"])).norm()), rot_angle(R.cpu(), g[name + ".R"])
+            assert dT < TOL_T and dR < TOL_R, (name, dT, dR)
+            assert conf.numel() == int(g[name + ".n_conf"]) and abs(rmse - float(g[name + ".rmse"])) < 1e-4
+            assert abs(simvec_to_num(conf) - float(g[name + ".conf30"])) < 1e-5
+        else:
+            prob = dec.loop_detection_forward(src, dst, ms, md)
+            np.testing.assert_allclose(prob.cpu().numpy(), g[name + ".prob"], atol=2e-5)
+    # a mask of the wrong shape is an error, not a silent broadcast
+    src, dst, ms, md = r2_cases.masked_cases()["reg_256"]
+    with pytest.raises(ValueError):
+        dec.registration_forward(src[0], dst[0], ms[:, :100], md)
