@@ -29,6 +29,7 @@ SIGNATURES = {
     "dpm_fps_workspace_bytes": (c_size_t, [I, I, I]),
     "dpm_fps": (I, [P, P, I, I, I, P, P, P, P, P]),
     "dpm_fps_ex": (I, [P, P, I, I, I, P, P, P, P, I, P]),
+    "dpm_fps_start": (I, [P, P, P, I, I, I, P, P, P, P, P]),
     "dpm_knn_workspace_bytes": (c_size_t, [I, I]),
     "dpm_knn_hybrid": (I, [P, P, P, I, I, I, I, D, P, P, P]),
     "dpm_knn_hybrid_reuse": (I, [P, P, P, I, I, I, I, D, P, P, P, P, P]),

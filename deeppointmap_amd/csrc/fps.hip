@@ -38,7 +38,8 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
                                                     const int32_t *__restrict__ lengths, int N, int K,
                                                     int32_t *__restrict__ idx_all,
                                                     float *__restrict__ new_xyz_all,
-                                                    int32_t *__restrict__ new_len, float *__restrict__ cd_ws) {
+                                                    int32_t *__restrict__ new_len, float *__restrict__ cd_ws,
+                                                    const int32_t *__restrict__ start) {
     constexpr int NW = BLOCK / 64;
     constexpr int OB = 1024;  // picks buffered in LDS between flushes
     __shared__ float s_v[2][NW], s_x[2][NW], s_y[2][NW], s_z[2][NW];
@@ -67,16 +68,18 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
     } else {
         for (int i = t; i < len; i += BLOCK) cdg[i] = __builtin_inff();
     }
-    // slot 0 is index 0 even for an empty frame (utils.py:249-250)
-    int cur = 0;
+    // slot 0 is index 0 even for an empty frame (utils.py:249-250) -- or the caller's start index
+    // (`random_start_point`, utils.py:248)
+    const int s0 = start ? min(max(start[b], 0), max(len - 1, 0)) : 0;
+    int cur = s0;
     if (t == 0) {
-        idx[0] = 0;
-        new_xyz[0] = xyz[0];
-        new_xyz[1] = xyz[1];
-        new_xyz[2] = xyz[2];
+        idx[0] = s0;
+        new_xyz[0] = xyz[3 * s0];
+        new_xyz[1] = xyz[3 * s0 + 1];
+        new_xyz[2] = xyz[3 * s0 + 2];
         new_len[b] = max(kn, 1);
     }
-    float sx = xyz[0], sy = xyz[1], sz = xyz[2];
+    float sx = xyz[3 * s0], sy = xyz[3 * s0 + 1], sz = xyz[3 * s0 + 2];
     for (int r = 1; r < kn; ++r) {
         Best best{-1.f, 0x7fffffff};
         float bx = 0.f, by = 0.f, bz = 0.f;  // coordinates of this thread's best point
@@ -235,7 +238,8 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                                                         float *__restrict__ closest_all,
                                                         int32_t *__restrict__ idx_all,
                                                         float *__restrict__ new_xyz_all,
-                                                        int32_t *__restrict__ new_len, int slots) {
+                                                        int32_t *__restrict__ new_len, int slots,
+                                                        const int32_t *__restrict__ start = nullptr) {
     constexpr int NW = FB / 64;
     constexpr int OB = 2048;  // picks buffered in LDS between flushes to global memory
     // per-wave bests, double-buffered by round parity: [parity][value, index bits, x, y, z][wave] in ONE block, so
@@ -273,9 +277,10 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
         x1 = wave_max_dpp(x1), y1 = wave_max_dpp(y1), z1 = wave_max_dpp(z1);
         if (lane == l) bx0 = x0, by0 = y0, bz0 = z0, bx1 = x1, by1 = y1, bz1 = z1;
     }
+    const int s0 = start ? min(max(start[b], 0), max(true_len - 1, 0)) : 0;  // `random_start_point` (utils.py:248)
     if (t == 0) {
-        idx[0] = 0;  // slot 0 is index 0 even for an empty frame (utils.py:249-250)
-        new_xyz[0] = xyz[0], new_xyz[1] = xyz[1], new_xyz[2] = xyz[2];
+        idx[0] = s0;  // slot 0 is index 0 even for an empty frame (utils.py:249-250)
+        new_xyz[0] = xyz[3 * s0], new_xyz[1] = xyz[3 * s0 + 1], new_xyz[2] = xyz[3 * s0 + 2];
         new_len[b] = max(kn, 1);
     }
     // every closest distance starts at +inf; lanes without a bucket hold the "cannot win" value for good, which also
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
     float bmax = mine ? __builtin_inff() : -1.f;
     int bidx = 0x7fffffff;
     float wx = 0.f, wy = 0.f, wz = 0.f;  // coordinates of this bucket's current best point
-    float sx = xyz[0], sy = xyz[1], sz = xyz[2];
+    float sx = xyz[3 * s0], sy = xyz[3 * s0 + 1], sz = xyz[3 * s0 + 2];
     float wv = -1.f, wbx = 0.f, wby = 0.f, wbz = 0.f;  // this wave's best over ALL its buckets, valid across rounds
     int wi = 0x7fffffff;
     int wl = 0;  // the bucket slot (lane) that holds the wave's best
@@ -723,9 +728,9 @@ __global__ __launch_bounds__(FB) void fps_bucket_spec_kernel(const float *__rest
 
 template <int BLOCK, int PPT, bool REG>
 int launch(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx, float *new_xyz,
-           int32_t *new_len, float *ws, hipStream_t st) {
+           int32_t *new_len, float *ws, hipStream_t st, const int32_t *start = nullptr) {
     hipLaunchKernelGGL((fps_kernel<BLOCK, PPT, REG>), dim3(B), dim3(BLOCK), 0, st, xyz, lengths, N, K, idx,
-                       new_xyz, new_len, ws);
+                       new_xyz, new_len, ws, start);
     return dpm_launch_status();
 }
 
@@ -749,13 +754,13 @@ extern "C" size_t dpm_fps_workspace_bytes(int B, int N, int K) {
     return bucket > tree ? bucket : tree;
 }
 
-extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
-                          float *new_xyz, int32_t *new_lengths, void *workspace, int algo,
-                          dpm_stream_t stream) {
+static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t *start, int B, int N, int K, int32_t *idx,
+                        float *new_xyz, int32_t *new_lengths, void *workspace, int algo, dpm_stream_t stream) {
     DPM_CHECK_ARG(xyz && lengths && idx && new_xyz && new_lengths);
     DPM_CHECK_ARG(B >= 1 && N >= 1 && K >= 1);
     DPM_CHECK_ARG(algo >= 0 && algo <= 7);
     hipStream_t st = (hipStream_t)stream;
+    if (start && (algo == 3 || algo == 4 || algo == 6 || algo == 7)) return DPM_EUNSUPPORTED;  // start index: algos 1, 2, 5
     if (algo == 0) algo = (N > 16384 && N <= 65536) ? 5 : (N > 16384 ? 2 : 1);  // 5: shortest chain (1.05 us per pick); 4: fewest instructions
     if (algo >= 5) {  // (6 / 7: the speculative multi-pick kernel, two / three picks per round) the bucket kernel over the Sort-Tile-Recursive packing of fps_tree.hip (fewer buckets survive a round)
         DPM_CHECK_ARG(workspace != nullptr);
@@ -775,7 +780,7 @@ extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N
                                new_lengths, slots);
         else
             hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
-                               new_lengths, slots);
+                               new_lengths, slots, start);
         return dpm_launch_status();
     }
     if (algo == 4) {  // one wave per frame over a two-level box tree (fps_tree.hip)
@@ -798,19 +803,31 @@ extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N
                                new_xyz, new_lengths, 0);
         else
             hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx,
-                               new_xyz, new_lengths, 0);
+                               new_xyz, new_lengths, 0, start);
         return dpm_launch_status();
     }
     float *ws = (float *)workspace;
-    if (N <= 64) return launch<64, 1, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
-    if (N <= 256) return launch<256, 1, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
+    if (N <= 64) return launch<64, 1, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st, start);
+    if (N <= 256) return launch<256, 1, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st, start);
     // block shapes measured per level (scripts/fps_small_bench.py): fewer waves = cheaper barrier and second-level
     // reduction, more points per thread = more independent work per round
-    if (N <= 1024) return launch<256, 4, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
-    if (N <= 4096) return launch<512, 8, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
-    if (N <= 16384) return launch<1024, 16, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
+    if (N <= 1024) return launch<256, 4, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st, start);
+    if (N <= 4096) return launch<512, 8, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st, start);
+    if (N <= 16384) return launch<1024, 16, true>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st, start);
     DPM_CHECK_ARG(workspace != nullptr);
-    return launch<1024, 1, false>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st);
+    return launch<1024, 1, false>(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, ws, st, start);
+}
+
+extern "C" int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
+                          float *new_xyz, int32_t *new_lengths, void *workspace, int algo,
+                          dpm_stream_t stream) {
+    return fps_dispatch(xyz, lengths, nullptr, B, N, K, idx, new_xyz, new_lengths, workspace, algo, stream);
+}
+
+extern "C" int dpm_fps_start(const float *xyz, const int32_t *lengths, const int32_t *start, int B, int N, int K,
+                             int32_t *idx, float *new_xyz, int32_t *new_lengths, void *workspace, dpm_stream_t stream) {
+    DPM_CHECK_ARG(start != nullptr);
+    return fps_dispatch(xyz, lengths, start, B, N, K, idx, new_xyz, new_lengths, workspace, 0, stream);
 }
 
 extern "C" int dpm_fps(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,

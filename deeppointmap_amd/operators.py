@@ -5,6 +5,7 @@ keyword-only call convention (`self.sample(points=..., points_padding=..., K=...
 (pointnext.py:35-36,45,49,82,91) runs unchanged.  The '-t3d' names are aliases: there is one backend.
 
 Not implemented: `Sampler('voxel')` (no shipped config selects it).
+`random_start_point=True` draws its start indices from Python's `random` exactly as the reference does.
 """
 from __future__ import annotations
 
@@ -63,9 +64,13 @@ class Sampler:
     def fps(points: torch.Tensor, points_padding: torch.Tensor, K: int,
             random_start_point: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
         """utils.py:210-285 -> (sampled points (B,K,D) with zero rows at padding, padding mask (B,K))."""
+        lengths, start = _lengths(points_padding), None
         if random_start_point:
-            raise NotImplementedError("random_start_point=True is never used by the reference's inference path")
-        idx, _, _ = ops.fps(_xyz(points), _lengths(points_padding), K)
+            # the reference draws random.randint(0, lengths[n] - 1) once per frame, in batch order (utils.py:248): the same
+            # draws from the same generator, so a seeded run picks the same start points
+            from random import randint
+            start = torch.tensor([randint(0, int(n) - 1) for n in lengths.cpu()], dtype=torch.int32, device=points.device)
+        idx, _, _ = ops.fps(_xyz(points), lengths, K, start=start)
         mask = idx < 0
         gathered = torch.gather(points, 1, idx.clamp(min=0).long().unsqueeze(-1).expand(-1, -1, points.shape[-1]))
         return gathered.masked_fill(mask.unsqueeze(-1), 0.0), mask

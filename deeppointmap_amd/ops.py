@@ -112,12 +112,24 @@ def to_channel_first(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def fps(xyz: torch.Tensor, lengths: torch.Tensor, K: int, algo: int = 0):
-    """xyz (B,N,3), lengths (B,) -> idx (B,K) int32 (-1 = padding), new_xyz (B,K,3), new_lengths (B,)."""
+def fps(xyz: torch.Tensor, lengths: torch.Tensor, K: int, algo: int = 0, start: Optional[torch.Tensor] = None):
+    """xyz (B,N,3), lengths (B,) -> idx (B,K) int32 (-1 = padding), new_xyz (B,K,3), new_lengths (B,).
+    start (B,) int32: first pick of every frame (`random_start_point`); None = point 0."""
     _chk(xyz, torch.float32, "xyz")
     _chk(lengths, torch.int32, "lengths")
     B, N, _ = xyz.shape
     lib = _lib.load()
+    if start is not None:
+        _chk(start, torch.int32, "start")
+        if tuple(start.shape) != (B,):
+            raise ValueError(f"start must have shape ({B},)")
+        idx = torch.empty(B, K, device=xyz.device, dtype=torch.int32)
+        new_xyz = torch.empty(B, K, 3, device=xyz.device, dtype=torch.float32)
+        new_len = torch.empty(B, device=xyz.device, dtype=torch.int32)
+        ws = torch.empty(lib.dpm_fps_workspace_bytes(B, N, K), device=xyz.device, dtype=torch.uint8)
+        _lib.check(lib.dpm_fps_start(_ptr(xyz), _ptr(lengths), _ptr(start), B, N, K, _ptr(idx), _ptr(new_xyz), _ptr(new_len),
+                                     _ptr(ws), _stream(xyz)), "dpm_fps_start")
+        return idx, new_xyz, new_len
     if algo == 0 and N > 16384 and "DPM_FPS_ALGO" in os.environ:  # tuning knob (scripts/, bench experiments)
         algo = int(os.environ["DPM_FPS_ALGO"])
     idx = torch.empty(B, K, device=xyz.device, dtype=torch.int32)

@@ -81,6 +81,11 @@ int dpm_fps(const float *xyz, const int32_t *lengths, int B, int N, int K, int32
  * 6 / 7 = 5 with two / three speculative picks per round.  All give identical bits; the tests run all of them. */
 int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
                float *new_xyz, int32_t *new_lengths, void *workspace, int algo, dpm_stream_t stream);
+/* `random_start_point=True` (utils.py:248): frame b starts from point start[b] (clamped to its valid points) instead of
+ * point 0; the caller draws the indices (the reference: random.randint(0, lengths[n] - 1), one draw per frame in batch
+ * order).  Default algorithm choice (1 / 5 / 2 by N). */
+int dpm_fps_start(const float *xyz, const int32_t *lengths, const int32_t *start, int B, int N, int K, int32_t *idx,
+                  float *new_xyz, int32_t *new_lengths, void *workspace, dpm_stream_t stream);
 
 /* Querier.hybrid_query / hybrid_query_t3d == pytorch3d.ops.knn_points + radius mask
  * (network/encoder/utils.py:76-89,113-123): for each centre the K nearest valid points, slots

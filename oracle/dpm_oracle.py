@@ -35,10 +35,11 @@ SD = Dict[str, Tensor]
 # ----------------------------------------------------------------------------------------------
 # a3  farthest point sampling                          network/encoder/utils.py:210-270
 # ----------------------------------------------------------------------------------------------
-def fps_indices(xyz: Tensor, length: int, K: int) -> Tensor:
+def fps_indices(xyz: Tensor, length: int, K: int, start: int = 0) -> Tensor:
     """xyz (N,3) f32 -> idx (K,) int64, -1 where fewer than K valid points.
 
-    Start at index 0 (utils.py:249, random_start_point=False); every round
+    Start at index 0 (utils.py:249, random_start_point=False) or at `start` (the caller's random.randint draw,
+    utils.py:248); every round
     closest = min(closest, (dx^2+dy^2)+dz^2) and the next pick is the FIRST argmax
     (utils.py:254-259).  torch evaluates `(d**2).sum(-1)` left to right without FMA
     contraction, which is what the HIP kernel reproduces bit for bit.
@@ -48,8 +49,8 @@ def fps_indices(xyz: Tensor, length: int, K: int) -> Tensor:
         return idx
     p = xyz[:length, :3].contiguous()
     closest = torch.full((length,), float("inf"), dtype=torch.float32)
-    sel = 0
-    idx[0] = 0
+    sel = int(start)
+    idx[0] = sel
     for i in range(1, min(length, K)):
         d = p[sel] - p
         closest = torch.minimum((d * d).sum(-1), closest)

@@ -97,6 +97,22 @@ def converged_cases():
     return out
 
 
+# ---- farthest point sampling from a random start point ------------------------------------------------------------------
+RANDOM_START_SEED = 11
+
+
+def random_start_cases():
+    """name -> (points (B,N,3), padding (B,N) bool, K).  The start indices come from random.randint under
+    random.seed(RANDOM_START_SEED), one draw per frame in batch order, cases in this dict's order."""
+    g = torch.Generator().manual_seed(21)
+    small = torch.rand(3, 1000, 3, generator=g) * 2 - 1
+    pad = torch.zeros(3, 1000, dtype=torch.bool)
+    pad[1, 700:] = True
+    pad[2, 40:] = True            # fewer valid points than K: -1 padding after the 40th pick
+    big = torch.randn(1, 20000, 3, generator=g) * torch.tensor([30.0, 30.0, 1.5])
+    return {"small_ragged": (small, pad, 64), "bucket_20000": (big, torch.zeros(1, 20000, dtype=torch.bool), 256)}
+
+
 # ---- padding masks (key_padding_mask of the attention blocks) ----------------------------------------------------------
 def masked_cases():
     """name -> (src (B,131,M), dst (B,131,N), src_mask (B,M) bool or None, dst_mask (B,N) bool or None): key-frame

@@ -186,3 +186,41 @@ def test_hip_padding_masks_vs_reference(cfg_full):
     src, dst, ms, md = r2_cases.masked_cases()["reg_256"]
     with pytest.raises(ValueError):
         dec.registration_forward(src[0], dst[0], ms[:, :100], md)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sampler('fps')(random_start_point=True): the start index is random.randint(0, length - 1), one draw per frame
+# ---------------------------------------------------------------------------------------------------------------------
+def test_oracle_fps_random_start_vs_reference():
+    import random
+    g = load_golden("fps_random_start.npz")
+    random.seed(r2_cases.RANDOM_START_SEED)
+    for name, (pts, pad, K) in r2_cases.random_start_cases().items():
+        lengths = (~pad).sum(1)
+        for b in range(pts.shape[0]):
+            idx = O.fps_indices(pts[b], int(lengths[b]), K, start=random.randint(0, int(lengths[b]) - 1))
+            assert np.array_equal(O.gather_masked(pts[b], idx).numpy(), g[name + ".points"][b]), (name, b)
+            assert np.array_equal((idx < 0).numpy(), g[name + ".mask"][b])
+
+
+@pytest.mark.gpu
+def test_hip_fps_random_start_vs_reference():
+    import random
+    from deeppointmap_amd.operators import Sampler
+    g = load_golden("fps_random_start.npz")
+    fps = Sampler("fps-t3d")
+    random.seed(r2_cases.RANDOM_START_SEED)
+    for name, (pts, pad, K) in r2_cases.random_start_cases().items():
+        new, mask = fps(points=pts.to(DEV), points_padding=pad.to(DEV), K=K, random_start_point=True)
+        assert np.array_equal(new.cpu().numpy(), g[name + ".points"]), name   # same draws, same picks, same order
+        assert np.array_equal(mask.cpu().numpy(), g[name + ".mask"]), name
+    # and through every algorithm that takes a start index, at the size the Sort-Tile-Recursive packing serves
+    from deeppointmap_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    xyz = (torch.randn(2, 30000, 3, generator=gen) * torch.tensor([40.0, 40.0, 2.0])).to(DEV)
+    lens = torch.tensor([30000, 17000], dtype=torch.int32, device=DEV)
+    start = torch.tensor([12345, 16999], dtype=torch.int32, device=DEV)
+    got = ops.fps(xyz, lens, 300, start=start)[0].cpu()
+    for b in range(2):
+        want = O.fps_indices(xyz[b].cpu(), int(lens[b]), 300, start=int(start[b]))
+        assert torch.equal(got[b].long(), want), b
