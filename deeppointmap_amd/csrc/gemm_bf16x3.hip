@@ -16,6 +16,8 @@ namespace {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;  // first-class vector values: the HIP uint4 struct array ended up in scratch
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == DPM_ACT_RELU) return fmaxf(v, 0.f);
@@ -58,20 +60,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__rest
         by = (int)((slot / gridDim.x) * 8 + xcd), bx = (int)(slot % gridDim.x);
     }
     const int row0 = by * BM, col0 = bx * BN;
-    // staging maps: X as fp32 float4 (4 per thread), W planes as 8 bf16 = uint4 (6 per thread)
-    const int xr_ = t >> 3, xk = (t & 7) * 4;
-    float4 xr[4];
-    uint4 wr[6];
-    auto request = [&](int k0) {
+    // staging maps: X as fp32 float4 (4 per thread: rows xr_ + 32 p), W planes as 8 bf16 = uint4 (6 per thread: plane
+    // p >> 1, rows wr_ + 64 (p & 1)).  Every index below is a compile-time constant after unrolling: arrays indexed
+    // through a lambda or a runtime value end up in scratch memory (the first version of this kernel did: 112 B / lane).
+    const int xr_ = t >> 3, xk = (t & 7) * 4, wr_ = t >> 2, wk = (t & 3) * 8;
+    const float *xp[4];
+    const uint16_t *wp[2];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            xr[p] = *reinterpret_cast<const float4 *>(X + (size_t)min(row0 + p * 32 + xr_, R - 1) * ldx + k0 + xk);
+    for (int p = 0; p < 4; ++p) xp[p] = X + (size_t)min(row0 + p * 32 + xr_, R - 1) * ldx + xk;
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
-            const int e = t + 256 * p, pl = e >> 9, rem = e & 511, r = rem >> 2, k8 = (rem & 3) * 8;
-            wr[p] = *reinterpret_cast<const uint4 *>(Wp + (size_t)pl * plane + (size_t)min(col0 + r, Cout - 1) * ldw + k0 + k8);
-        }
-    };
+    for (int p = 0; p < 2; ++p) wp[p] = Wp + (size_t)min(col0 + p * 64 + wr_, Cout - 1) * ldw + wk;
+    f32x4 xr[4];
+    u32x4 wr[6];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) xr[p] = *reinterpret_cast<const f32x4 *>(xp[p]);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) wr[p] = *reinterpret_cast<const u32x4 *>(wp[p & 1] + (size_t)(p >> 1) * plane);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -79,26 +83,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__rest
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    request(0);
     const int fr = lane & 31, fk = (lane >> 5) * 8;
     for (int k0 = 0; k0 < Cin; k0 += KT) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            unsigned h[4], m[4], l[4];
-            split3(xr[p].x, h[0], m[0], l[0]), split3(xr[p].y, h[1], m[1], l[1]);
-            split3(xr[p].z, h[2], m[2], l[2]), split3(xr[p].w, h[3], m[3], l[3]);
+            unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+            split3(xr[p][0], h0, m0, l0), split3(xr[p][1], h1, m1, l1), split3(xr[p][2], h2, m2, l2), split3(xr[p][3], h3, m3, l3);
             const int r = p * 32 + xr_;
-            *reinterpret_cast<uint2 *>(&Xs[0][r][xk]) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-            *reinterpret_cast<uint2 *>(&Xs[1][r][xk]) = make_uint2(pack2(m[0], m[1]), pack2(m[2], m[3]));
-            *reinterpret_cast<uint2 *>(&Xs[2][r][xk]) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+            *reinterpret_cast<uint2 *>(&Xs[0][r][xk]) = make_uint2(pack2(h0, h1), pack2(h2, h3));
+            *reinterpret_cast<uint2 *>(&Xs[1][r][xk]) = make_uint2(pack2(m0, m1), pack2(m2, m3));
+            *reinterpret_cast<uint2 *>(&Xs[2][r][xk]) = make_uint2(pack2(l0, l1), pack2(l2, l3));
         }
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
-            const int e = t + 256 * p, pl = e >> 9, rem = e & 511, r = rem >> 2, k8 = (rem & 3) * 8;
-            *reinterpret_cast<uint4 *>(&Ws[pl][r][k8]) = wr[p];
-        }
+        for (int p = 0; p < 6; ++p) *reinterpret_cast<u32x4 *>(&Ws[p >> 1][(p & 1) * 64 + wr_][wk]) = wr[p];
         __syncthreads();
-        if (k0 + KT < Cin) request(k0 + KT);
+        {   // the next K-tile is requested while this one feeds the MFMAs -- unconditionally (the last trip re-reads its
+            // own tile): behind a branch the compiler keeps the prefetch registers in scratch memory
+            const int kn = min(k0 + KT, Cin - KT);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) xr[p] = *reinterpret_cast<const f32x4 *>(xp[p] + kn);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) wr[p] = *reinterpret_cast<const u32x4 *>(wp[p & 1] + (size_t)(p >> 1) * plane + kn);
+        }
 #pragma unroll
         for (int ks = 0; ks < KT; ks += 16) {
             bf16x8 a[3][2], b[3][2];  // a: W fragments (the instruction's A operand), b: X fragments
@@ -110,14 +116,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__rest
                 for (int i = 0; i < 2; ++i) b[pl][i] = *reinterpret_cast<const bf16x8 *>(&Xs[pl][wm * 64 + i * 32 + fr][ks + fk]);
             }
             // smallest terms first; (plane of W, plane of X): (1,1) (2,0) (0,2) (1,0) (0,1) (0,0)
-            constexpr int PW[6] = {1, 2, 0, 1, 0, 0}, PX[6] = {1, 0, 2, 0, 1, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PW[q]][j], b[PX[q]][i], acc[i][j], 0, 0, 0);
+#define DPM_B3(PWQ, PXQ)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)              \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PWQ][j], b[PXQ][i], acc[i][j], 0, 0, 0)
+            DPM_B3(1, 1);
+            DPM_B3(2, 0);
+            DPM_B3(0, 2);
+            DPM_B3(1, 0);
+            DPM_B3(0, 1);
+            DPM_B3(0, 0);
+#undef DPM_B3
         }
         __syncthreads();
     }

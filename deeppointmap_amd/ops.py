@@ -350,7 +350,8 @@ def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     if residual is not None:
         r2 = residual.reshape(-1, Cout)
         _chk(r2, torch.float32, "residual")
-    if GEMM_MODE == "bf16x3" and R >= 4096 and Cin % 32 == 0 and Cout % 4 == 0 and W.dim() >= 2 and W.is_contiguous():
+    if (GEMM_MODE == "bf16x3" and (R // 128) * (Cout // 128) >= 256 and Cin >= 128 and Cin % 32 == 0 and Cout % 128 == 0
+            and W.dim() >= 2 and W.is_contiguous()):
         # experimental (DPM_GEMM=bf16x3): exact three-term bf16 split on the bf16 matrix pipe, fp32-level accuracy
         Wp = _derived("bf16x3", (W,), lambda: split_bf16x3(W))
         st = _lib.load().dpm_linear_bf16x3(_ptr(x2), x2.stride(0), _ptr(Wp), Cin, Cout * Cin, _ptr(bias), _ptr(r2),
