@@ -54,3 +54,39 @@ def test_gather_to_root_world2_gloo():
 def test_gather_is_identity_without_process_group():
     t = torch.arange(6.0).view(2, 3)
     assert gather_to_root(t) is t
+
+
+def _halo_worker(rank, world, port, q):
+    from deeppointmap_amd.shard import exchange_halo
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    for step in range(3):  # the hand-over is one collective per rank and step: three in a row must stay matched
+        desc = torch.full((131, 8), 100.0 * step + rank)
+        pcd = torch.full((3, 40), 1000.0 * step + rank)
+        got_d, got_p = exchange_halo(desc, pcd)
+        prev = (rank - 1) % world
+        ok &= tuple(got_d.shape) == (131, 8) and tuple(got_p.shape) == (3, 40)
+        ok &= bool((got_d == 100.0 * step + prev).all()) and bool((got_p == 1000.0 * step + prev).all())
+        got_d2, none = exchange_halo(desc, None)  # descriptors only (no scans: no information matrix)
+        ok &= none is None and bool((got_d2 == 100.0 * step + prev).all())
+    q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_ring_hands_the_last_frame_to_the_next_rank(world):
+    """Block boundaries (reference odometry.py:103-127: every scan is registered against its predecessor): rank r gets
+    the last frame of rank r-1, rank 0 the last frame of the whole window."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + os.getpid() % 1000 + world
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res)
