@@ -237,6 +237,29 @@ def main():
 
     # ---- extra measurements, outside the timed region and never part of `value` ---------------------------------
     extras = {}
+    alone = {}
+    if not args.no_extras and rank == 0:
+        # (0) the two roofline kernels ALONE on the chip (the figures inside the timed region include what the other
+        #     pipeline stages cost them): first-stage sampling of one 64-frame batch, and the 256 -> 768 projection
+        def alone_ms(fn, n):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        xyz0, len0 = ops.prepare_points(pts, pad)
+        alone["fps_ms"] = alone_ms(lambda: orig_fps(xyz0, len0, cfg.encoder.npoint[0]), 3)
+        if gemm_flops[0]:
+            rows = gemm_flops[0] // (2 * 768 * 256)
+            gx, gw, gb = torch.randn(rows, 256, device=dev), torch.randn(768, 256, device=dev) / 16, torch.randn(768, device=dev)
+            go = torch.empty(rows, 768, device=dev)
+            alone["gemm_ms"] = alone_ms(lambda: orig_linear(gx, gw, gb, out=go), 20)
+            del gx, gw, gb, go
+        del xyz0, len0
     if not args.no_extras:
         if world == 1 and not args.no_pipeline:
             # (1) PCIe-inclusive rate: the scans start in pinned host memory and are copied in every step (the metres copy
@@ -349,6 +372,10 @@ def main():
                                  "reference's loop re-reads the WHOLE frame every round (4095 x 65536 x 16 B = 4.3 GB "
                                  "per frame, 275 GB per launch), the bucket pruning cuts that ~85x; see DESIGN.md"},
         }
+        if "fps_ms" in alone:   # the same kernel pair with the chip to itself (outside the timed region)
+            line["roofline"]["alone"] = {"launch_ms": round(alone["fps_ms"], 4),
+                                         "us_per_round": round(alone["fps_ms"] * 1e3 / (cfg.encoder.npoint[0] - 1), 3),
+                                         "frac": round(alg / (alone["fps_ms"] * 1e-3) / HBM_PEAK, 6)}
         line.update(extras)
         if "rank0_serial_ms" in extras:
             line["value_with_rank0_consumer"] = round(world * F / (dt / args.steps + extras["rank0_serial_ms"] * 1e-3), 1)
@@ -361,6 +388,10 @@ def main():
                 "avg_launch_ms": round(gemm_ms, 4), "flops_per_launch": gemm_flops[0],
                 "note": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak); timed with HIP events on its "
                         "launch stream while the other pipeline stages share the chip"}
+            if "gemm_ms" in alone:  # the same launch with the chip to itself (outside the timed region)
+                ta = gemm_flops[0] / (alone["gemm_ms"] * 1e-3) / 1e12
+                line["roofline_mfma"]["alone"] = {"launch_ms": round(alone["gemm_ms"], 4), "achieved": round(ta, 2),
+                                                  "frac": round(ta / 157.3, 4)}
         if world == 1 and args.cpu_frames > 0:
             # torch's intra-op pool stops scaling (and then collapses) well below the box's core count on
             # these small ops: 16 threads measured fastest on the 256-core GPU host (8: 0.83, 16: 0.63,
