@@ -14,12 +14,14 @@ from deeppointmap_amd.weights import init_procedural
 dev = torch.device("cuda:0")
 cfg = default_args()
 hot = HotPath(init_procedural(Encoder(cfg)).to(dev), init_procedural(Decoder(cfg)).to(dev))
-F = 64
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 64  # 1 or 2: the latency-mode shapes, where launch gaps dominate
 pts, pad = synthetic.frames(F, 65536)
 pts, pad = pts.to(dev), pad.to(dev)
 pcd = (pts * 60).contiguous()
 pre = hot.encoder.presample(pts, pad)
 pairs, index = hot._ring_pairs(F, dev)
+if F == 2:
+    pairs, index = [(0, 1)], (torch.tensor([0], dtype=torch.int32, device=dev), torch.tensor([1], dtype=torch.int32, device=dev))
 desc = hot.extract(pts, pad, presampled=pre)
 _, table = hot.register(desc, pcd, pairs, materialize=False, pair_index=index)
 torch.cuda.synchronize()
