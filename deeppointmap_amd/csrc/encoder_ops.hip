@@ -3,6 +3,7 @@
 // linear, LayerNorm, 3-NN feature propagation.  fp32 throughout, like the reference.
 // Compiled with -ffp-contract=off: every fused multiply-add is an explicit fmaf().
 #include "dpm_common.h"
+#include "topk_emulate.h"
 
 namespace {
 
@@ -245,11 +246,16 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float *__restr
 // strict <, the earlier index stays ahead on ties, as topk(k=3, largest=False) on the reference's distance row);
 // the wave's three nearest are then the heads of three rounds of a wave arg-min, the winning lane popping its head.
 // Distances in the expanded form -2ab + |a|^2 + |b|^2 like the reference (pointnext.py:205, utils.py:288-295).
+// When coarse points at EXACTLY the third distance are left out (mirror-symmetric clouds: two key points equally far
+// from a third), which of them torch.topk keeps is the data movement of std::nth_element (3 * 64 > S, every shipped
+// level) or of std::partial_sort's heap-select: the row of S (distance, index) pairs goes to LDS (`rows` != 0: the launch
+// reserved 4 * S pairs) and lane 0 replays libstdc++ on it (topk_emulate.h) -- rare, and S is 16 or 64.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void three_interp_cat_kernel(
     const float *__restrict__ xyz1_all, const float *__restrict__ xyz2_all, const int32_t *__restrict__ len2,
     const float *__restrict__ fea1_all, const float *__restrict__ fea2_all, int N, int S, int D1, int D2,
-    float *__restrict__ out_all) {
+    float *__restrict__ out_all, int rows) {
+    extern __shared__ __attribute__((aligned(8))) unsigned char s_rows_raw[];
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (n >= N) return;
@@ -297,6 +303,48 @@ __global__ __launch_bounds__(256) void three_interp_cat_kernel(
         }
         bd[k] = md, bi[k] = mi == 0x7fffffff ? 0 : mi;
         if (i0 == mi && mi != 0x7fffffff) d0 = d1, i0 = i1, d1 = d2, i1 = i2, d2 = INF, i2 = 0x7fffffff;  // pop
+    }
+    if (rows && ls >= 3) {
+        // does a point at exactly the third distance stay outside the three?
+        const float t3 = bd[2];
+        int eq = 0;
+        for (int j = lane; j < ls; j += 64) {
+            const float x = q[3 * j], y = q[3 * j + 1], z = q[3 * j + 2];
+            float d = -2.f * fmaf(pz, z, fmaf(py, y, px * x));
+            d += pp;
+            d += (x * x + y * y) + z * z;
+            eq += d == t3;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) eq += __shfl_xor(eq, off, 64);
+        const int taken = 1 + (bd[1] == t3) + (bd[0] == t3);
+        if (eq > taken) {  // wave-uniform
+            VI *row = reinterpret_cast<VI *>(s_rows_raw) + (size_t)(threadIdx.x >> 6) * S;
+            for (int j = lane; j < S; j += 64) {
+                float d = INF;  // padded coarse points are pushed far away by the reference: above every real one, equal among themselves
+                if (j < ls) {
+                    const float x = q[3 * j], y = q[3 * j + 1], z = q[3 * j + 2];
+                    d = -2.f * fmaf(pz, z, fmaf(py, y, px * x));
+                    d += pp;
+                    d += (x * x + y * y) + z * z;
+                }
+                row[j].v = d, row[j].i = j;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                if (3 * 64 <= S) vi_heap_select<false>(row, 0, 3, S);  // torch.topk: partial_sort when k * 64 <= n
+                else vi_nth_element<false>(row, S, 2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // the three survivors, ascending like the reference's sorted result (values tie, the set is what matters)
+            VI a = row[0], b2 = row[1], c2 = row[2];
+            if (b2.v < a.v) { VI t = a; a = b2; b2 = t; }
+            if (c2.v < b2.v) { VI t = b2; b2 = c2; c2 = t; }
+            if (b2.v < a.v) { VI t = a; a = b2; b2 = t; }
+            bd[0] = a.v, bi[0] = a.i, bd[1] = b2.v, bi[1] = b2.i, bd[2] = c2.v, bi[2] = c2.i;
+        }
     }
     float w0 = 1.f / fmaxf(bd[0], 1e-8f), w1 = 1.f / fmaxf(bd[1], 1e-8f), w2 = 1.f / fmaxf(bd[2], 1e-8f);
     if (ls < 3) w2 = 0.f;
@@ -488,8 +536,11 @@ extern "C" int dpm_three_interp_cat(const float *xyz1, const float *xyz2, const 
                                     dpm_stream_t stream) {
     DPM_CHECK_ARG(xyz1 && xyz2 && lengths2 && fea1 && fea2 && out);
     DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && D1 >= 0 && D2 >= 1);
-    hipLaunchKernelGGL(three_interp_cat_kernel, dim3(dpm_cdiv(N, 4), B), dim3(256), 0, (hipStream_t)stream, xyz1, xyz2, lengths2,
-                       fea1, fea2, N, S, D1, D2, out);
+    // rows of up to 1024 coarse points fit the tie replay's LDS scratch (4 waves x S pairs); larger ones keep the
+    // smallest-index rule
+    const int rows = S <= 1024 ? 1 : 0;
+    hipLaunchKernelGGL(three_interp_cat_kernel, dim3(dpm_cdiv(N, 4), B), dim3(256), rows ? sizeof(VI) * 4 * (size_t)S : 0,
+                       (hipStream_t)stream, xyz1, xyz2, lengths2, fea1, fea2, N, S, D1, D2, out, rows);
     return dpm_launch_status();
 }
 

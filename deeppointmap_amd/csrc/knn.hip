@@ -479,36 +479,45 @@ struct KnnGrid {  // per frame header in the workspace
 
 __global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float *__restrict__ points_all,
                                                               const int32_t *__restrict__ lengths, int N,
-                                                              float cs_min, KnnGrid *__restrict__ hdr_all,
+                                                              float cs_min, float r2_margin, KnnGrid *__restrict__ hdr_all,
                                                               int *__restrict__ start_all,
                                                               float4 *__restrict__ sorted_all,
                                                               int *__restrict__ tie_count) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *tie_count = 0;
     __shared__ int s_hist[GDIM * GDIM];
     __shared__ float s_red[4][16];
+    __shared__ float s_m2[16];
     __shared__ int s_wsum[16];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float *pts = points_all + (size_t)b * N * 3;
     const int len = min(max(lengths[b], 0), N);
-    float lox = __builtin_inff(), loy = lox, hix = -lox, hiy = -lox;
+    float lox = __builtin_inff(), loy = lox, hix = -lox, hiy = -lox, m2 = 0.f;
     for (int i = t; i < len; i += 1024) {
-        const float x = pts[3 * i], y = pts[3 * i + 1];
+        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
         lox = fminf(lox, x), hix = fmaxf(hix, x), loy = fminf(loy, y), hiy = fmaxf(hiy, y);
+        m2 = fmaxf(m2, sq3(x, y, z));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         lox = fminf(lox, __shfl_xor(lox, off, 64)), loy = fminf(loy, __shfl_xor(loy, off, 64));
         hix = fmaxf(hix, __shfl_xor(hix, off, 64)), hiy = fmaxf(hiy, __shfl_xor(hiy, off, 64));
+        m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
     }
-    if (lane == 0) s_red[0][w] = lox, s_red[1][w] = loy, s_red[2][w] = hix, s_red[3][w] = hiy;
+    if (lane == 0) s_red[0][w] = lox, s_red[1][w] = loy, s_red[2][w] = hix, s_red[3][w] = hiy, s_m2[w] = m2;
     for (int c = t; c < GDIM * GDIM; c += 1024) s_hist[c] = 0;
     __syncthreads();
     for (int k = 0; k < 16; ++k) {
         lox = fminf(lox, s_red[0][k]), loy = fminf(loy, s_red[1][k]);
         hix = fmaxf(hix, s_red[2][k]), hiy = fmaxf(hiy, s_red[3][k]);
+        m2 = fmaxf(m2, s_m2[k]);
     }
     if (len == 0) lox = loy = hix = hiy = 0.f;
     const float ext = fmaxf(fmaxf(hix - lox, hiy - loy), 1e-6f);
+    // The search compares the reference's EXPANDED-form distance with r^2, and that form's rounding error grows with
+    // the squared magnitude of the coordinates (it is a difference of numbers of size |a|^2 + |b|^2): a point whose
+    // computed distance is <= r^2 can truly be sqrt(r^2 + err) away.  The cell edge covers it: 2e-5 for coordinates
+    // normalised to the unit ball (what the encoder feeds), scaled up for clouds that are not.
+    if (r2_margin > 0.f) cs_min = fmaxf(cs_min, sqrtf(r2_margin + 2e-5f * fmaxf(1.f, m2)) * 1.002f);
     const float cs = fmaxf(cs_min, ext / (float)(GDIM - 1));
     const float inv_cs = 1.0f / cs;
     const int g = min(GDIM, (int)(ext * inv_cs) + 1);
@@ -1119,10 +1128,11 @@ KnnWs carve(void *workspace, int B, int N) {
 }
 void launch_grid_build(const float *points, const int32_t *lengths, int B, int N, double radius, const KnnWs &w,
                        hipStream_t st) {
-    // cell edge > sqrt(r^2 + 2e-5): the expanded-form distance can undershoot the true one by ~1.5e-6
+    // cell edge > sqrt(r^2 + 2e-5 max(1, max |p|^2)): the expanded-form distance can undershoot the true one by ~1.5e-6 on
+    // unit-ball coordinates and proportionally more on larger ones (the kernel knows the frame's extent)
     const float cs_min = (float)(sqrt(radius * radius + 2e-5) * 1.002);
-    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, st, points, lengths, N, cs_min, w.hdr, w.start,
-                       w.sorted, w.tie_count);
+    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, st, points, lengths, N, cs_min, (float)(radius * radius),
+                       w.hdr, w.start, w.sorted, w.tie_count);
 }
 int launch_grid_search(const float *points, const int32_t *lengths, const float *centers, int B, int N, int S, int K,
                        float r2, int32_t *idx, const KnnWs &w, const int32_t *reuse_idx, const int32_t *center_src,
@@ -1207,7 +1217,7 @@ extern "C" int dpm_knn_self(const float *xyz, int N, int K, double cell, int32_t
     // source after we have returned, and a fill is capturable in a HIP graph)
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)len_dev, N, 1, st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(1), dim3(1024), 0, st, xyz, len_dev, N, (float)cell, hdr, start, sorted,
+    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(1), dim3(1024), 0, st, xyz, len_dev, N, (float)cell, 0.f, hdr, start, sorted,
                        tie_count);
     hipLaunchKernelGGL(knn_self_kernel, dim3(dpm_cdiv(N, WPB)), dim3(WPB * 64), 0, st, xyz, N, K, hdr, start, sorted, idx,
                        dist2, mean_dist);
@@ -1232,7 +1242,7 @@ extern "C" int dpm_point_normals(const float *xyz, int N, double radius, float *
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)len_dev, N, 1, st);
     if (e != hipSuccess) return (int)e;
     // cell edge slightly above the radius: the 3x3 block then contains every point strictly within it
-    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(1), dim3(1024), 0, st, xyz, len_dev, N, (float)(radius * 1.001), hdr, start,
+    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(1), dim3(1024), 0, st, xyz, len_dev, N, (float)(radius * 1.001), 0.f, hdr, start,
                        sorted, tie_count);
     hipLaunchKernelGGL(point_normals_kernel, dim3(dpm_cdiv(N, WPB)), dim3(WPB * 64), 0, st, xyz, N,
                        (float)(radius * radius), hdr, start, sorted, normals);

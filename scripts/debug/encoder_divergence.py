@@ -1,0 +1,56 @@
+"""debug: first stage at which the HIP encoder and the oracle diverge on one frame set (reduced configuration).
+usage: encoder_divergence.py B N start [length0]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+from deeppointmap_amd import synthetic
+from deeppointmap_amd.config import reduced_args
+from deeppointmap_amd.encoder import Encoder
+from deeppointmap_amd.weights import init_procedural
+from oracle import dpm_oracle as O
+torch.set_grad_enabled(False)
+B, N, start = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+cfg = reduced_args()
+enc = init_procedural(Encoder(cfg)).to("cuda:0")
+sd = {k: v.detach().cpu() for k, v in enc.flat().items()}
+pts, pad = synthetic.frames(B, N, start=start)
+if len(sys.argv) > 4:
+    L = int(sys.argv[4]); pad[0, L:] = True; pts[0, :, L:] = 0
+tg, to = {}, {}
+coor, fea, mask = enc(pts, pad, trace=tg)
+O.encoder_forward(sd, cfg, pts, pad, trace=to)
+for k in to:
+    if k not in tg:
+        continue
+    a, b = tg[k].cpu(), to[k]
+    if k.endswith(".idx") and not k.endswith("fps.idx"):
+        a = a.reshape(-1, a.shape[-1]).numpy(); b = b.reshape(-1, b.shape[-1]).numpy()
+        rows = [i for i in range(a.shape[0]) if set(a[i]) != set(b[i])]
+        print(f"{k:28s} rows differing as sets: {len(rows)} of {a.shape[0]}" + (f"   first {rows[0]}: got {sorted(set(a[rows[0]]) - set(b[rows[0]]))} want {sorted(set(b[rows[0]]) - set(a[rows[0]]))}" if rows else ""))
+    elif k.endswith("fps.idx"):
+        print(f"{k:28s} equal {bool((a.long() == b.long()).all())}")
+    else:
+        b = b if b.shape == a.shape else b.reshape(a.shape) if b.numel() == a.numel() else None
+        if b is None:
+            print(f"{k:28s} shapes {tuple(tg[k].shape)} vs {tuple(to[k].shape)}"); continue
+        print(f"{k:28s} max abs diff {float((a - b).abs().max()):.2e}")
+# detail of the first-level neighbour rows that differ
+k = "downsampler.0.sa.idx"
+a, b_ = tg[k].cpu(), to[k]
+Bn, Sn, Kn = b_.shape
+a = a.reshape(Bn, Sn, Kn).numpy(); bo = b_.numpy()
+xyz = pts[:, :3].transpose(1, 2).contiguous()
+ctr = tg["downsampler.0.fps.new"].cpu()
+r = cfg.encoder.radius_list[0][0]
+d_all = O.expanded_sqdist(ctr, O.push_padding_far(xyz, pad))
+shown = 0
+for f in range(Bn):
+    rows = [s_ for s_ in range(Sn) if set(a[f, s_]) != set(bo[f, s_])]
+    print(f"frame {f} (length {int((~pad[f]).sum())}): {len(rows)} rows differ; radius^2 {r * r:.6f}")
+    for s_ in rows[:3]:
+        extra_w = sorted(set(bo[f, s_]) - set(a[f, s_])); extra_g = sorted(set(a[f, s_]) - set(bo[f, s_]))
+        d = d_all[f, s_]
+        srt = d.sort()[0]
+        print(f"  row {s_}: oracle-only {[(int(i), float(d[int(i)])) for i in extra_w]} kernel-only {[(int(i), float(d[int(i)])) for i in extra_g]}; "
+              f"in radius {int((d <= r * r).sum())}, K {Kn}, K-th {float(srt[Kn - 1]):.6f}, centre index in row? nearest {int(d.argmin())} d {float(d.min()):.2e}; distinct kernel {len(set(a[f, s_]))} oracle {len(set(bo[f, s_]))}")

@@ -199,6 +199,22 @@ def test_knn_grid_equals_brute_force(ops):
         assert (a[:, -12:] == a[:, -12:, :1]).all()  # far-away centres: every slot is the nearest point
 
 
+def test_knn_grid_far_from_the_origin_equals_brute_force(ops):
+    """The reference's expanded-form distance loses absolute precision with the squared magnitude of the coordinates: 65
+    units from the origin its quantum is 5e-4, a fifth of r^2 = 0.0025, and points truly outside the radius are computed
+    inside it.  The grid's cell edge has to grow with that error (csrc/knn.hip, knn_grid_build_kernel) or the 3x3
+    neighbourhood misses them: found by scripts/fuzz_encoder.py on synthetic frames that drift away from the origin."""
+    for shift in ([-65.4, -29.1, 0.0], [5.0, -4.0, 0.3]):
+        pts = (synthetic.frame(4, 8192).t() + torch.tensor(shift)).unsqueeze(0).contiguous()
+        lens = _lengths([8192])
+        ctr = pts[:, ::8].contiguous()
+        for r, K in [(0.05, 32), (0.1, 32)]:
+            a = ops.knn_hybrid(pts.to(DEV), lens, ctr.to(DEV), K, r).cpu().numpy()
+            b = ops.knn_hybrid(pts.to(DEV), lens, ctr.to(DEV), K, r, brute=True).cpu().numpy()
+            assert idx_rows_equal_as_sets(a[0], b[0]).all(), (shift, r, K)
+            assert (a[0][:, 0] == b[0][:, 0]).all()
+
+
 def test_knn_prebuilt_grid_equals_one_call(ops):
     """dpm_knn_build_grid + dpm_knn_hybrid_prebuilt (grid sorted ahead of time, e.g. on another stream) against the
     one-call form: identical neighbour sets and nearest slots (the order of the other slots follows the grid's
@@ -333,6 +349,29 @@ def test_three_interp_vs_oracle(ops):
     bi = torch.arange(B).view(B, 1, 1)
     want = torch.cat([f1, (f2[bi, i] * w.unsqueeze(-1)).sum(2)], dim=-1)
     torch.testing.assert_close(out, want, rtol=1e-4, atol=1e-4)
+
+
+def test_three_interp_ties_at_the_third_neighbour_follow_torch_topk(ops):
+    """Mirror-symmetric key points put two coarse points at EXACTLY the same distance from a fine one; when that tie
+    straddles the third place, the reference keeps whichever torch.topk's std::nth_element (3 * 64 > S) or heap-select
+    (S >= 192) leaves in front -- not the smallest index.  One-hot coarse features make the output row the weight vector."""
+    gen = torch.Generator().manual_seed(4)
+    for S in (16, 64, 256):
+        half = (torch.randint(-8, 9, (1, S // 2, 3), generator=gen).float() * 0.125)
+        half[..., 1] = half[..., 1].abs() + 0.125
+        mirror = half * torch.tensor([1.0, -1.0, 1.0])
+        xyz2 = torch.cat([half, mirror], 1)[:, torch.randperm(S, generator=gen)].contiguous()   # every point has its mirror image
+        xyz1 = torch.randint(-8, 9, (1, 96, 3), generator=gen).float() * 0.125
+        xyz1[..., 1] = 0.0                                                                  # fine points on the mirror plane
+        f1, f2 = torch.zeros(1, 96, 4), torch.eye(S).unsqueeze(0)
+        got = ops.three_interp_cat(xyz1.to(DEV), xyz2.to(DEV), _lengths([S]), f1.to(DEV), f2.to(DEV)).cpu()[..., 4:]
+        d, i = torch.topk(O.expanded_sqdist(xyz1, xyz2), 3, dim=-1, largest=False)
+        w = 1.0 / d.clamp(min=1e-8)
+        want = torch.zeros(1, 96, S).scatter_add_(2, i, w / w.sum(-1, keepdim=True))
+        all_d = O.expanded_sqdist(xyz1, xyz2)
+        straddle = int(((all_d == d[..., 2:3]).sum(-1) > (d == d[..., 2:3]).sum(-1)).sum())
+        assert straddle > 10, (S, straddle)          # the case this test is for does occur
+        torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
 
 
 def test_group_mlp_max_vs_oracle(ops):
