@@ -4,7 +4,7 @@ import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deeppointmap_amd import synthetic
-from deeppointmap_amd.config import reduced_args
+from deeppointmap_amd.config import default_args, reduced_args
 from deeppointmap_amd.encoder import Encoder
 from deeppointmap_amd.weights import init_procedural
 from oracle import dpm_oracle as O
@@ -27,21 +27,25 @@ if os.environ.get("PINNED_DIST") == "1":
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 rng = random.Random(seed)
-cfg = reduced_args()
+FULL = os.environ.get("FULL_CONFIG") == "1"   # the shipped configuration on 16 384 - 65 536-point frames (slow oracle)
+cfg = default_args() if FULL else reduced_args()
 enc = init_procedural(Encoder(cfg)).to("cuda:0")
 sd = {k: v.detach().cpu() for k, v in enc.flat().items()}
 t0, n, bad, worst = time.time(), 0, 0, 0.0
 while time.time() - t0 < budget:
     B, N = rng.randint(1, 3), rng.choice([rng.randint(600, 3000), rng.randint(3000, 9000), 4096, 8192])
+    if FULL:
+        B, N = rng.randint(1, 2), rng.choice([65536, rng.randint(20000, 65536), 16384, rng.randint(5000, 16384)])
     start = rng.randint(0, 10_000)
     pts, pad = synthetic.frames(B, N, start=start)
     for b in range(B):
         if rng.random() < 0.5:
-            L = rng.randint(max(N // 3, 600), N)
+            L = rng.randint(max(N // 3, 600 if not FULL else 4500), N)
             pad[b, L:] = True
             pts[b, :, L:] = 0.0
     coor, fea, mask = enc(pts, pad)
-    want = O.extract_descriptors(sd, cfg, pts, pad)            # (B, C + 3, S): features, then xyz * 60
+    oc, of, _ = O.encoder_forward(sd, cfg, pts, pad, fast_fps=FULL)   # the C restatement of the sampling loop for big frames
+    want = torch.cat([of, oc * 60.0], dim=1)            # (B, C + 3, S): features, then xyz * 60
     got = torch.cat([fea, coor * 60.0], 1).cpu()
     C = fea.shape[1]
     ok_xyz = torch.equal(got[:, C:], want[:, C:])

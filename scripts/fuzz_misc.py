@@ -1,0 +1,99 @@
+"""One-off fuzz of the smaller exact pieces against the oracle / torch: the Kabsch loop with tied weights, the dual-softmax
+top-k (index sets, ties), the information matrix on shifted / rotated / ragged clouds, scan pre-processing."""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from deeppointmap_amd import ops, synthetic
+from deeppointmap_amd.registration import calculate_information_matrix_from_pcd
+from oracle import dpm_oracle as O
+
+torch.set_grad_enabled(False)
+dev = "cuda:0"
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+rng = random.Random(seed)
+g = torch.Generator().manual_seed(seed)
+
+
+def rot_angle(A, B):
+    M = A.double().T @ B.double()
+    return float(np.arctan2(float(torch.linalg.norm(M - M.T)) / (2 * 2 ** 0.5), float((torch.trace(M) - 1) / 2)))
+
+
+def rand_rot(scale):
+    v = torch.randn(3, generator=g) * scale
+    th = float(v.norm())
+    K = torch.tensor([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]]) / max(th, 1e-9)
+    return (torch.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K).float()
+
+
+t0, cnt, bad = time.time(), {"kabsch": 0, "topk": 0, "info": 0}, 0
+while time.time() - t0 < budget:
+    # ---- Kabsch loop -------------------------------------------------------------------------------------------------
+    n = rng.choice([rng.randint(31, 200), rng.randint(200, 2200), rng.randint(2200, 6000)])
+    src = torch.randn(3, n, generator=g) * rng.choice([1.0, 10.0, 40.0])
+    R0 = rand_rot(rng.choice([0.01, 0.3, 2.0]))
+    dst = R0 @ src + torch.randn(3, 1, generator=g) * 2 + rng.choice([0.01, 0.3, 3.0]) * torch.randn(3, n, generator=g)
+    kind = rng.randint(0, 2)
+    if kind == 0:
+        w = torch.rand(n, generator=g) * rng.choice([0.01, 0.4, 1.0])
+    elif kind == 1:
+        lv = rng.choice([3, 10, 60])
+        w = torch.randint(0, lv, (n,), generator=g).float() / (1.3 * lv)
+    else:
+        h = torch.rand(n // 2 + 1, generator=g) * rng.choice([0.02, 0.9])
+        w = torch.cat([h, h])[:n]
+    Ro, To, inl, rmse = O.solve_svd(w, src, dst, margins=(m := []))
+    res = ops.corr_kabsch(None, src.t().contiguous().to(dev), dst.t().contiguous().to(dev), None, None, w.to(dev), 2.0).cpu()
+    n_in = int(res[14])
+    dT, dR = float((res[9:12].view(3, 1) - To).norm()), rot_angle(res[:9].view(3, 3), Ro)
+    scale = max(1.0, float(dst.abs().max()))
+    ok = n_in == int(inl.sum()) and dT < 2e-5 * scale and dR < 2e-5
+    if not ok and min(m) > 1e-4:
+        bad += 1
+        print(f"KABSCH MISMATCH seed {seed}: n {n} kind {kind}: inliers {n_in} vs {int(inl.sum())}, dT {dT:.2e} dR {dR:.2e}, iterations {int(res[15])} vs {len(m)}, margins {[f'{x:.1e}' for x in m]}")
+    cnt["kabsch"] += 1
+    # ---- dual-softmax top-k --------------------------------------------------------------------------------------------
+    M, N = rng.choice([(256, 256), (rng.randint(8, 600), rng.randint(8, 600)), (rng.randint(600, 3000), rng.randint(64, 700))])
+    k = rng.randint(1, min(4096, M * N))
+    if rng.random() < 0.3:
+        S = torch.randint(-4, 5, (M, N), generator=g).float() / 8          # exact ties everywhere
+    else:
+        a = torch.nn.functional.normalize(torch.randn(M, 32, generator=g), dim=1)
+        b = torch.nn.functional.normalize(torch.randn(N, 32, generator=g), dim=1)
+        S = a @ b.t()
+    Sd = S.clone().to(dev)
+    val, idx = ops.dual_softmax_topk(Sd, 0.1, k)
+    P = Sd.cpu().reshape(-1)
+    hv, hi = torch.topk(P, k)
+    idx = idx.cpu().long()
+    ok = torch.equal(val.cpu(), hv) and len(set(idx.tolist())) == k and torch.equal(P[idx], val.cpu())
+    if not ok:
+        bad += 1
+        print(f"TOPK MISMATCH seed {seed}: M {M} N {N} k {k}: values equal {torch.equal(val.cpu(), hv)}, distinct {len(set(idx.tolist()))}, gathered equal {torch.equal(P[idx], val.cpu())}")
+    cnt["topk"] += 1
+    # ---- information matrix ----------------------------------------------------------------------------------------------
+    n1, n2 = rng.choice([(4096, 4096), (rng.randint(200, 9000), rng.randint(200, 9000)), (rng.randint(9000, 30000), rng.randint(9000, 30000))])
+    fa, fb = rng.randint(0, 300), rng.randint(0, 300)
+    a = synthetic.frame(fa, n1) * 60
+    b = synthetic.frame(fa + rng.randint(0, 3), n2) * 60
+    shift = torch.randn(3, 1, generator=g) * rng.choice([0.0, 5.0, 300.0])
+    a, b = a + shift, b + shift
+    SE3 = torch.eye(4)
+    SE3[:3, :3] = rand_rot(rng.choice([0.0, 0.02, 0.5]))
+    SE3[:3, 3] = torch.randn(3, generator=g) * rng.choice([0.0, 0.05, 2.0])
+    SE3[:3, 3] += (shift - SE3[:3, :3] @ shift).flatten()                  # a rotation about the clouds' own origin
+    want = O.information_matrix(a, b, SE3)
+    got = calculate_information_matrix_from_pcd(a, b, SE3, device=dev)
+    tol = 3e-4 * max(float(want.abs().max()), 1.0)
+    if float(got[3, 3]) != float(want[3, 3]) or float((got - want).abs().max()) > tol:
+        # a pair sitting on the 1 m cut (or two targets equally near) may fall either way between two fp32 evaluations
+        p1 = (SE3[:3, :3] @ a + SE3[:3, 3:4]).t()
+        d, _ = O.nn1(p1, b.t().contiguous())
+        near_cut = int(((d - 1.0).abs() < 1e-4 * (1 + float(p1.abs().max()) ** 2 * 1e-3)).sum())
+        if abs(float(got[3, 3]) - float(want[3, 3])) > near_cut:
+            bad += 1
+            print(f"INFO MISMATCH seed {seed}: n {n1} {n2} shift {shift.flatten().tolist()}: count {float(got[3, 3])} vs {float(want[3, 3])}, max diff {float((got - want).abs().max()):.3e} (tol {tol:.1e}), pairs at the cut {near_cut}")
+    cnt["info"] += 1
+print(f"seed {seed}: {cnt}, {bad} mismatches, {time.time() - t0:.0f} s")
