@@ -235,6 +235,56 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Attention for head widths other than 32 (decoder.model_channel != 256; no shipped config): one WAVE per (sequence, head,
+// query); lane j looks at the keys j, j + 64, ... with its own running max / sum / weighted value sum, the lanes are
+// merged at the end (rescaled to the wave's max).  Plain fp32 FMAs -- correct for any Decoder(args), not tuned.
+// ------------------------------------------------------------------------------------------
+template <int D, bool MASK>
+__global__ __launch_bounds__(256) void attention_generic_kernel(const float *__restrict__ Q, int ldq, long long sq,
+                                                                const float *__restrict__ Kp, int ldk, long long sk,
+                                                                const float *__restrict__ V, int ldv, long long sv,
+                                                                float *__restrict__ O, int ldo, long long so, int M, int N,
+                                                                float scale, int kv_shift, const uint8_t *__restrict__ key_mask) {
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y, b = blockIdx.z;
+    if (m >= M) return;
+    int bk = b + kv_shift;
+    if (bk >= (int)gridDim.z) bk -= (int)gridDim.z;
+    const float *q = Q + (size_t)b * sq + (size_t)m * ldq + h * D;
+    const float *Kb = Kp + (size_t)bk * sk + h * D, *Vb = V + (size_t)bk * sv + h * D;
+    const uint8_t *km = MASK ? key_mask + (size_t)bk * N : nullptr;
+    float qv[D], o[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) qv[c] = q[c] * scale, o[c] = 0.f;
+    float mx = -__builtin_inff(), l = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        if (MASK && km[n]) continue;
+        const float *kr = Kb + (size_t)n * ldk, *vr = Vb + (size_t)n * ldv;
+        float sc = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) sc = fmaf(qv[c], kr[c], sc);
+        const float nm = fmaxf(mx, sc);
+        const float corr = __expf(mx - nm), pv = __expf(sc - nm);  // exp(-inf) = 0 on a lane's first key
+        l = l * corr + pv;
+#pragma unroll
+        for (int c = 0; c < D; ++c) o[c] = fmaf(pv, vr[c], o[c] * corr);
+        mx = nm;
+    }
+    const float gm = wave_max(mx);
+    const float f = mx == -__builtin_inff() ? 0.f : __expf(mx - gm);  // a lane that saw no key contributes nothing
+    const float L = wave_sum(l * f);
+    float mine = 0.f, mine2 = 0.f;  // lane c keeps channel c (and c + 64)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const float t = wave_sum(o[c] * f);
+        if (c < 64) mine = lane == c ? t : mine;
+        else mine2 = lane == c - 64 ? t : mine2;
+    }
+    float *orow = O + (size_t)b * so + (size_t)m * ldo + h * D;
+    if (lane < D) orow[lane] = mine / L;  // every key masked: 0 / 0 = NaN, as in the reference
+    if (D > 64 && lane + 64 < D) orow[lane + 64] = mine2 / L;
+}
+
+// ------------------------------------------------------------------------------------------
 // F.normalize(x, p=2, dim=-1): x / max(||x||, 1e-12); one wave per row
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void l2norm_kernel(const float *__restrict__ X, int R, int C,
@@ -1063,7 +1113,26 @@ extern "C" int dpm_attention_masked(const float *Q, int ldq, long long sq, const
                                     int M, int N, int heads, int head_dim, int kv_shift, const uint8_t *key_mask,
                                     dpm_stream_t stream) {
     DPM_CHECK_ARG(Q && K && V && out && B >= 1 && M >= 1 && N >= 1 && heads >= 1 && kv_shift >= 0 && kv_shift < B);
-    if (head_dim != HD) return DPM_EUNSUPPORTED;
+    if (head_dim != HD) {  // other decoder widths: the generic kernel
+        const float sc = (float)(1.0 / sqrt((double)head_dim));
+        const dim3 grid(dpm_cdiv(M, 4), heads, B);
+#define DPM_ATTG(D)                                                                                                      \
+    do {                                                                                                                 \
+        if (key_mask)                                                                                                    \
+            hipLaunchKernelGGL((attention_generic_kernel<D, true>), grid, dim3(256), 0, (hipStream_t)stream, Q, ldq, sq, K, ldk, \
+                               sk, V, ldv, sv, out, ldo, so, M, N, sc, kv_shift, key_mask);                              \
+        else                                                                                                             \
+            hipLaunchKernelGGL((attention_generic_kernel<D, false>), grid, dim3(256), 0, (hipStream_t)stream, Q, ldq, sq, K, ldk, \
+                               sk, V, ldv, sv, out, ldo, so, M, N, sc, kv_shift, key_mask);                              \
+    } while (0)
+        if (head_dim == 8) DPM_ATTG(8);
+        else if (head_dim == 16) DPM_ATTG(16);
+        else if (head_dim == 64) DPM_ATTG(64);
+        else if (head_dim == 128) DPM_ATTG(128);
+        else return DPM_EUNSUPPORTED;
+#undef DPM_ATTG
+        return dpm_launch_status();
+    }
     const bool vec = ldk % 4 == 0 && ldv % 4 == 0 && sk % 4 == 0 && sv % 4 == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0 &&
                      ldo % 4 == 0 && so % 4 == 0 && ((uintptr_t)out & 15) == 0;  // 16-byte K / V loads and output stores
     const float scale = (float)(1.0 / sqrt((double)head_dim));

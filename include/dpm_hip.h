@@ -213,7 +213,9 @@ int dpm_posemb(const float *xyz, int ld, const float *dim_t, int F, int E, int R
                dpm_stream_t stream);
 
 /* Scaled-dot-product core of nn.MultiheadAttention (descriptor_attention.py:14-15,35-45):
- * out[b,m,h*d:(h+1)*d] = softmax(Q_h K_h^T / sqrt(d)) V_h; no masks, dropout 0; head_dim 32.
+ * out[b,m,h*d:(h+1)*d] = softmax(Q_h K_h^T / sqrt(d)) V_h; no masks, dropout 0.  head_dim 32 (every shipped config:
+ * model_channel 256, 8 heads) runs on the matrix cores; 8, 16, 64 and 128 (other Decoder(args)) through a generic kernel;
+ * other widths return DPM_EUNSUPPORTED.
  * Q/K/V/out: row leading dims ld*, batch strides s* (in floats). */
 int dpm_attention(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
                   const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,

@@ -59,6 +59,30 @@ def test_attention_core_vs_torch(ops):
     assert torch.equal(one, two)
 
 
+def test_attention_other_head_widths_vs_torch(ops):
+    """decoder.model_channel other than 256 (head widths 8, 16, 64, 128 at the reference's 8 heads): the generic kernel,
+    with key masks and shifted keys; a width without a kernel is refused, not mis-computed."""
+    gen = torch.Generator().manual_seed(8)
+    for d, B, M, N in [(16, 2, 100, 77), (8, 1, 33, 200), (64, 3, 64, 64), (128, 2, 50, 130)]:
+        E = 8 * d
+        q, k, v = (torch.randn(B * n, E, generator=gen) for n in (M, N, N))
+        mask = torch.rand(B, N, generator=gen) < 0.3
+        mask[:, 0] = False
+        for km, shift in ((None, 0), (mask, 0), (mask, 1 if B > 1 else 0)):
+            out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), B, M, N, 8, kv_shift=shift,
+                                key_mask=None if km is None else km.view(torch.uint8).to(DEV)).cpu()
+            qh = q.view(B, M, 8, d).transpose(1, 2).double()
+            kh = k.view(B, N, 8, d).transpose(1, 2).double().roll(-shift, 0)
+            vh = v.view(B, N, 8, d).transpose(1, 2).double().roll(-shift, 0)
+            sc = qh @ kh.transpose(-1, -2) / d ** 0.5
+            if km is not None:
+                sc = sc.masked_fill(km.roll(-shift, 0)[:, None, None, :], float("-inf"))
+            want = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B * M, E).float()
+            torch.testing.assert_close(out, want, rtol=1e-4, atol=2e-5)
+    with pytest.raises(ValueError):
+        ops.attention(torch.zeros(4, 96, device=DEV), torch.zeros(4, 96, device=DEV), torch.zeros(4, 96, device=DEV), 1, 4, 4, 8)
+
+
 def test_dual_softmax_topk_vs_torch(ops):
     gen = torch.Generator().manual_seed(7)
     for M, N, k in [(256, 256, 128), (1024, 256, 640), (300, 77, 1), (64, 64, 4096), (2048, 1024, 1536), (4096, 256, 2176)]:
