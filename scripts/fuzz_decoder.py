@@ -57,11 +57,30 @@ while time.time() - t0 < budget:
         kgap = float((cs[-2] - cs[-1]) / cs[-1]) if cs.numel() > 1 else 1.0
         # pair confidences agree with the reference to ~1e-3 relative (fp32 sums in another order through three attention
         # blocks, then exp(./0.1) twice): a k-th confidence closer than that to its neighbour can fall either way
-        cond = min(tro["margins"]) < 1e-4 or (pairs_g != pairs_o and kgap < 2e-3)
+        # ... and so can the 64 seed correspondences of the Kabsch loop (decoder.py:233-235: topk(w, 64)) when no weight
+        # exceeds 0.5 and the 64th / 65th DISTINCT weights are closer than the confidences' agreement
+        ws = tro["w"].unique().sort(descending=True)[0]
+        sgap = 1.0
+        if int((tro["w"] > 0.5).sum()) < 64 and tro["w"].numel() > 64:
+            w64 = tro["w"].sort(descending=True)[0][63]
+            below = ws[ws < w64]
+            sgap = float((w64 - below[0]) / w64) if below.numel() else 1.0
+        cond = min(tro["margins"]) < 1e-4 or (pairs_g != pairs_o and kgap < 2e-3) or sgap < 1e-4
         bad += 0 if cond else 1
         print(f"{'ill-conditioned' if cond else 'MISMATCH'} seed {seed}: M {M} N {N} num_sample {ns} masks {masks[0] is not None}: dT {dT:.2e} dR {dR:.2e} "
               f"inliers {conf.numel()} vs {co.numel()} rmse {rmse:.4f} vs {ro:.4f}; same pairs {pairs_g == pairs_o} "
               f"(k-th confidence gap {kgap:.1e}), n_corr {tr['n_corr']} vs {tro['w'].numel()}, oracle margins {[f'{m:.1e}' for m in tro['margins']]}")
+        if not cond:
+            from deeppointmap_amd import ops
+            # the Kabsch kernel on the ORACLE's correspondences: is the difference made before it or inside it?
+            res = ops.corr_kabsch(None, tro["src"].t().contiguous().cuda(), tro["dst"].t().contiguous().cuda(), None, None, tro["w"].cuda(), 2.0).cpu()
+            print(f"   kernel Kabsch on the oracle's correspondences: dT {float((res[9:12].view(3, 1) - To).norm()):.2e}, inliers {int(res[14])} vs {co.numel()}, iterations {int(res[15])} vs {len(tro['margins'])}")
+            go = {(a, b): (c, o) for a, b, c, o in zip(tr["src_index"].flatten().tolist(), tr["dst_index"].flatten().tolist(), tr["conf"].flatten().tolist(), tr["offsets"].cpu().view(-1, 3).tolist())}
+            k = tro["conf"].numel()
+            dc = max(abs(go[(a, b)][0] - c) / c for a, b, c in zip(tro["src_index"].tolist(), tro["dst_index"].tolist(), tro["conf"].tolist()) if (a, b) in go)
+            print(f"   pair confidences: max relative difference {dc:.2e}; offsets tensor {tuple(tr['offsets'].shape)}; inlier weights equal as multisets: {sorted(conf.cpu().tolist()) == sorted(co.tolist())}; "
+                  f"|x| diff {float((tr['x'].cpu().view(-1) - tro['x'].reshape(-1)).abs().max()):.2e}")
+            w = tro["w"]; print(f"   weights: {w.numel()} values, {w.unique().numel()} distinct; 64th/65th largest {w.sort(descending=True)[0][62:66].tolist()}; > 0.5: {int((w > 0.5).sum())}")
     if n % 5 == 0:  # loop detection on a small batch of the same shapes
         C = rng.randint(1, 5)
         S, D = torch.stack([desc(M) for _ in range(C)]), torch.stack([desc(N) for _ in range(C)])
