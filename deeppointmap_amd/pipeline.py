@@ -113,6 +113,9 @@ class HotPath:
                                                       order=pair_index[2] if len(pair_index) > 2 else None)
         if pcd_m is not None:
             F = pcd_m.shape[0]
+            if halo_pcd is None and any(p[0] >= F for p in pairs):
+                raise ValueError("chain mode: the frame before this batch came without its scan, so the information matrix of "
+                                 "the first edge cannot be built (pass scans for every batch of a chain, or for none)")
             if halo_pcd is not None:
                 # the batched search addresses scans of ONE tensor: it runs with the ring's sources (the grids were built
                 # for exactly these targets), and pair 0 -- whose source scan is the hand-over frame -- is redone alone
@@ -193,6 +196,16 @@ class HotPath:
         self._pending["n"] += 1
         rings = [self._ring_pairs(h[0].shape[0], dev) if h[2] is not None else None for h in hold]  # before the stream switch: a first call copies H2D
         sa.wait_stream(main)  # inputs the caller produced asynchronously on its stream (H2D copies, GPU pre-processing)
+        for points, padding, pcd_m in hold:
+            # the caller may drop its tensors as soon as submit() returns: every stream that will read them has to be on
+            # record with the allocator, or their memory is handed out again while a stage is still reading it
+            # (found by scripts/fuzz_pipeline.py: 4 % of the batches came back with a wrong information matrix)
+            for t in (points, padding):
+                if t.is_cuda:
+                    t.record_stream(sa)
+            if pcd_m is not None and pcd_m.is_cuda:
+                pcd_m.record_stream(sa)
+                pcd_m.record_stream(self._side["reg"])
         with torch.cuda.stream(sa):
             first = self.encoder.sample_first_level([h[0] for h in hold], [h[1] for h in hold]) if len(hold) > 1 else [None]
             for (points, padding, pcd_m), ring, s0 in zip(hold, rings, first):

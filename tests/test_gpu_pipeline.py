@@ -87,6 +87,49 @@ def test_streaming_pipeline_equals_plain_steps(hot):
         assert torch.equal(d0, d1) and torch.equal(t0, t1)
 
 
+def test_streaming_pipeline_survives_callers_that_drop_their_inputs(hot):
+    """submit() returns while three streams still read the batch: a caller that frees its tensors and allocates new ones
+    right away must not get its memory recycled under a running stage (the inputs are put on record with every stream
+    that reads them).  Varying batch shapes, ring and chain mode; every result bit-equal to an unpipelined step.
+    (scripts/fuzz_pipeline.py found 4 % wrong information matrices before the record_stream calls were there.)"""
+    import random
+    from deeppointmap_amd.pipeline import HotPath
+    rng = random.Random(5)
+    for chain in (False, True):
+        pipe, plain = HotPath(hot.encoder, hot.decoder), HotPath(hot.encoder, hot.decoder)
+        pipe.chain = plain.chain = chain
+        inputs, outs = [], []
+        for i in range(10):
+            F, N = rng.randint(2, 4), rng.choice([16384, 20000, 24000])
+            pts, pad = synthetic.frames(F, N, start=3 * i)
+            if i % 3 == 1:
+                pad[0, N - 3000:] = True
+                pts[0, :, N - 3000:] = 0
+            inputs.append((pts, pad))
+            p, q = pts.to(DEV), pad.to(DEV)
+            m = (p * 60).contiguous()
+            r = pipe.submit(p, q, m)
+            del p, q, m
+            junk = torch.empty(rng.randint(8, 96) << 20, device=DEV).normal_()   # takes over whatever was just freed
+            del junk
+            if r is not None:
+                outs.append((r[0].clone(), r[1].clone()))
+        outs += [(d.clone(), t.clone()) for d, t in pipe.flush()]
+        torch.cuda.synchronize()
+        assert len(outs) == len(inputs)
+        for (pts, pad), (d, t) in zip(inputs, outs):
+            p = pts.to(DEV)
+            d0, _, t0 = plain.step(p, pad.to(DEV), (p * 60).contiguous(), materialize=False)
+            assert torch.equal(d, d0) and torch.equal(t, t0), chain
+    # a chain whose predecessor came without its scan cannot build the first edge's information matrix: say so
+    pipe = HotPath(hot.encoder, hot.decoder)
+    pipe.chain = True
+    pts, pad = synthetic.frames(2, 16384)
+    pipe.step(pts.to(DEV), pad.to(DEV), None, materialize=False)
+    with pytest.raises(ValueError, match="chain mode"):
+        pipe.step(pts.to(DEV), pad.to(DEV), (pts * 60).to(DEV), materialize=False)
+
+
 def test_five_consecutive_full_size_pairs_vs_reference(hot):
     """BASELINE.json config 2 in miniature: six 65 536-point scans, five odometry edges, every pose within the
     north_star tolerance of what the REFERENCE computes end to end (tests/golden/poses_full.npz)."""
