@@ -160,7 +160,7 @@ def preprocess_scans(scans, voxel_size: float = 0.3, min_dis: float = 1.0, max_d
                                                float(ratio), int(max_cells), ops._ptr(out), ops._ptr(idx), N,
                                                ops._ptr(status[b]), ops._ptr(work[b % len(side)]), st.cuda_stream),
                        "dpm_preprocess_scan")
-            x.record_stream(st)
+            out.record_stream(cur)  # allocated on the side stream, packed into the batch on the caller's stream below
             outs.append(out)
     for st in side:
         cur.wait_stream(st)
