@@ -761,7 +761,9 @@ static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t 
     DPM_CHECK_ARG(algo >= 0 && algo <= 7);
     hipStream_t st = (hipStream_t)stream;
     if (start && (algo == 3 || algo == 4 || algo == 6 || algo == 7)) return DPM_EUNSUPPORTED;  // start index: algos 1, 2, 5
-    if (algo == 0) algo = (N > 16384 && N <= 65536) ? 5 : (N > 16384 ? 2 : 1);  // 5: shortest chain (1.05 us per pick); 4: fewest instructions
+    // beyond 65 536 points per frame (no shipped pipeline produces such frames: raw scans are voxel-sampled first) the
+    // bucket kernels' one-bucket-per-lane layout ends; the plain kernel with `closest` in the workspace takes over
+    if (algo == 0) algo = (N > 16384 && N <= 65536) ? 5 : (N > 16384 && N <= 64 * MAXBUCKETS ? 2 : 1);  // 5: shortest chain (1.05 us per pick); 4: fewest instructions
     if (algo >= 5) {  // (6 / 7: the speculative multi-pick kernel, two / three picks per round) the bucket kernel over the Sort-Tile-Recursive packing of fps_tree.hip (fewer buckets survive a round)
         DPM_CHECK_ARG(workspace != nullptr);
         if (N <= 16384 || N > 65536) return DPM_EUNSUPPORTED;

@@ -75,7 +75,7 @@ int dpm_gather_frames(const float *src, long long frame_stride, int rows, int ld
 size_t dpm_fps_workspace_bytes(int B, int N, int K);
 int dpm_fps(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
             float *new_xyz, int32_t *new_lengths, void *workspace, dpm_stream_t stream);
-/* same, with the algorithm forced: 0 = auto (1 up to 16 384 points, 5 up to 65 536), 1 = register / brute force,
+/* same, with the algorithm forced: 0 = auto (1 up to 16 384 points, 5 up to 65 536, 1 again beyond), 1 = register / brute force,
  * 2 = bucket-pruned over Z-ordered grid cells, 3 = 2 with speculative two-picks-per-round, 4 = one wave per frame over a
  * two-level box tree (16 384 < N <= 65 536), 5 = the bucket kernel over the Sort-Tile-Recursive packing of 4 (same range),
  * 6 / 7 = 5 with two / three speculative picks per round.  All give identical bits; the tests run all of them. */

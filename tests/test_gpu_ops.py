@@ -128,6 +128,17 @@ def test_fps_tree_ragged_batch_full_size(ops):
     assert nl2.cpu().tolist() == [300, 100, 1, 1]
 
 
+def test_fps_beyond_65536_points_per_frame(ops):
+    """The bucket kernels end at 65 536 points per frame; larger frames (the reference takes any size) fall back to the
+    plain kernel and stay bit-exact."""
+    gen = torch.Generator().manual_seed(6)
+    xyz = torch.randn(2, 70000, 3, generator=gen) * torch.tensor([30.0, 30.0, 2.0])
+    lens = torch.tensor([70000, 66000], dtype=torch.int32)
+    got = ops.fps(xyz.to(DEV), lens.to(DEV), 300)[0].cpu()
+    for b in range(2):
+        assert torch.equal(got[b].long(), O.fps_indices_fast(xyz[b], int(lens[b]), 300)), b
+
+
 def test_fps_all_levels_sizes(ops):
     gen = torch.Generator().manual_seed(6)
     for N, K in [(4096, 1024), (1024, 256), (256, 64), (64, 16), (16, 16), (3, 8)]:
