@@ -221,6 +221,14 @@ class Decoder(ParamTree):
             x, xyz_s, y, xyz_d, B, M, N = self._descriptor_attention_forward(src_descriptor, dst_descriptor, *masks)
         E = self.model_channel
         k = self._num_pairs(num_sample, M, N)
+        if k < 1:
+            # fewer than two pairs requested (e.g. one token against one): the reference selects nothing, its Kabsch loop
+            # averages an empty set and it returns NaN poses with no inliers (decoder.py:227-265) -- so do we
+            res = torch.full((B, ops.RES_HDR), float("nan"), device=x.device, dtype=torch.float32)
+            res[:, 13:16] = 0.0
+            if header_out is not None:
+                header_out.copy_(res)
+            return res
         # similarity head -> L2 normalise -> M x N similarity -> dual softmax -> top-k   (decoder.py:181-191)
         if (M == N and x.is_contiguous() and y.is_contiguous() and
                 x.untyped_storage().data_ptr() == y.untyped_storage().data_ptr() and
