@@ -26,6 +26,7 @@ SOURCES = {
     "decoder_ops.hip": [],
     "infomat.hip": [],
     "preprocess.hip": [],
+    "voxel_sample.hip": [],
 }
 
 

@@ -15,12 +15,12 @@ struct VI {
 };
 
 template <bool LARGEST>
-__device__ __forceinline__ bool vi_before(const VI &a, const VI &b) {
+__host__ __device__ __forceinline__ bool vi_before(const VI &a, const VI &b) {
     return LARGEST ? a.v > b.v : a.v < b.v;
 }
 
 template <bool LARGEST>
-__device__ void vi_adjust_heap(VI *a, int hole, int len, VI value) {  // std::__adjust_heap + __push_heap
+__host__ __device__ void vi_adjust_heap(VI *a, int hole, int len, VI value) {  // std::__adjust_heap + __push_heap
     const int top = hole;
     int sc = hole;
     while (sc < (len - 1) / 2) {
@@ -37,7 +37,7 @@ __device__ void vi_adjust_heap(VI *a, int hole, int len, VI value) {  // std::__
     a[hole] = value;
 }
 template <bool LARGEST>
-__device__ void vi_heap_select(VI *a, int first, int middle, int last) {  // std::__heap_select
+__host__ __device__ void vi_heap_select(VI *a, int first, int middle, int last) {  // std::__heap_select
     const int len = middle - first;
     if (len >= 2)
         for (int parent = (len - 2) / 2;; --parent) {
@@ -52,7 +52,7 @@ __device__ void vi_heap_select(VI *a, int first, int middle, int last) {  // std
         }
 }
 template <bool LARGEST>
-__device__ void vi_nth_element(VI *a, int n, int nth) {  // std::nth_element -> std::__introselect
+__host__ __device__ void vi_nth_element(VI *a, int n, int nth) {  // std::nth_element -> std::__introselect
     int first = 0, last = n;
     int depth = 2 * (31 - __builtin_clz(n));
     auto sw = [&](int x, int y) {
@@ -217,4 +217,99 @@ __device__ void vi_nth_element_wave(LdsVI a, int n, int nth, LdsU16 up, LdsU16 d
         }
     }
     fence();
+}
+
+
+// ---- torch.topk(sorted=True) in full: not only WHICH k elements, but the ORDER they come out in (TopKImpl.h: after
+// std::partial_sort the first k ARE sorted -- __heap_select + __sort_heap --; on the nth_element branch the first k - 1
+// are sorted by std::sort -- __introsort_loop + __final_insertion_sort -- and the k-th stays where nth_element left it).
+// Neither sort is stable, so among equal values the order is again a matter of libstdc++'s data movement.  The voxel
+// sampler needs it: it returns points in the order of a topk over integer voxel populations, which tie all the time.
+// One thread; the caller's VI row is permuted in place and its first k entries are the answer.
+template <bool LARGEST>
+__host__ __device__ void vi_sort_heap(VI *a, int first, int last) {  // std::__sort_heap (via __pop_heap)
+    while (last - first > 1) {
+        --last;
+        const VI value = a[last];
+        a[last] = a[first];
+        vi_adjust_heap<LARGEST>(a + first, 0, last - first, value);
+    }
+}
+template <bool LARGEST>
+__host__ __device__ void vi_unguarded_linear_insert(VI *a, int last) {
+    const VI val = a[last];
+    int next = last - 1;
+    while (vi_before<LARGEST>(val, a[next])) a[last] = a[next], last = next, --next;
+    a[last] = val;
+}
+template <bool LARGEST>
+__host__ __device__ void vi_insertion_sort(VI *a, int first, int last) {  // std::__insertion_sort
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (vi_before<LARGEST>(a[i], a[first])) {
+            const VI val = a[i];
+            for (int j = i; j > first; --j) a[j] = a[j - 1];
+            a[first] = val;
+        } else vi_unguarded_linear_insert<LARGEST>(a, i);
+    }
+}
+template <bool LARGEST>
+__host__ __device__ void vi_sort(VI *a, int first, int last) {  // std::sort -> std::__sort
+    if (first == last) return;
+    // __introsort_loop; its recursion on the right part becomes an explicit stack (depth <= 2 lg n <= 64)
+    int stack_first[64], stack_last[64], stack_depth[64], sp = 0;
+    int lo0 = first, hi0 = last, depth = 2 * (31 - __builtin_clz((unsigned)(last - first)));
+    while (true) {
+        while (hi0 - lo0 > 16) {
+            if (depth == 0) {  // __partial_sort(first, last, last)
+                vi_heap_select<LARGEST>(a, lo0, hi0, hi0);
+                vi_sort_heap<LARGEST>(a, lo0, hi0);
+                break;
+            }
+            --depth;
+            auto sw = [&](int x, int y) {
+                const VI t = a[x];
+                a[x] = a[y], a[y] = t;
+            };
+            const int A = lo0 + 1, B = lo0 + (hi0 - lo0) / 2, C = hi0 - 1;  // __move_median_to_first(first, ...)
+            if (vi_before<LARGEST>(a[A], a[B])) {
+                if (vi_before<LARGEST>(a[B], a[C])) sw(lo0, B);
+                else if (vi_before<LARGEST>(a[A], a[C])) sw(lo0, C);
+                else sw(lo0, A);
+            } else if (vi_before<LARGEST>(a[A], a[C])) sw(lo0, A);
+            else if (vi_before<LARGEST>(a[B], a[C])) sw(lo0, C);
+            else sw(lo0, B);
+            const VI pivot = a[lo0];  // __unguarded_partition(first + 1, last, first)
+            int lo = lo0 + 1, hi = hi0;
+            while (true) {
+                while (vi_before<LARGEST>(a[lo], pivot)) ++lo;
+                --hi;
+                while (vi_before<LARGEST>(pivot, a[hi])) --hi;
+                if (!(lo < hi)) break;
+                sw(lo, hi);
+                ++lo;
+            }
+            // __introsort_loop(cut, last, depth) runs to completion BEFORE the left part continues: the order of the two
+            // does not matter to the result (disjoint ranges), so the right part is parked on the stack
+            stack_first[sp] = lo, stack_last[sp] = hi0, stack_depth[sp] = depth, ++sp;
+            hi0 = lo;
+        }
+        if (sp == 0) break;
+        --sp, lo0 = stack_first[sp], hi0 = stack_last[sp], depth = stack_depth[sp];
+    }
+    if (last - first > 16) {  // __final_insertion_sort
+        vi_insertion_sort<LARGEST>(a, first, first + 16);
+        for (int i = first + 16; i != last; ++i) vi_unguarded_linear_insert<LARGEST>(a, i);
+    } else vi_insertion_sort<LARGEST>(a, first, last);
+}
+// the whole of topk_impl_loop for one row of n (value, index) pairs, sorted=True; 0 < k <= n
+template <bool LARGEST>
+__host__ __device__ void vi_topk_sorted(VI *a, int n, int k) {
+    if ((long long)k * 64 <= n) {  // std::partial_sort(begin, begin + k, end)
+        vi_heap_select<LARGEST>(a, 0, k, n);
+        vi_sort_heap<LARGEST>(a, 0, k);
+    } else {
+        vi_nth_element<LARGEST>(a, n, k - 1);
+        vi_sort<LARGEST>(a, 0, k - 1);
+    }
 }

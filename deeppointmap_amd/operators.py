@@ -4,8 +4,8 @@ keyword-only call convention (`self.sample(points=..., points_padding=..., K=...
 (float tensors / int64 index tensors on the input's device), so reference code that uses the tables
 (pointnext.py:35-36,45,49,82,91) runs unchanged.  The '-t3d' names are aliases: there is one backend.
 
-Not implemented: `Sampler('voxel')` (no shipped config selects it).
-`random_start_point=True` draws its start indices from Python's `random` exactly as the reference does.
+`Sampler('voxel')` (no shipped config selects it) is the voxel-grid kernel chain of
+csrc/voxel_sample.hip.  `random_start_point=True` draws its start indices from Python's `random` exactly as the reference does.
 """
 from __future__ import annotations
 
@@ -76,5 +76,13 @@ class Sampler:
         return gathered.masked_fill(mask.unsqueeze(-1), 0.0), mask
 
     @staticmethod
-    def voxel(*a, **k):
-        raise NotImplementedError("Sampler('voxel') is not selected by any shipped config and is not implemented")
+    def voxel(points: torch.Tensor, points_padding: torch.Tensor, K: int, voxel_size: float = 0.3,
+              sample_range: float = 1.0) -> Tuple[torch.Tensor, torch.Tensor]:
+        """utils.py:150-207 -> (sampled points (B,K,D): per occupied voxel the point nearest its centre, the K most
+        populated voxels in torch.topk's order when there are more than K, zero rows at padding; padding mask (B,K)).
+        K=None (one frame): every occupied voxel, ascending voxel id."""
+        pts = points.to(torch.float32).contiguous()
+        idx, _ = ops.voxel_sample(pts, points_padding, K, voxel_size, sample_range)
+        mask = idx < 0
+        gathered = torch.gather(points, 1, idx.clamp(min=0).long().unsqueeze(-1).expand(-1, -1, points.shape[-1]))
+        return gathered.masked_fill(mask.unsqueeze(-1), 0.0), mask

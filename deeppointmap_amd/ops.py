@@ -199,6 +199,44 @@ def ball_query(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tenso
     return idx
 
 
+VOXEL_SAMPLER_MAX_CELLS = 1 << 28   # 3 GB of grid per frame; finer grids than that are refused
+
+
+def voxel_sample(points: torch.Tensor, padding: torch.Tensor, K: Optional[int], voxel_size: float = 0.3,
+                 sample_range: float = 1.0):
+    """Sampler.voxel (utils.py:150-207): points (B,N,D) float32, padding (B,N) bool -> (sel (B,cap) int32 original
+    indices in the reference's output order, -1 = padding; n_unique (B,) int32 occupied voxels).  cap = K, or the number
+    of occupied voxels for K=None (B must be 1 then, as in the reference).  One host read of the grid sizes (the
+    reference walks every frame on the host), a second one for K=None."""
+    _chk(points, torch.float32, "points")
+    if padding.dtype != torch.bool or tuple(padding.shape) != tuple(points.shape[:2]):
+        raise ValueError("points_padding must be a (B,N) bool tensor")
+    B, N, D = points.shape
+    if K is None and B != 1:
+        raise ValueError("K=None takes one frame (utils.py:200)")
+    lib, dev, st = _lib.load(), points.device, _stream(points)
+    pad = padding.contiguous().view(torch.uint8)
+    hdr = torch.empty(B, 8, device=dev, dtype=torch.float32)
+    _lib.check(lib.dpm_voxel_sampler_bounds(_ptr(points), _ptr(pad), B, N, D, float(voxel_size), float(sample_range),
+                                            _ptr(hdr), st), "dpm_voxel_sampler_bounds")
+    dims = hdr[:, 3:6].double().cpu()
+    if not bool(torch.isfinite(dims).all()):
+        raise ValueError("voxel sampler: the frame's bounding box is not finite")
+    cells = int(dims.prod(1).max().item())
+    if cells > VOXEL_SAMPLER_MAX_CELLS:
+        raise ValueError(f"voxel sampler: {cells} grid cells per frame exceed {VOXEL_SAMPLER_MAX_CELLS}")
+    ws = torch.empty(lib.dpm_voxel_sampler_workspace_bytes(B, N, cells), device=dev, dtype=torch.uint8)
+    cap = N if K is None else int(K)
+    sel = torch.empty(B, cap, device=dev, dtype=torch.int32)
+    n_unique = torch.empty(B, device=dev, dtype=torch.int32)
+    _lib.check(lib.dpm_voxel_sampler_select(_ptr(points), _ptr(pad), B, N, D, float(voxel_size), float(sample_range),
+                                            _ptr(hdr), cells, -1 if K is None else int(K), _ptr(sel), cap,
+                                            _ptr(n_unique), _ptr(ws), st), "dpm_voxel_sampler_select")
+    if K is None:
+        sel = sel[:, :int(n_unique[0].item())]
+    return sel, n_unique
+
+
 PROJECTED_COUT = (32, 64, 128, 256, 512)
 
 # Tensors derived from weights alone (a packed copy of weight columns, the product of two weight matrices) are

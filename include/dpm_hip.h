@@ -119,6 +119,37 @@ int dpm_knn_hybrid_prebuilt(const float *points, const int32_t *lengths, const f
 int dpm_ball_query(const float *points, const int32_t *lengths, const float *centers, int B, int N, int S,
                    int K, double radius, int32_t *idx, dpm_stream_t stream);
 
+/* Sampler.voxel (network/encoder/utils.py:150-207): per frame, the point nearest the centre of every occupied voxel
+ * (smallest index among equals) among the points within `sample_range` of the origin, in ascending voxel-id order; if
+ * more than K voxels are occupied, the K most populated ones in the order torch.topk(counts, K) returns them (its CPU
+ * kernel's choice and order among equal counts, replayed).  points (B,N,D) with D >= 3 (xyz first), padding (B,N)
+ * uint8 (1 = padded: moved to 2*sample_range before the bounding box is taken, as the reference does).
+ * Two calls, because the grid size is data dependent:
+ *   dpm_voxel_sampler_bounds  -> hdr (B,8) floats: xyz_min[3], X, Y, Z (integer-valued, utils.py:159-161), 0, 0;
+ *                                the caller reads X*Y*Z back and sizes the workspace for max_cells >= max_b X*Y*Z;
+ *   dpm_voxel_sampler_select  -> sel (B,cap) original point indices in output order, -1 = padding rows
+ *                                (utils.py:192-198), and n_unique (B) = occupied voxels.  K >= 1: cap == K;
+ *                                K < 0 (the reference's K=None, B == 1 there): cap == N, all voxels.
+ *                                A frame whose grid exceeds max_cells (or is not finite) gets hdr[6] = 1 and no points.
+ *                                hdr[7] = 1 marks a frame where two points of a voxel were exactly equally near its
+ *                                centre: the reference's pick then follows its unstable torch.sort, which one thread
+ *                                replays over the frame's N distances (exact, slow: lattices / duplicated points only).
+ * N <= 2^24.  workspace: dpm_voxel_sampler_workspace_bytes(B, N, max_cells). */
+int dpm_voxel_sampler_bounds(const float *points, const uint8_t *padding, int B, int N, int D, double voxel_size,
+                             double sample_range, float *hdr, dpm_stream_t stream);
+size_t dpm_voxel_sampler_workspace_bytes(int B, int N, long long max_cells);
+int dpm_voxel_sampler_select(const float *points, const uint8_t *padding, int B, int N, int D, double voxel_size,
+                             double sample_range, float *hdr, long long max_cells, int K, int32_t *sel, int cap,
+                             int32_t *n_unique, void *workspace, dpm_stream_t stream);
+
+/* HOST function (no GPU involved): torch.topk(values, k, largest, sorted=True) on one row of n floats without NaNs, by
+ * the step-by-step replay of its CPU kernel that the device code uses (csrc/topk_emulate.h, same source compiled for
+ * the host) -- which elements survive and in which order among equal values.  out_idx (k).  Exists so that the replay
+ * can be held to torch.topk by tests that run without a GPU. */
+int dpm_host_topk_replay(const float *values, int n, int k, int largest, int32_t *out_idx);
+/* Same for torch.sort(values, descending, stable=False) -> out_idx (n): std::sort over (value, index) pairs. */
+int dpm_host_sort_replay(const float *values, int n, int descending, int32_t *out_idx);
+
 /* SetAbstraction / LocalAggregation body (network/encoder/pointnext.py:52-61,97-107):
  * out[b,s,:] = max_k relu(LN(W [fea[idx[b,s,k]], (xyz[idx]-center)/radius] + bias)).
  * W (Cout, Cin+3) row-major exactly as the Conv2d weight (Cout,Cin+3,1,1): first Cin columns

@@ -106,6 +106,54 @@ def fps(points: Tensor, padding: Tensor, K: int, fast: bool = False) -> Tuple[Te
 
 
 # ----------------------------------------------------------------------------------------------
+# a20  voxel sampler                                    network/encoder/utils.py:150-207
+# ----------------------------------------------------------------------------------------------
+def voxel_sample(points: Tensor, padding: Tensor, K: Optional[int], voxel_size: float = 0.3,
+                 sample_range: float = 1.0) -> Tuple[Tensor, Tensor, Tensor]:
+    """points (B,N,D), padding (B,N) bool -> (sampled (B,cap,D), mask (B,cap), original indices (B,cap), -1 = padding).
+    Per frame: padded points sit at 2*sample_range (they stretch the grid and are then out of range); every point
+    within sample_range belongs to voxel trunc((p - min) / voxel_size); a voxel is represented by its point nearest
+    the voxel centre (among exactly equal distances: the one torch.sort -- not stable on the CPU -- puts first,
+    utils.py:174-183) and voxels come out in ascending id (np.unique), or -- more than K of them -- as
+    torch.topk(population, K) orders the K fullest (utils.py:187-189)."""
+    B, N, D = points.shape
+    f32 = torch.float32
+    vs, half = torch.tensor(voxel_size, dtype=f32), torch.tensor(voxel_size / 2, dtype=f32)
+    out_idx = []
+    for b in range(B):
+        xyz = points[b, :, :3].to(f32).clone()
+        xyz[padding[b]] = 2 * sample_range
+        lo, hi = xyz.min(0).values, xyz.max(0).values
+        dims = torch.trunc((hi - lo) / vs) + 1                                   # X, Y, Z as floats (utils.py:159-161)
+        inside = (xyz[:, 0] * xyz[:, 0] + xyz[:, 1] * xyz[:, 1]) + xyz[:, 2] * xyz[:, 2] <= torch.tensor(sample_range * sample_range, dtype=f32)
+        rel = xyz - lo
+        v = torch.trunc(rel / vs).to(torch.int32)
+        vid = ((v[:, 0].to(f32) + v[:, 1].to(f32) * dims[0]) + (v[:, 2].to(f32) * dims[0]) * dims[1]).to(torch.int32)
+        d = (rel - v.to(f32) * vs) - half
+        dis = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        keep = torch.nonzero(inside).flatten()
+        # representative of a voxel = its point with the smallest rank in torch.sort's order of ALL N distances
+        rank = torch.empty(N, dtype=torch.int64)
+        rank[torch.sort(dis).indices] = torch.arange(N)
+        order = np.lexsort((rank[keep].numpy(), vid[keep].numpy()))               # by voxel, then rank
+        sv = vid[keep].numpy()[order]
+        starts = np.flatnonzero(np.r_[True, sv[1:] != sv[:-1]]) if len(sv) else np.zeros(0, np.int64)
+        first = keep.numpy()[order][starts]                                      # ascending voxel id
+        count = np.diff(np.r_[starts, len(sv)])
+        if K is not None and len(first) > K:
+            first = first[torch.topk(torch.from_numpy(count.astype(np.int64)), k=K).indices.numpy()]
+        out_idx.append(torch.from_numpy(first.astype(np.int64)))
+    cap = K if K is not None else len(out_idx[0])
+    assert K is not None or B == 1
+    idx = torch.full((B, cap), -1, dtype=torch.int64)
+    for b, i in enumerate(out_idx):
+        idx[b, :len(i)] = i
+    mask = idx < 0
+    sampled = torch.gather(points, 1, idx.clamp(min=0).unsqueeze(-1).expand(-1, -1, D)).masked_fill(mask.unsqueeze(-1), 0.0)
+    return sampled, mask, idx
+
+
+# ----------------------------------------------------------------------------------------------
 # a4  kNN-within-radius ("hybrid") grouping             network/encoder/utils.py:76-89, 288-295
 # ----------------------------------------------------------------------------------------------
 def expanded_sqdist(a: Tensor, b: Tensor) -> Tensor:

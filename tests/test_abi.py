@@ -39,6 +39,34 @@ def test_version_and_error_strings_need_no_gpu():
         _lib.check(1, "x")
 
 
+def test_host_replay_of_torch_topk_and_sort():
+    """csrc/topk_emulate.h compiled for the host (dpm_host_topk_replay / dpm_host_sort_replay) against torch itself on
+    tie-heavy rows: which elements, and in which order among equal values -- both topk branches (partial_sort for
+    k * 64 <= n, nth_element + sort otherwise), largest and smallest, and the unstable full sort.  The device code that
+    has to agree with the reference on ties (voxel sampler, Kabsch seeds, neighbour queries) runs this source."""
+    import numpy as np
+    import torch
+    from deeppointmap_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for trial in range(600):
+        n = int(rng.integers(1, 4000))
+        k = int(rng.integers(1, n + 1)) if trial % 3 else max(1, n // int(rng.integers(64, 300)))
+        v = rng.integers(0, int(rng.choice([2, 3, 7, 40, 1000])), size=n).astype(np.float32)
+        largest = trial % 4 != 0
+        want = torch.topk(torch.from_numpy(v), k, largest=largest).indices.numpy()
+        got = np.zeros(k, np.int32)
+        assert lib.dpm_host_topk_replay(v.ctypes.data, n, k, int(largest), got.ctypes.data) == 0
+        assert np.array_equal(want, got), (trial, n, k, largest)
+        # integer populations take the same kernel in torch (the voxel sampler's case)
+        want_i = torch.topk(torch.from_numpy(v.astype(np.int64)), k, largest=largest).indices.numpy()
+        assert np.array_equal(want_i, got)
+        if trial % 3 == 0:
+            perm = np.zeros(n, np.int32)
+            assert lib.dpm_host_sort_replay(v.ctypes.data, n, int(not largest), perm.ctypes.data) == 0
+            assert np.array_equal(torch.sort(torch.from_numpy(v), descending=not largest).indices.numpy(), perm)
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from deeppointmap_amd import _lib, ops

@@ -497,8 +497,78 @@ def test_operator_tables_match_reference_semantics():
     gi = torch.where(gi == 3000, first, gi)
     valid = first[..., 0] < 3000  # rows with at least one point in range (the reference indexes out of range otherwise)
     assert torch.equal(bl[valid], gi[valid])
-    with pytest.raises(NotImplementedError):
-        Sampler("voxel")(points=pts, points_padding=pad, K=4)
+
+
+def _voxel_cases():
+    import sys
+    from conftest import GOLDEN
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    import voxel_cases
+    return voxel_cases.cases()
+
+
+def test_voxel_sampler_vs_reference_fixture():
+    """Sampler('voxel') (utils.py:150-207) against the reference's own outputs (tests/golden/make_golden_voxel.py): the
+    same points in the same order, bit for bit -- both torch.topk branches over tied voxel populations, K=None, ragged
+    frames with feature channels, fewer voxels than K, an empty frame, and the exact-distance-tie frames (lattices,
+    duplicated points) whose pick follows the reference's unstable torch.sort."""
+    from deeppointmap_amd.operators import Sampler
+    g = load_golden("voxel_sampler.npz")
+    cases = _voxel_cases()
+    assert len(cases) >= 10
+    for name, (pts, pad, K, vs, sr) in cases.items():
+        new, mask = Sampler("voxel")(points=pts.to(DEV), points_padding=pad.to(DEV), K=K, voxel_size=vs, sample_range=sr)
+        assert new.dtype == torch.float32 and mask.dtype == torch.bool
+        assert tuple(new.shape) == g[name + ".sampled"].shape, name
+        assert np.array_equal(new.cpu().numpy(), g[name + ".sampled"]), name
+        assert np.array_equal(mask.cpu().numpy(), g[name + ".mask"]), name
+
+
+def test_voxel_sampler_fuzz_vs_oracle(ops):
+    """random clouds / grids / K against the oracle's restatement (itself held to the reference fixture on the CPU), and
+    the slow-path flag: set on lattice frames, clear on generic ones"""
+    g = torch.Generator().manual_seed(77)
+    flagged = 0
+    for trial in range(40):
+        B = 1 if trial % 5 == 0 else int(torch.randint(1, 5, (1,), generator=g))
+        N = int(torch.randint(40, 9000, (1,), generator=g))
+        D = 3 + trial % 3
+        pts = torch.rand(B, N, D, generator=g) * 2 - 1
+        pts[..., :3] *= torch.tensor([1.3, 0.9, 0.2])
+        lattice = trial % 4 == 1
+        if lattice:
+            pts[..., :3] = torch.round(pts[..., :3] * 8) / 8
+        pad = torch.zeros(B, N, dtype=torch.bool)
+        if trial % 2:
+            for b in range(B):
+                pad[b, int(torch.randint(1, N, (1,), generator=g)):] = True
+        vs, sr = [0.3, 0.07, 0.15, 0.03][trial % 4], [1.0, 0.6, 1.5][trial % 3]
+        K = None if B == 1 else [8, 50, 400, 3000][trial % 4]
+        want, wmask, widx = O.voxel_sample(pts, pad, K, vs, sr)
+        sel, n_unique = ops.voxel_sample(pts.to(DEV), pad.to(DEV), K, vs, sr)
+        assert torch.equal(sel.cpu().long(), widx), (trial, B, N, K, vs, sr)
+        flagged += int(lattice)
+    assert flagged >= 5
+    # the slow path is taken exactly when a voxel's nearest distance is shared
+    lib_pts = torch.rand(1, 2000, 3, generator=g) * 2 - 1
+    from deeppointmap_amd import _lib
+    from deeppointmap_amd.ops import _ptr, _stream
+    for lattice in (False, True):
+        p = (torch.round(lib_pts * 8) / 8 if lattice else lib_pts).to(DEV).contiguous()
+        padm = torch.zeros(1, 2000, dtype=torch.uint8, device=DEV)
+        hdr = torch.empty(1, 8, device=DEV)
+        lib = _lib.load()
+        _lib.check(lib.dpm_voxel_sampler_bounds(_ptr(p), _ptr(padm), 1, 2000, 3, 0.3, 1.0, _ptr(hdr), _stream(p)), "bounds")
+        cells = int(hdr[0, 3:6].double().prod().item())
+        ws = torch.empty(lib.dpm_voxel_sampler_workspace_bytes(1, 2000, cells), dtype=torch.uint8, device=DEV)
+        sel = torch.empty(1, 16, dtype=torch.int32, device=DEV)
+        nu = torch.empty(1, dtype=torch.int32, device=DEV)
+        _lib.check(lib.dpm_voxel_sampler_select(_ptr(p), _ptr(padm), 1, 2000, 3, 0.3, 1.0, _ptr(hdr), cells, 16, _ptr(sel), 16,
+                                                _ptr(nu), _ptr(ws), _stream(p)), "select")
+        assert float(hdr[0, 7]) == (1.0 if lattice else 0.0) and float(hdr[0, 6]) == 0.0
+    with pytest.raises(ValueError):   # a grid finer than the cell budget is refused, not truncated
+        ops.voxel_sample(lib_pts.to(DEV), torch.zeros(1, 2000, dtype=torch.bool, device=DEV), 8, 1e-4, 1.0)
 
 
 def test_linear_bf16x3_split_is_exact_and_fp32_accurate(ops):

@@ -34,6 +34,22 @@ def test_fps_c_equals_torch_loop():
     assert torch.equal(O.fps_indices(pts, 2500, 300), O.fps_indices_fast(pts, 2500, 300))
 
 
+def test_voxel_sampler_vs_reference():
+    """oracle.voxel_sample against the reference's Sampler('voxel') outputs (tests/golden/make_golden_voxel.py)"""
+    import sys
+    from conftest import GOLDEN
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    import voxel_cases
+    g = load_golden("voxel_sampler.npz")
+    cases = voxel_cases.cases()
+    assert len(cases) >= 10
+    for name, (pts, pad, K, vs, sr) in cases.items():
+        new, mask, idx = O.voxel_sample(pts, pad, K, vs, sr)
+        assert np.array_equal(new.numpy(), g[name + ".sampled"]), name
+        assert np.array_equal(mask.numpy(), g[name + ".mask"]), name
+
+
 def test_hybrid_query_vs_reference():
     g = load_golden("knn.npz")
     names = sorted({k.rsplit(".", 1)[0] for k in g if k.endswith(".idx")})
