@@ -80,3 +80,13 @@ def reduced_args() -> Cfg:
     a = default_args()
     a.encoder.npoint = [512, 256, 128, 64, 16]
     return a
+
+
+def reduced_voxel_args() -> Cfg:
+    """reduced_args with voxel samplers at the first and third stage (pointnext.py:21,29-32: the one sampler option no
+    shipped config selects); the first keeps the 512 fullest of a few thousand voxels (top-k branch), the third finds
+    fewer voxels than it may keep (padded level)."""
+    a = reduced_args()
+    a.encoder.sample = [{"type": "voxel", "size": 0.02, "range": 1.0}, {"type": "fps-t3d"},
+                        {"type": "voxel", "size": 0.25, "range": 1.0}, {"type": "fps-t3d"}, {"type": "fps-t3d"}]
+    return a

@@ -30,16 +30,18 @@ class Encoder(ParamTree):
         self.downsample_layers = len(self.encoder_cfg.npoint)
         self.upsample_layers = self.encoder_cfg.upsample_layers
         for s in self.encoder_cfg.sample:
-            if s["type"] not in ("fps", "fps-t3d"):
-                raise NotImplementedError(f"sampler {s['type']!r}: only farthest point sampling is implemented "
-                                          "(all shipped configs use fps-t3d)")
+            if s["type"] not in ("fps", "fps-t3d", "voxel"):  # pointnext.py:21
+                raise ValueError(f"{dict(s)} is not a supported sampling way, please use 'fps' or 'voxel'")
+            if s["type"] == "voxel" and not ("size" in s and "range" in s):  # pointnext.py:30-31
+                raise ValueError("a voxel sampler needs 'size' and 'range'")
+        self.all_fps = all(s["type"] != "voxel" for s in self.encoder_cfg.sample)
         # Farthest point sampling is nested: level i+1 samples the level-i picks starting from the same first point,
         # and the k-th level-i pick is the farthest of ALL level-(i-1) points from the picks before it -- in
         # particular the farthest among the level-i picks themselves -- so level i+1 reproduces the level-i pick
         # ORDER: its result is the first npoint[i+1] picks of level i (ties included: the first-index rule on
         # positions agrees with the pick order).  Only the first level is computed; False runs every level
         # (tests assert both give identical tensors).
-        self.nested_fps = all(b <= a for a, b in zip(self.encoder_cfg.npoint, self.encoder_cfg.npoint[1:]))
+        self.nested_fps = self.all_fps and all(b <= a for a, b in zip(self.encoder_cfg.npoint, self.encoder_cfg.npoint[1:]))
         # presample() also answers the neighbour queries (coordinates only): a pipeline knob -- where they run moves
         # work between the geometry and the feature stage, the results are the same tensors either way
         self.presample_neighbours = False
@@ -59,6 +61,20 @@ class Encoder(ParamTree):
                                  self.p(prefix + ".1.ln.weight"), self.p(prefix + ".1.ln.bias"), radius)
 
     # -- forward -------------------------------------------------------------------------------
+    def _sample_level(self, i: int, xyz: torch.Tensor, lengths: torch.Tensor):
+        """The sampler of downsampling stage i (pointnext.py:29-35, 45-46) -> (idx (B,K) int32 into the level's points,
+        -1 = padding; new_xyz (B,K,3), zero rows at padding; new_lengths (B,)).  'voxel' stages (no shipped config has
+        one) go through the voxel-grid kernels of csrc/voxel_sample.hip, which read the grid size back once per call."""
+        st, k = self.encoder_cfg.sample[i], self.encoder_cfg.npoint[i]
+        if st["type"] != "voxel":
+            return ops.fps(xyz, lengths, k)
+        N = xyz.shape[1]
+        pad = torch.arange(N, device=xyz.device).unsqueeze(0) >= lengths.unsqueeze(1)
+        sel, _ = ops.voxel_sample(xyz, pad, k, st["size"], st["range"])
+        mask = sel < 0
+        new = torch.gather(xyz, 1, sel.clamp(min=0).long().unsqueeze(-1).expand(-1, -1, 3)).masked_fill(mask.unsqueeze(-1), 0.0)
+        return sel, new.contiguous(), (~mask).sum(1).to(torch.int32)
+
     @torch.no_grad()
     def sample_first_level(self, points_list, padding_list):
         """First-level farthest point sampling of SEVERAL batches in one launch (the sampling kernel runs one wave per
@@ -69,7 +85,7 @@ class Encoder(ParamTree):
             pts = torch.cat([p.to(device=dev, dtype=torch.float32) for p in points_list], 0)
             pad = torch.cat([p.to(device=dev) for p in padding_list], 0)
             xyz, lengths = ops.prepare_points(pts.contiguous(), pad.contiguous())
-            fidx, new, nl = ops.fps(xyz, lengths, self.encoder_cfg.npoint[0])
+            fidx, new, nl = self._sample_level(0, xyz, lengths)
         out, o = [], 0
         for p in points_list:
             b = p.shape[0]
@@ -99,7 +115,7 @@ class Encoder(ParamTree):
             n_levels = len(self.encoder_cfg.npoint) if levels is None else levels
             npoint = list(self.encoder_cfg.npoint[:n_levels])
             if n_levels >= 1 and (self.nested_fps or n_levels == 1):
-                first = sampled0 if sampled0 is not None else ops.fps(xyz, lengths, npoint[0])
+                first = sampled0 if sampled0 is not None else self._sample_level(0, xyz, lengths)
                 # every lower level is a prefix of the first level's picks: one bookkeeping launch for all of them
                 lower = ops.nested_levels(first[1], first[2], npoint[1:]) if n_levels > 1 else []
                 for i, (fidx, cur, cur_len) in enumerate([first] + lower):
@@ -107,7 +123,7 @@ class Encoder(ParamTree):
             else:
                 cur, cur_len = xyz, lengths
                 for i, k in enumerate(npoint):
-                    fidx, cur, cur_len = sampled0 if (i == 0 and sampled0 is not None) else ops.fps(cur, cur_len, k)
+                    fidx, cur, cur_len = sampled0 if (i == 0 and sampled0 is not None) else self._sample_level(i, cur, cur_len)
                     out[f"fidx{i}"], out[f"xyz{i}"], out[f"len{i}"] = fidx, cur, cur_len
             # The search grids of the neighbour queries depend on coordinates and radii only: they are sorted here,
             # next to the sampling, and forward() runs just the searches.  Same bookkeeping as forward(): a
@@ -187,7 +203,7 @@ class Encoder(ParamTree):
                 if f"fidx{i}" in samp:
                     fidx, new_xyz, new_len = samp[f"fidx{i}"], samp[f"xyz{i}"], samp[f"len{i}"]
                 else:  # levels the geometry pass left to this stream
-                    fidx, new_xyz, new_len = ops.fps(xyz, lengths, npoint)
+                    fidx, new_xyz, new_len = self._sample_level(i, xyz, lengths)
                 prev = self_q.get((float(radii[0]), int(ks[0])))
                 grids, knn = samp.get("grids", {}), samp.get("knn", {})
                 gidx = knn.get(("sa", i))

@@ -270,7 +270,11 @@ def encoder_forward(sd: SD, cfg, points: Tensor, padding: Tensor, trace: Optiona
         xyz, fea, pad = levels[-1]
         radii, ks = enc.radius_list[i], enc.nsample_list[i]
         pre = f"downsampler.{i}"
-        new_xyz, new_pad, fidx = fps(xyz, pad, npoint, fast=fast_fps)
+        st = enc.sample[i]
+        if st["type"] == "voxel":   # pointnext.py:30-32: {'type': 'voxel', 'size': ..., 'range': ...}
+            new_xyz, new_pad, fidx = voxel_sample(xyz, pad, npoint, st["size"], st["range"])
+        else:
+            new_xyz, new_pad, fidx = fps(xyz, pad, npoint, fast=fast_fps)
         gidx = hybrid_query(radii[0], ks[0], xyz, new_xyz, pad)
         new_fea = grouped_mlp_max(sd, pre + ".sa.mlp", radii[0], xyz, fea, new_xyz, gidx)
         if trace is not None:

@@ -17,12 +17,17 @@ def make_encoder(cfg):
     return init_procedural(Encoder(cfg)).to(DEV)
 
 
-@pytest.mark.parametrize("fixture", ["encoder_reduced.npz", "encoder_reduced_padded.npz"])
+@pytest.mark.parametrize("fixture", ["encoder_reduced.npz", "encoder_reduced_padded.npz", "encoder_reduced_voxel.npz"])
 def test_encoder_reduced_per_stage_vs_reference(fixture, cfg_reduced):
     g = load_golden(fixture)
+    if "lengths" in g:   # voxel samplers at stages 0 and 2 (config.reduced_voxel_args), second frame ragged
+        from deeppointmap_amd.config import reduced_voxel_args
+        cfg_reduced = reduced_voxel_args()
     enc = make_encoder(cfg_reduced)
     pts = T(g["points"])
-    if "length" in g:
+    if "lengths" in g:
+        pad = torch.arange(pts.shape[2]).unsqueeze(0) >= T(g["lengths"]).unsqueeze(1)
+    elif "length" in g:
         pad = torch.arange(pts.shape[2]).unsqueeze(0) >= int(g["length"])
     else:
         pad = torch.zeros(pts.shape[0], pts.shape[2], dtype=torch.bool)

@@ -61,11 +61,15 @@ def test_hybrid_query_vs_reference():
         assert np.array_equal(idx.numpy(), g[n + ".idx"]), n
 
 
-@pytest.mark.parametrize("fixture", ["encoder_reduced.npz", "encoder_reduced_padded.npz"])
+@pytest.mark.parametrize("fixture", ["encoder_reduced.npz", "encoder_reduced_padded.npz", "encoder_reduced_voxel.npz"])
 def test_encoder_reduced_per_stage(fixture, cfg_reduced, sd_enc):
     g = load_golden(fixture)
     pts = T(g["points"])
-    if "length" in g:
+    if "lengths" in g:   # voxel samplers at stages 0 and 2 (config.reduced_voxel_args), second frame ragged
+        from deeppointmap_amd.config import reduced_voxel_args
+        cfg_reduced = reduced_voxel_args()
+        pad = torch.arange(pts.shape[2]).unsqueeze(0) >= T(g["lengths"]).unsqueeze(1)
+    elif "length" in g:
         pad = torch.arange(pts.shape[2]).unsqueeze(0) >= int(g["length"])
     else:
         pad = torch.zeros(pts.shape[0], pts.shape[2], dtype=torch.bool)
