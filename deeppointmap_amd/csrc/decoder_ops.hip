@@ -82,13 +82,19 @@ __device__ __forceinline__ float rows4_sum(float v) {
 // 128 queries, so the fetch of the first K / V tile (a block lives for only N / 64 tiles) is paid half as often.
 // MASK: key_mask (batch, N) bytes, non-zero = the key is padding (nn.MultiheadAttention's key_padding_mask): its score is
 // -inf like a key beyond N.  A sequence whose keys are ALL masked gives NaN rows, as in the reference.
-template <bool VEC, int QT, bool MASK = false>
+// SPLIT: few queries against many keys (a scan's 256 tokens attending a 4096-token map tile: 32 blocks walking 64 key
+// tiles each).  The keys are cut into `nsplit` ranges of whole tiles, gridDim.x = query tiles x nsplit; a block writes its
+// range's UNNORMALISED output rows (relative to its own running max) into part_o (nsplit, B, M, heads*HD) and
+// (max, sum) into part_ml (nsplit, B, heads, M, 2); attention_merge_kernel rescales and adds the ranges.
+template <bool VEC, int QT, bool MASK = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
                                                         const float *__restrict__ Kp, int ldk, long long sk,
                                                         const float *__restrict__ V, int ldv, long long sv,
                                                         float *__restrict__ O, int ldo, long long so, int M,
                                                         int N, float scale, int kv_shift,
-                                                        const uint8_t *__restrict__ key_mask = nullptr) {
+                                                        const uint8_t *__restrict__ key_mask = nullptr, int nsplit = 1,
+                                                        float *__restrict__ part_o = nullptr,
+                                                        float *__restrict__ part_ml = nullptr) {
     constexpr int TK = 64;                 // keys per tile
     __shared__ __attribute__((aligned(16))) float Ks[TK][HD + 2];  // A operand of S^T: A[i=key][k=d] = Ks[key][d]
     // A operand of O^T: A[i=d][k=key] = Vs[key][d].  Row stride 36: 16-byte aligned rows, and the four lane groups of
@@ -99,7 +105,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
                                         gridDim.x * gridDim.y * gridDim.z);
     const int b = bid / (gridDim.x * gridDim.y), h = (bid / gridDim.x) % gridDim.y;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4;
-    const int q0 = (bid % gridDim.x) * (64 * QT) + w * (16 * QT);
+    const int qtiles = SPLIT ? gridDim.x / nsplit : gridDim.x, split = SPLIT ? (bid % gridDim.x) / qtiles : 0;
+    const int q0 = ((bid % gridDim.x) % qtiles) * (64 * QT) + w * (16 * QT);
+    // key range of this block: whole tiles, the same count for every range but the last
+    const int chunk = SPLIT ? ((N + TK * nsplit - 1) / (TK * nsplit)) * TK : N;
+    const int n_begin = split * chunk, n_end = SPLIT ? min(N, n_begin + chunk) : N;
     const float *Qb = Q + (size_t)b * sq + h * HD;
     // batch element b reads the keys / values of element (b + kv_shift) mod batch: with the source and target tokens
     // of B pairs stacked as 2B sequences and kv_shift = B, ONE launch is both directions of a cross attention
@@ -141,8 +151,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
             }
         }
     };
-    fetch(0);
-    for (int n0 = 0; n0 < N; n0 += TK) {
+    fetch(n_begin);
+    for (int n0 = n_begin; n0 < n_end; n0 += TK) {
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
             *reinterpret_cast<float4 *>(&Vs[kr][c4]) = vreg[p];     // row stride 144 B: 16-byte aligned
         }
         __syncthreads();
-        if (n0 + TK < N) fetch(n0 + TK);
+        if (n0 + TK < n_end) fetch(n0 + TK);
         // S^T tile: 64 keys x 16 queries = 4 MFMA blocks (16 keys each), 8 k-steps over d
         f32x4 sacc[QT][4];
 #pragma unroll
@@ -215,6 +225,24 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
             }
     }
     // lane: queries q0 + 16 u + (lane&15), channels 16 jd + 4 g .. +3
+    if (SPLIT) {
+        const int B = gridDim.z, E = gridDim.y * HD;
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            const float l = rows4_sum(lrow[u]);
+            const int m = q0 + 16 * u + (lane & 15);
+            if (m >= M) continue;
+            float *o = part_o + (((size_t)split * B + b) * M + m) * E + h * HD + 4 * g;
+#pragma unroll
+            for (int jd = 0; jd < 2; ++jd)
+                *reinterpret_cast<float4 *>(o + 16 * jd) = make_float4(oacc[u][jd][0], oacc[u][jd][1], oacc[u][jd][2], oacc[u][jd][3]);
+            if (g == 0) {
+                float *ml = part_ml + ((((size_t)split * B + b) * gridDim.y + h) * M + m) * 2;
+                ml[0] = mrow[u], ml[1] = l;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         const float inv = 1.f / rows4_sum(lrow[u]);
@@ -232,6 +260,27 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
             }
         }
     }
+}
+
+// out[b, m, c] = sum_s part_o[s, b, m, c] e^(m_s - m*) / sum_s l_s e^(m_s - m*), m* = max_s m_s (per head): the ranges of a
+// key-split attention joined in range order (fixed order: deterministic)
+__global__ __launch_bounds__(256) void attention_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
+                                                              int nsplit, int B, int M, int heads, float *__restrict__ O,
+                                                              int ldo, long long so) {
+    const int E = heads * HD;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)B * M * E) return;
+    const int c = (int)(e % E), m = (int)((e / E) % M), b = (int)(e / ((size_t)E * M)), h = c / HD;
+    float mx = -__builtin_inff();
+    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, part_ml[((((size_t)s * B + b) * heads + h) * M + m) * 2]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float *ml = part_ml + ((((size_t)s * B + b) * heads + h) * M + m) * 2;
+        const float f = __expf(ml[0] - mx);
+        num += part_o[(((size_t)s * B + b) * M + m) * E + c] * f;
+        den += ml[1] * f;
+    }
+    O[(size_t)b * so + (size_t)m * ldo + c] = num / den;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -340,6 +389,52 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict_
         cmax[c] = mx;
         csum[c] = (ss[0][threadIdx.x] + ss[1][threadIdx.x]) + (ss[2][threadIdx.x] + ss[3][threadIdx.x]);
     }
+}
+
+// Column statistics of a TALL score matrix (map-sized registrations: 4096 rows against 256 or 4096 columns, one pair per
+// call): the kernel above gives a column to four threads, each walking M / 4 rows -- 1024 dependent trips with a handful
+// of workgroups on the chip.  Here the rows are cut into `splits` slabs (blockIdx.z): slab maxima, then slab sums against
+// the column's FULL maximum (read from the slab maxima), then one fixed-order sum over the slabs: deterministic, and the
+// same max / the same exponentials as the one-kernel form -- only the order of the final additions differs.
+__global__ __launch_bounds__(256) void col_slab_kernel(const float *__restrict__ S, int M, int N, float itau, int splits,
+                                                       float *__restrict__ pmax, float *__restrict__ psum, int phase) {
+    __shared__ float sh[4][64];
+    const int batch = blockIdx.y / splits, z = blockIdx.y - batch * splits;
+    S += (size_t)batch * M * N;
+    const size_t slab = ((size_t)batch * splits + z) * N;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int rows = (M + splits - 1) / splits, r0 = z * rows, r1 = min(M, r0 + rows);
+    float acc = phase == 0 ? -__builtin_inff() : 0.f, mx = 0.f;
+    if (c < N) {
+        if (phase == 0) {
+#pragma unroll 8
+            for (int r = r0 + g; r < r1; r += 4) acc = fmaxf(acc, S[(size_t)r * N + c] * itau);
+        } else {
+            mx = -__builtin_inff();
+            for (int k = 0; k < splits; ++k) mx = fmaxf(mx, pmax[((size_t)batch * splits + k) * N + c]);
+#pragma unroll 8
+            for (int r = r0 + g; r < r1; r += 4) acc += expf(S[(size_t)r * N + c] * itau - mx);
+        }
+    }
+    sh[g][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (g == 0 && c < N) {
+        const int l = threadIdx.x;
+        if (phase == 0) pmax[slab + c] = fmaxf(fmaxf(sh[0][l], sh[1][l]), fmaxf(sh[2][l], sh[3][l]));
+        else psum[slab + c] = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
+    }
+}
+__global__ __launch_bounds__(256) void col_slab_finish_kernel(int N, int splits, const float *__restrict__ pmax,
+                                                              const float *__restrict__ psum, float *__restrict__ cmax,
+                                                              float *__restrict__ csum) {
+    const int batch = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float mx = -__builtin_inff(), sum = 0.f;
+    for (int k = 0; k < splits; ++k) {
+        mx = fmaxf(mx, pmax[((size_t)batch * splits + k) * N + c]);
+        sum += psum[((size_t)batch * splits + k) * N + c];
+    }
+    cmax[(size_t)batch * N + c] = mx, csum[(size_t)batch * N + c] = sum;
 }
 
 __global__ __launch_bounds__(256) void dual_softmax_kernel(float *__restrict__ S, long long rows, int M, int N, float itau,
@@ -1159,6 +1254,41 @@ extern "C" int dpm_attention_masked(const float *Q, int ldq, long long sq, const
     return dpm_launch_status();
 }
 
+// Key-split form (few queries, many keys; see attention_kernel<SPLIT>): same arguments as dpm_attention_shifted plus the
+// number of key ranges and a workspace of dpm_attention_split_workspace_bytes(B, M, heads, head_dim, nsplit) bytes.
+extern "C" size_t dpm_attention_split_workspace_bytes(int B, int M, int heads, int head_dim, int nsplit) {
+    if (B <= 0 || M <= 0 || heads <= 0 || head_dim <= 0 || nsplit <= 0) return 0;
+    return sizeof(float) * (size_t)nsplit * B * M * ((size_t)heads * head_dim + 2 * (size_t)heads) + 256;
+}
+
+extern "C" int dpm_attention_split(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                                   const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
+                                   int N, int heads, int head_dim, int kv_shift, int nsplit, void *workspace,
+                                   dpm_stream_t stream) {
+    DPM_CHECK_ARG(Q && K && V && out && workspace && B >= 1 && M >= 1 && N >= 1 && heads >= 1 && kv_shift >= 0 && kv_shift < B);
+    DPM_CHECK_ARG(nsplit >= 2 && nsplit <= 64 && (long long)(nsplit - 1) * 64 < N);
+    if (head_dim != HD) return DPM_EUNSUPPORTED;
+    DPM_CHECK_ARG(ldq >= heads * HD && ldk >= heads * HD && ldv >= heads * HD && ldo >= heads * HD);
+    // every range must hold at least one key: ranges are ceil(N / (64 nsplit)) tiles long
+    const int chunk = ((N + 64 * nsplit - 1) / (64 * nsplit)) * 64;
+    DPM_CHECK_ARG((long long)(nsplit - 1) * chunk < N);
+    hipStream_t st = (hipStream_t)stream;
+    float *part_o = (float *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float *part_ml = part_o + (size_t)nsplit * B * M * heads * HD;
+    const bool vec = ldk % 4 == 0 && ldv % 4 == 0 && sk % 4 == 0 && sv % 4 == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)V & 15) == 0;
+    const float scale = (float)(1.0 / sqrt((double)head_dim));
+    const dim3 grid(dpm_cdiv(M, 64) * nsplit, heads, B);
+    if (vec)
+        hipLaunchKernelGGL((attention_kernel<true, 1, false, true>), grid, dim3(256), 0, st, Q, ldq, sq, K, ldk, sk, V, ldv, sv,
+                           out, ldo, so, M, N, scale, kv_shift, nullptr, nsplit, part_o, part_ml);
+    else
+        hipLaunchKernelGGL((attention_kernel<false, 1, false, true>), grid, dim3(256), 0, st, Q, ldq, sq, K, ldk, sk, V, ldv, sv,
+                           out, ldo, so, M, N, scale, kv_shift, nullptr, nsplit, part_o, part_ml);
+    hipLaunchKernelGGL(attention_merge_kernel, dim3(dpm_cdiv((long long)B * M * heads * HD, 256)), dim3(256), 0, st, part_o, part_ml,
+                       nsplit, B, M, heads, out, ldo, so);
+    return dpm_launch_status();
+}
+
 extern "C" int dpm_attention_shifted(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
                                      const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B,
                                      int M, int N, int heads, int head_dim, int kv_shift, dpm_stream_t stream) {
@@ -1180,10 +1310,14 @@ extern "C" int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_st
 
 constexpr long long TOPK_BIG = 1LL << 18;  // elements per problem above which the grid-wide top-k is used
 
+// row slabs of the column statistics: none up to 512 rows (the batched 256 x 256 hot path keeps its one-kernel form)
+static int col_splits(int M) { return M <= 512 ? 1 : std::min(64, (M + 127) / 128); }
+
 extern "C" size_t dpm_pairing_workspace_bytes(int batch, int M, int N) {
     size_t b = sizeof(float) * 2 * (size_t)batch * ((size_t)M + (size_t)N) + 256;
     if ((long long)M * N >= TOPK_BIG)
         b += 256 + (size_t)batch * (sizeof(TopkState) + (size_t)TK_MAXK * (sizeof(float) + 2 * sizeof(int)));
+    if (col_splits(M) > 1) b += 256 + sizeof(float) * 2 * (size_t)batch * col_splits(M) * (size_t)N;
     return b;
 }
 
@@ -1196,9 +1330,21 @@ extern "C" int dpm_dual_softmax_topk(float *S, int batch, int M, int N, double t
     const size_t BM = (size_t)batch * M, BN = (size_t)batch * N;
     float *rmax = (float *)workspace, *rsum = rmax + BM, *cmax = rsum + BM, *csum = cmax + BN;
     const float itau = 1.0f / (float)tau;  // torch divides by the scalar as a multiplication by 1/tau
-    const long long total = (long long)batch * M * N;
     hipLaunchKernelGGL(row_stats_kernel, dim3(dpm_cdiv((long long)BM, 4)), dim3(256), 0, st, S, (int)BM, N, itau, rmax, rsum);
-    hipLaunchKernelGGL(col_stats_kernel, dim3(dpm_cdiv(N, 64), batch), dim3(256), 0, st, S, M, N, itau, cmax, csum);
+    const int splits = col_splits(M);
+    if (splits == 1) {
+        hipLaunchKernelGGL(col_stats_kernel, dim3(dpm_cdiv(N, 64), batch), dim3(256), 0, st, S, M, N, itau, cmax, csum);
+    } else {  // slabs live behind everything else in the workspace
+        size_t off = sizeof(float) * 2 * (BM + BN) + 256;
+        if ((long long)M * N >= TOPK_BIG)
+            off += 256 + (size_t)batch * (sizeof(TopkState) + (size_t)TK_MAXK * (sizeof(float) + 2 * sizeof(int)));
+        float *pmax = (float *)((((uintptr_t)workspace + off) + 255) & ~(uintptr_t)255), *psum = pmax + (size_t)batch * splits * N;
+        for (int phase = 0; phase < 2; ++phase)
+            hipLaunchKernelGGL(col_slab_kernel, dim3(dpm_cdiv(N, 64), batch * splits), dim3(256), 0, st, S, M, N, itau, splits,
+                               pmax, psum, phase);
+        hipLaunchKernelGGL(col_slab_finish_kernel, dim3(dpm_cdiv(N, 256), batch), dim3(256), 0, st, N, splits, pmax, psum, cmax,
+                           csum);
+    }
     hipLaunchKernelGGL(dual_softmax_kernel, dim3((unsigned)(BM * dpm_cdiv(N, 256))), dim3(256), 0, st, S, (long long)BM, M, N,
                        itau, rmax, rsum, cmax, csum);
     const long long n = (long long)M * N;

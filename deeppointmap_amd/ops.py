@@ -497,6 +497,24 @@ def posemb(xyz_rows: torch.Tensor, dim_t: torch.Tensor, emb_dim: int) -> torch.T
     return out
 
 
+ATTENTION_SPLIT_MIN_KEYS = 1024   # key-split attention: from this many keys on ...
+ATTENTION_SPLIT_BLOCKS = 256      # ... while ONE sequence's plain launch would leave the chip's CUs without a workgroup each
+
+
+def attention_key_splits(B: int, M: int, N: int, heads: int, head_dim: int) -> int:
+    """Number of key ranges for dpm_attention_split (1 = plain kernel): few queries against many keys -- a scan's tokens
+    attending a map tile -- give a handful of workgroups that each walk the whole key sequence.  Depends on the shape of
+    ONE sequence only, never on the batch size, so a pair's result does not depend on the batch it travels in."""
+    if head_dim != 32 or N < ATTENTION_SPLIT_MIN_KEYS:
+        return 1
+    blocks = -(-M // 64) * heads   # per sequence: B stays out of the rule (see above)
+    if blocks >= ATTENTION_SPLIT_BLOCKS:
+        return 1
+    ns = max(1, min(ATTENTION_SPLIT_BLOCKS // blocks, N // 256, 64))
+    chunk = -(-N // (64 * ns)) * 64   # keys per range (whole tiles); drop ranges that would start beyond the last key
+    return -(-N // chunk)
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, M: int, N: int, heads: int = 8,
               out: Optional[torch.Tensor] = None, kv_shift: int = 0, key_mask: Optional[torch.Tensor] = None):
     """q (B*M,E) / k,v (B*N,E) row views (column slices of wider buffers allowed) -> (B*M,E)
@@ -514,6 +532,14 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, M: int,
         _chk(key_mask, torch.uint8, "key_mask")
         if tuple(key_mask.shape) != (B, N):
             raise ValueError(f"key_mask must be ({B}, {N}), got {tuple(key_mask.shape)}")
+    nsplit = attention_key_splits(B, M, N, heads, E // heads) if key_mask is None else 1
+    if nsplit > 1:
+        lib = _lib.load()
+        ws = torch.empty(lib.dpm_attention_split_workspace_bytes(B, M, heads, E // heads, nsplit), device=q.device, dtype=torch.uint8)
+        _lib.check(lib.dpm_attention_split(_ptr(q), q.stride(0), M * q.stride(0), _ptr(k), k.stride(0), N * k.stride(0),
+                                           _ptr(v), v.stride(0), N * v.stride(0), _ptr(out), E, M * E, B, M, N, heads,
+                                           E // heads, int(kv_shift), nsplit, _ptr(ws), _stream(q)), "dpm_attention_split")
+        return out
     _lib.check(_lib.load().dpm_attention_masked(_ptr(q), q.stride(0), M * q.stride(0), _ptr(k), k.stride(0),
                                                 N * k.stride(0), _ptr(v), v.stride(0), N * v.stride(0), _ptr(out), E,
                                                 M * E, B, M, N, heads, E // heads, int(kv_shift), _ptr(key_mask), _stream(q)),

@@ -265,6 +265,16 @@ int dpm_attention_masked(const float *Q, int ldq, long long sq, const float *K, 
                          const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
                          int N, int heads, int head_dim, int kv_shift, const uint8_t *key_mask, dpm_stream_t stream);
 
+/* Key-split form of dpm_attention_shifted for FEW queries against MANY keys (scan-to-map registration: 256 scan tokens
+ * attending a 4096-token map tile, mapping.py:153-155 -> descriptor_attention.py:41-44): the keys are cut into `nsplit`
+ * ranges of whole 64-key tiles that run as separate workgroups, and a second kernel joins the ranges (rescaled to the
+ * common maximum, fixed order).  Same result up to the rounding of that join.  2 <= nsplit <= 64, every range non-empty;
+ * head_dim 32 only; workspace: dpm_attention_split_workspace_bytes(B, M, heads, head_dim, nsplit). */
+size_t dpm_attention_split_workspace_bytes(int B, int M, int heads, int head_dim, int nsplit);
+int dpm_attention_split(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk, const float *V,
+                        int ldv, long long sv, float *out, int ldo, long long so, int B, int M, int N, int heads,
+                        int head_dim, int kv_shift, int nsplit, void *workspace, dpm_stream_t stream);
+
 /* F.normalize(x, p=2, dim=-1) (decoder.py:185): x / max(||x||, 1e-12), rows (R,C). */
 int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stream);
 

@@ -6,7 +6,7 @@ db = sqlite3.connect(sys.argv[1])
 first = sys.argv[2] if len(sys.argv) > 2 else "prepare_points_kernel"
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
-rows = db.execute(f"select name, start, end, {qcol or 0}, grid_x/workgroup_x, workgroup_x from kernels order by start").fetchall()
+rows = db.execute(f"select name, start, end, {qcol or 0}, (grid_x/workgroup_x)*(grid_y/workgroup_y)*(grid_z/workgroup_z), workgroup_x from kernels order by start").fetchall()
 starts = [i for i, r in enumerate(rows) if first in r[0]]
 lo = starts[-1]
 rows = rows[lo:]

@@ -59,6 +59,36 @@ def test_attention_core_vs_torch(ops):
     assert torch.equal(one, two)
 
 
+def test_attention_key_split_vs_torch(ops):
+    """few queries against many keys (scan tokens attending a map tile) run key-split (dpm_attention_split): against fp64
+    torch, against the plain kernel, ragged last ranges, strided operands and shifted keys; the split count depends on the
+    shape of one sequence only, so a batch equals its per-sequence calls bit for bit"""
+    gen = torch.Generator().manual_seed(31)
+    for B, M, N in [(1, 256, 4096), (2, 100, 1500), (1, 17, 1024), (3, 256, 2049), (1, 1024, 4096)]:
+        ns = ops.attention_key_splits(B, M, N, 8, 32)
+        assert ns > 1, (B, M, N)
+        q, k, v = (torch.randn(B * n, 256, generator=gen) for n in (M, N, N))
+        out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), B, M, N, 8).cpu()
+        qh = q.view(B, M, 8, 32).transpose(1, 2).double()
+        kh = k.view(B, N, 8, 32).transpose(1, 2).double()
+        vh = v.view(B, N, 8, 32).transpose(1, 2).double()
+        want = (torch.softmax(qh @ kh.transpose(-1, -2) / 32 ** 0.5, -1) @ vh).transpose(1, 2).reshape(B * M, 256).float()
+        torch.testing.assert_close(out, want, rtol=1e-4, atol=2e-5)
+        if B > 1:   # batch == per-sequence calls
+            one = torch.cat([ops.attention(q[b * M:(b + 1) * M].to(DEV), k[b * N:(b + 1) * N].to(DEV), v[b * N:(b + 1) * N].to(DEV),
+                                           1, M, N, 8).cpu() for b in range(B)])
+            assert torch.equal(out, one)
+    assert ops.attention_key_splits(64, 256, 256, 8, 32) == 1 and ops.attention_key_splits(1, 4096, 4096, 8, 32) == 1
+    # strided q / k / v (column slices of a fused projection) and kv_shift
+    B, M, N = 2, 128, 2048
+    qkv = torch.randn(B * N, 768, generator=gen).to(DEV)
+    qq = qkv[:B * M, :256]
+    a = ops.attention(qq, qkv[:, 256:512], qkv[:, 512:], B, M, N, 8, kv_shift=1)
+    want = torch.cat([ops.attention(qq[:M].contiguous(), qkv[N:, 256:512].contiguous(), qkv[N:, 512:].contiguous(), 1, M, N, 8),
+                      ops.attention(qq[M:].contiguous(), qkv[:N, 256:512].contiguous(), qkv[:N, 512:].contiguous(), 1, M, N, 8)])
+    assert torch.equal(a, want)
+
+
 def test_attention_other_head_widths_vs_torch(ops):
     """decoder.model_channel other than 256 (head widths 8, 16, 64, 128 at the reference's 8 heads): the generic kernel,
     with key masks and shifted keys; a width without a kernel is refused, not mis-computed."""
