@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 from deeppointmap_amd import synthetic
 src = 'deeppointmap_amd/csrc/fps.hip'
 so = '/tmp/libfps_stats.so'
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-DDPM_FPS_STATS', src, '-o', so])
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-DDPM_FPS_STATS', src, 'deeppointmap_amd/csrc/fps_tree.hip', '-o', so])
 lib = ctypes.CDLL(so)
 lib.dpm_fps_workspace_bytes.restype = ctypes.c_size_t
 B, N, K = 1, 65536, 4096
