@@ -36,6 +36,7 @@ class Decoder(ParamTree):
         self.attention_layers = self.decoder_cfg.attention_layers
         self.tau = args.loss.tau
         self._dim_t: Dict[str, torch.Tensor] = {}
+        self.stack_sides = True   # M != N: one launch per row-wise layer over both sides (False: the per-side loop)
         self.eval()
 
     # -- helpers -------------------------------------------------------------------------------
@@ -119,6 +120,9 @@ class Decoder(ParamTree):
         if M == N:
             x, y = self._attention_layers_joint(ts, td, B, M, mask=None if ms is None else torch.cat([ms, md]))
             return x, xyz_s, y, xyz_d, B, M, N
+        if self.stack_sides:
+            x, y = self._attention_layers_stacked(ts, td, B, M, N, ms, md)
+            return x, xyz_s, y, xyz_d, B, M, N
         ps, pd = ops.posemb(xyz_s, self._dimt(dev), E), ops.posemb(xyz_d, self._dimt(dev), E)
         # x + pos enters every layer: fold the addition into the producing kernel's epilogue
         xp = ops.linear(ts[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=ps)
@@ -138,6 +142,37 @@ class Decoder(ParamTree):
             yp = self._lin_ln(pre + ".mlp.2", pre + ".norm3", self._lin(pre + ".mlp.0", y2, ops.ACT_RELU), y2,
                               None if last else pd)
         return xp, xyz_s, yp, xyz_d, B, M, N
+
+    def _attention_layers_stacked(self, ts, td, B, M, N, ms=None, md=None):
+        """The two-sided loop of `_descriptor_attention_forward` for M != N (scan-to-map: a 4096-token tile against a
+        256-token scan) with the source and target rows stacked into one (B*M + B*N)-row matrix: the layers share their
+        weights between the sides, so every projection / LayerNorm / MLP is ONE launch over all rows instead of one per
+        side -- the target side's launches (256 rows: pure launch latency) disappear -- and only the attention cores run
+        per side, writing into the row ranges of one output.  Row-wise kernels give bit-identical rows whatever the
+        row count, so the result equals the per-side loop bit for bit (`stack_sides = False` runs that one)."""
+        C, E, dev = self.in_channel, self.model_channel, self.device
+        R1 = B * M
+        z_in = torch.cat([ts, td], dim=0)
+        pos = ops.posemb(z_in[:, C:C + 3], self._dimt(dev), E)
+        zp = ops.linear(z_in[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=pos)
+        for l in range(self.attention_layers):
+            pre = f"descriptor_attention.{l}"
+            last = l == self.attention_layers - 1
+            sa, ca = pre + ".self_attn", pre + ".cross_attn"
+            qkv = ops.linear(zp, self.p(sa + ".in_proj_weight"), self.p(sa + ".in_proj_bias"))
+            a = torch.empty(zp.shape[0], E, device=dev, dtype=torch.float32)
+            ops.attention(qkv[:R1, :E], qkv[:R1, E:2 * E], qkv[:R1, 2 * E:], B, M, M, HEADS, out=a[:R1], key_mask=ms)
+            ops.attention(qkv[R1:, :E], qkv[R1:, E:2 * E], qkv[R1:, 2 * E:], B, N, N, HEADS, out=a[R1:], key_mask=md)
+            z1 = self._lin_ln(sa + ".out_proj", pre + ".norm1", a, zp, pos)
+            qkv = ops.linear(z1, self.p(ca + ".in_proj_weight"), self.p(ca + ".in_proj_bias"))
+            a = torch.empty(zp.shape[0], E, device=dev, dtype=torch.float32)
+            # both directions read the pre-update tensors (descriptor_attention.py:41-44)
+            ops.attention(qkv[:R1, :E], qkv[R1:, E:2 * E], qkv[R1:, 2 * E:], B, M, N, HEADS, out=a[:R1], key_mask=md)
+            ops.attention(qkv[R1:, :E], qkv[:R1, E:2 * E], qkv[:R1, 2 * E:], B, N, M, HEADS, out=a[R1:], key_mask=ms)
+            z2 = self._lin_ln(ca + ".out_proj", pre + ".norm2", a, z1)
+            zp = self._lin_ln(pre + ".mlp.2", pre + ".norm3", self._lin(pre + ".mlp.0", z2, ops.ACT_RELU), z2,
+                              None if last else pos)
+        return zp[:R1], zp[R1:]
 
     def _attention_layers_joint(self, ts, td, B, M, frames=None, mask=None):
         """Same arithmetic as the two-sided loop above for M == N, with the source and target tokens stacked into one

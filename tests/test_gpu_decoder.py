@@ -265,6 +265,27 @@ def test_batched_registration_equals_per_pair_calls(dec):
         assert torch.equal(table[b, :20], res[b, :20])
 
 
+def test_stacked_sides_equal_the_per_side_loop(dec):
+    """M != N (scan-to-map): the row-wise layers run once over the stacked source + target rows; bit-identical to the
+    per-side loop, with and without padding masks, single pairs and batches"""
+    gen = torch.Generator().manual_seed(12)
+    for B, M, N, masked in [(1, 1024, 256, False), (1, 4096, 256, False), (2, 300, 77, True), (3, 256, 512, True)]:
+        s = torch.cat([torch.rand(B, 128, M, generator=gen), 60 * torch.randn(B, 3, M, generator=gen)], 1).to(DEV)
+        d = torch.cat([torch.rand(B, 128, N, generator=gen), 60 * torch.randn(B, 3, N, generator=gen)], 1).to(DEV)
+        ms = md = None
+        if masked:
+            ms, md = torch.zeros(B, M, dtype=torch.bool), torch.zeros(B, N, dtype=torch.bool)
+            ms[:, M - 20:], md[:, N - 9:] = True, True
+        assert dec.stack_sides
+        try:
+            a = dec._descriptor_attention_forward(s, d, ms, md)
+            dec.stack_sides = False
+            b = dec._descriptor_attention_forward(s, d, ms, md)
+        finally:
+            dec.stack_sides = True
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]), (B, M, N, masked)
+
+
 def test_pairs_entry_equals_batched_entry(dec):
     """registration_forward_pairs shares the per-frame decoder prefix between the pairs a frame takes part in; rows
     are computed by row-wise kernels, so the result must equal the gathered-batch entry point bit for bit."""
