@@ -39,6 +39,7 @@ SIGNATURES = {
     "dpm_voxel_sampler_bounds": (I, [P, P, I, I, I, D, D, P, P]),
     "dpm_voxel_sampler_workspace_bytes": (c_size_t, [I, I, LL]),
     "dpm_voxel_sampler_select": (I, [P, P, I, I, I, D, D, P, LL, I, P, I, P, P, P]),
+    "dpm_posegraph_optimize": (I, [P, I, P, P, P, P, I, I, P, P, P]),
     "dpm_host_topk_replay": (I, [P, I, I, I, P]),
     "dpm_host_sort_replay": (I, [P, I, I, P]),
     "dpm_group_mlp_max": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, D, P, P]),

@@ -27,6 +27,7 @@ SOURCES = {
     "infomat.hip": [],
     "preprocess.hip": [],
     "voxel_sample.hip": [],
+    "posegraph.hip": [],
 }
 
 

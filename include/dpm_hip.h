@@ -142,6 +142,23 @@ int dpm_voxel_sampler_select(const float *points, const uint8_t *padding, int B,
                              double sample_range, float *hdr, long long max_cells, int K, int32_t *sel, int cap,
                              int32_t *n_unique, void *workspace, dpm_stream_t stream);
 
+/* ---------------------------------------------------------------- pose graph (host) ---- */
+
+/* HOST function (no GPU involved).  PoseGraph.__optim_open3d (system/modules/pose_graph.py:565-613):
+ * open3d.pipelines.registration.global_optimization(graph, GlobalOptimizationLevenbergMarquardt(),
+ * GlobalOptimizationConvergenceCriteria(), GlobalOptimizationOption(edge_prune_threshold=0, preference_loop_closure=2,
+ * reference_node)) on a graph whose edges are all certain (pose_graph.py:597) -- a restatement of open3d 0.16's published
+ * algorithm (parity unpinned: open3d is absent; see deeppointmap_amd/posegraph_optim.py).
+ * poses (n,4,4) row-major doubles (scan -> world); edge k: src[k] -> dst[k], X (E,4,4) = the o3d PoseGraphEdge
+ * transformation (source-scan coordinates into the target scan's frame), info (E,6,6) rotation block first.
+ * criteria: NULL = open3d's defaults, else 8 doubles {max_iteration, min_relative_increment,
+ * min_relative_residual_increment, min_right_term, min_residual, max_iteration_lm, upper_scale_factor,
+ * lower_scale_factor}.  out_poses (n,4,4): refined poses, node `reference_node` unchanged.  stats (6): iterations,
+ * residual at the start, residual at the end -- of the first and of the second Levenberg-Marquardt pass. */
+int dpm_posegraph_optimize(const double *poses, int n, const int32_t *src, const int32_t *dst, const double *X,
+                           const double *info, int E, int reference_node, const double *criteria, double *out_poses,
+                           double *stats);
+
 /* HOST function (no GPU involved): torch.topk(values, k, largest, sorted=True) on one row of n floats without NaNs, by
  * the step-by-step replay of its CPU kernel that the device code uses (csrc/topk_emulate.h, same source compiled for
  * the host) -- which elements survive and in which order among equal values.  out_idx (k).  Exists so that the replay

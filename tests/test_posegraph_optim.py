@@ -10,6 +10,7 @@ import pytest
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deeppointmap_amd import posegraph_optim as PG  # noqa: E402
 from oracle import dpm_oracle as O  # noqa: E402
+from oracle import posegraph_numpy as PN  # noqa: E402  (numpy statement of the native iteration)
 
 
 def _pose(rx, ry, rz, x, y, z):
@@ -74,7 +75,7 @@ def test_noisy_loop_matches_independent_solver(n, closures):
     ref_node = 0
     out, st = PG.global_optimization(init, edges, reference_node=ref_node, return_stats=True)
     want, want_res = O.pose_graph_least_squares(init, edges, reference_node=ref_node)
-    g = PG._Graph(out, edges)
+    g = PN._Graph(out, edges)
     res = g.residual(g.zeta(out))
     assert res <= st["first"]["residual_start"] * 0.5           # the loop closure pulled the drift in
     assert abs(res - want_res) <= 1e-5 * max(want_res, 1e-9) + 1e-9
@@ -87,13 +88,42 @@ def test_noisy_loop_matches_independent_solver(n, closures):
     assert np.linalg.norm(out[-1, :3, 3] - gt[-1, :3, 3]) < np.linalg.norm(init[-1, :3, 3] - gt[-1, :3, 3])
 
 
-def test_sparse_and_dense_factorisations_agree(monkeypatch):
+def test_native_iteration_equals_its_numpy_statement(monkeypatch):
+    """csrc/posegraph.hip (renumbering + skyline Cholesky) against oracle/posegraph_numpy.py (dense Cholesky, and sparse
+    LU): same iteration counts, poses to 1e-8"""
     rng = np.random.default_rng(11)
-    gt, init, edges = _loop(60, rng, closures=((0, -1), (10, 40)))
-    dense = PG.global_optimization(init, edges)
-    monkeypatch.setattr(PG, "DENSE_LIMIT", 0)          # force the sparse LU path (what a few hundred key-frames take)
-    sparse = PG.global_optimization(init, edges)
-    np.testing.assert_allclose(sparse, dense, atol=1e-8)
+    for n, closures in [(60, ((0, -1), (10, 40))), (7, ()), (150, ((0, -1), (5, 70), (30, 120), (31, 121), (90, 20)))]:
+        gt, init, edges = _loop(n, rng, closures=closures)
+        native, st = PG.global_optimization(init, edges, reference_node=n // 3, return_stats=True)
+        dense, sd = PN.global_optimization(init, edges, reference_node=n // 3, return_stats=True)
+        np.testing.assert_allclose(native, dense, atol=1e-8)
+        assert st["first"]["iterations"] == sd["first"]["iterations"] and st["second"]["iterations"] == sd["second"]["iterations"]
+        assert abs(st["first"]["residual"] - sd["first"]["residual"]) <= 1e-9 * max(1.0, sd["first"]["residual"])
+    monkeypatch.setattr(PN, "DENSE_LIMIT", 0)          # the sparse LU path of the numpy statement
+    sparse = PN.global_optimization(init, edges, reference_node=n // 3)
+    np.testing.assert_allclose(sparse, native, atol=1e-8)
+    # custom stopping rules reach the native routine
+    crit = PG.ConvergenceCriteria(max_iteration=1, max_iteration_lm=1)
+    one, st1 = PG.global_optimization(init, edges, criteria=crit, return_stats=True)
+    assert st1["first"]["iterations"] == 1 and st1["second"]["iterations"] == 1
+    np.testing.assert_allclose(one, PN.global_optimization(init, edges, criteria=crit), atol=1e-8)
+
+
+def test_native_solver_on_a_large_graph_with_many_loop_closures():
+    """1500 key-frames, loop closures all over the trajectory: the renumbered skyline stays narrow enough to finish in
+    seconds and reaches the objective of the numpy statement"""
+    import time
+    rng = np.random.default_rng(2)
+    n = 1500
+    closures = tuple((int(a), int(b)) for a, b in zip(rng.integers(0, n, 40), rng.integers(0, n, 40)) if abs(a - b) > 20)
+    gt, init, edges = _loop(n, rng, closures=((0, -1),) + closures)
+    t = time.perf_counter()
+    out, st = PG.global_optimization(init, edges, return_stats=True)
+    dt = time.perf_counter() - t
+    assert dt < 60, dt
+    assert st["second"]["residual"] < 0.2 * st["first"]["residual_start"]
+    g = PN._Graph(out, edges)
+    assert abs(g.residual(g.zeta(out)) - st["second"]["residual"]) <= 1e-6 * st["second"]["residual"]
 
 
 def test_token_level_entry_mirrors_the_reference_call_site():
