@@ -9,8 +9,10 @@ Parity pin: this restatement is checked against outputs of the reference itself,
 the build container by importing /root/reference (tests/golden/make_golden.py) and committed
 as fixtures under tests/golden/*.npz (tests/test_oracle_golden.py).  The reference has no
 tests or golden vectors of its own.  The information matrix (a18) can
-run in neither of its reference branches here (pytorch3d / open3d are absent), so for that one
-function parity is *unpinned* by the reference: it is pinned on hand-computed cases only.
+run in neither of its reference branches here as it stands (pytorch3d / open3d are absent): the
+fixture infomat.npz comes from the reference's own pytorch3d branch with its single knn_points(K=1)
+call answered by exhaustive search (tests/golden/make_golden_infomat.py), so the function is
+pinned around that primitive and the primitive itself remains a restatement (*partially pinned*).
 
 Everything is written functionally over a flat state dict `sd` (the reference checkpoints'
 key names) and in point-major layout (points x channels); citations give the reference

@@ -248,6 +248,20 @@ def test_information_matrix_vs_oracle():
     assert float(got[3, 3]) == 3.0 and float(got[0, 4]) == -6.0 and float(got[1, 5]) == -30.0
 
 
+def test_information_matrix_vs_reference_code():
+    """the HIP path against the reference's own function (tests/golden/infomat.npz; knn_points(K=1) answered by exhaustive
+    search when the fixture was made): matched-set size exactly, entries within fp32 accumulation noise of the
+    reference's fp32 sums"""
+    from deeppointmap_amd.registration import calculate_information_matrix_from_pcd
+    from test_oracle_golden import _infomat_cases
+    g, cases = _infomat_cases()
+    for name, (a, b) in cases.items():
+        want = g[name + ".info"]
+        got = calculate_information_matrix_from_pcd(a, b, T(g[name + ".SE3"]), device=DEV).numpy()
+        assert got[3, 3] == want[3, 3], name
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4 * np.abs(want).max(), err_msg=name)
+
+
 def test_batched_registration_equals_per_pair_calls(dec):
     g = load_golden("decoder.npz")
     names = ["synthetic01", "kitti01"]

@@ -147,6 +147,29 @@ def test_num_pairs_rule():
         O.num_pairs("x", 4, 4)
 
 
+def _infomat_cases():
+    g = load_golden("infomat.npz")
+    gen = torch.Generator().manual_seed(9)
+    cases = {}
+    for n in (4096, 20000):
+        cases[f"synthetic01_n{n}"] = (synthetic.frame(0, n) * 60, synthetic.frame(1, n) * 60)
+    cases["synthetic35_poor"] = (synthetic.frame(3, 8192) * 60, synthetic.frame(5, 6000) * 60)
+    return g, cases
+
+
+def test_information_matrix_vs_reference_code():
+    """oracle.information_matrix against the REFERENCE's own calculate_information_matrix_from_pcd (pytorch3d branch run with
+    knn_points(K=1) answered by exhaustive search: tests/golden/make_golden_infomat.py) -- the transform, the radius cut
+    and the G^T G accumulation are the reference's arithmetic"""
+    g, cases = _infomat_cases()
+    for name, (a, b) in cases.items():
+        want = g[name + ".info"]
+        got = O.information_matrix(a, b, T(g[name + ".SE3"])).numpy()
+        assert got[3, 3] == want[3, 3], name                       # the same matched set
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4 * np.abs(want).max(), err_msg=name)
+    assert g["synthetic35_poor.info"][3, 3] < 0.5 * 8192            # a case where most source points find no partner
+
+
 def test_information_matrix_hand_computed():
     # two target points, three source points: one matches t0, one matches t1, one is > 1 m away
     tgt = torch.tensor([[1.0, 2.0, 3.0], [-4.0, 0.5, 2.0]]).t().contiguous()
