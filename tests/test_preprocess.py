@@ -87,6 +87,33 @@ def test_oracle_filters_on_hand_cases():
     assert float(sim[3200:].mean()) < 3.9 and int((~keep[3200:]).sum()) > 30  # the cut falls inside the bush
 
 
+def _outlier_cloud():
+    base, _ = O.preprocess_scan(_raw_scan(), ratio=1.0)                # metres, after VoxelSample + DistanceSample
+    gen = torch.Generator().manual_seed(5)
+    return torch.cat([base, 40 * torch.rand(30, 3, generator=gen) + torch.tensor([0.0, 0.0, 8.0])]).contiguous()
+
+
+def test_oracle_outlier_filter_vs_reference_code():
+    """oracle.outlier_filter against the REFERENCE's OutlierFilter (pytorch3d branch, its knn_points call answered by
+    exhaustive search: tests/golden/make_golden_infomat.py): the same survivors"""
+    g = load_golden("outlier_filter.npz")
+    xyz = _outlier_cloud()
+    assert xyz.shape[0] == int(g["n"])
+    keep = O.outlier_filter(xyz, 10, 3.0)
+    assert 0 < int((~keep).sum()) < xyz.shape[0] // 20
+    assert np.array_equal(keep.numpy(), g["keep"])
+
+
+@pytest.mark.gpu
+def test_hip_outlier_filter_vs_reference_code():
+    from deeppointmap_amd import preprocess as P
+    g = load_golden("outlier_filter.npz")
+    xyz = _outlier_cloud()
+    kx, ki = P.outlier_filter(xyz.to("cuda:0"), 10, 3.0)
+    assert torch.equal(ki.cpu().long(), torch.nonzero(T(g["keep"])).flatten())
+    assert torch.equal(kx.cpu(), xyz[T(g["keep"])])
+
+
 @pytest.mark.gpu
 def test_hip_filters_vs_oracle():
     from deeppointmap_amd import preprocess as P
