@@ -50,7 +50,10 @@ while time.time() - t0 < budget:
     dT, dR = float((res[9:12].view(3, 1) - To).norm()), rot_angle(res[:9].view(3, 3), Ro)
     scale = max(1.0, float(dst.abs().max()))
     ok = n_in == int(inl.sum()) and dT < 2e-5 * scale and dR < 2e-5
-    if not ok and min(m) > 1e-4:
+    # a residual within 5e-4 (relative) of the inlier cut is a boundary decision: the cut is mean + 3 std of fp32 residuals of
+    # points tens of metres out, and a rotation that differs in its last fp32 bits moves such a residual by ~1e-4 of the cut
+    # (seed 5: n = 5049, margin 1.3e-4, one inlier flipped, poses 4.8e-6 m / 9.6e-8 rad apart)
+    if not ok and min(m) > 5e-4:
         bad += 1
         print(f"KABSCH MISMATCH seed {seed}: n {n} kind {kind}: inliers {n_in} vs {int(inl.sum())}, dT {dT:.2e} dR {dR:.2e}, iterations {int(res[15])} vs {len(m)}, margins {[f'{x:.1e}' for x in m]}")
     cnt["kabsch"] += 1
