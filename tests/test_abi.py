@@ -67,6 +67,28 @@ def test_host_replay_of_torch_topk_and_sort():
             assert np.array_equal(torch.sort(torch.from_numpy(v), descending=not largest).indices.numpy(), perm)
 
 
+def test_plain_c_program_links_and_runs(tmp_path):
+    """the boundary is a C ABI: tests/c/abi_smoke.c (no Python, no torch) compiles against include/dpm_hip.h with gcc, links
+    libdpm_hip.so and calls its host entry points (version, error strings, the torch.topk replay, the pose-graph
+    optimiser) -- no GPU involved"""
+    import shutil
+    import subprocess
+    from deeppointmap_amd import _lib
+    from deeppointmap_amd.csrc import build
+    build.build()
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.isdir("/opt/rocm/lib"):
+        pytest.skip("needs gcc and the ROCm runtime libraries")
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call([gcc, "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe, "-L" + libdir, "-ldpm_hip",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "c abi ok" in out.stdout
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from deeppointmap_amd import _lib, ops
