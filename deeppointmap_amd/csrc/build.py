@@ -64,5 +64,25 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def build_abi_smoke(verbose=False):
+    """tests/c/abi_gpu_smoke.cpp -> csrc/build/abi_gpu_smoke: the torch-free HIP host program that drives the C ABI (run by
+    tests/test_gpu_ops.py).  Built HERE, next to the library, so that the GPU box only runs it: a first hipcc invocation on a
+    fresh box takes minutes while the toolchain pages in."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    root = os.path.dirname(os.path.dirname(HERE))
+    src = os.path.join(root, "tests", "c", "abi_gpu_smoke.cpp")
+    exe = os.path.join(HERE, "build", "abi_gpu_smoke")
+    if not os.path.exists(src):
+        return None
+    if _stale(exe, [src, OUT, os.path.join(root, "include", "dpm_hip.h")]):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-O2", "-ffp-contract=off", "-I" + os.path.join(root, "include"), src, "-o", exe,
+               "-L" + os.path.dirname(OUT), "-ldpm_hip", "-Wl,-rpath,$ORIGIN/../.."]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_abi_smoke(verbose=True))

@@ -571,6 +571,21 @@ def test_voxel_sampler_fuzz_vs_oracle(ops):
         ops.voxel_sample(lib_pts.to(DEV), torch.zeros(1, 2000, dtype=torch.bool, device=DEV), 8, 1e-4, 1.0)
 
 
+def test_c_abi_from_a_program_without_torch():
+    """tests/c/abi_gpu_smoke.cpp: a HIP host program (hipMalloc / hipMemcpy, its own stream; no Python, no torch) calls
+    dpm_fps through include/dpm_hip.h and checks every pick of a ragged batch against a plain loop of the reference's rule.
+    The binary is built with the library (csrc/build.py::build_abi_smoke, __graft_entry__.build()) and only RUN here."""
+    import os
+    import subprocess
+    from deeppointmap_amd.csrc import build
+    exe = os.path.join(build.HERE, "build", "abi_gpu_smoke")
+    if not os.path.exists(exe):
+        pytest.skip("csrc/build/abi_gpu_smoke is built by __graft_entry__.build() / python deeppointmap_amd/csrc/build.py")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "c abi gpu ok" in out.stdout
+
+
 def test_linear_bf16x3_split_is_exact_and_fp32_accurate(ops):
     """csrc/gemm_bf16x3.hip (opt-in, DPM_GEMM=bf16x3): the three-term bf16 split reproduces the fp32 weight bit for bit
     and the six-product contraction is as close to fp64 as the fp32-MFMA kernel."""
