@@ -84,3 +84,47 @@ def test_rank_communicate_module_world3_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(res)
+
+
+def _two_channel_worker(rank, world, port, q):
+    """separate control and data groups (the shape of the RCCL set-up: control on gloo, tensors on their own group) and a
+    payload-free command in the other direction while uploads are in flight"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deeppointmap_amd.comm import RankCommunicateModule
+    control, data = dist.new_group(backend="gloo"), dist.new_group(backend="gloo")
+    comm = RankCommunicateModule(control_group=control, data_group=data, device=torch.device("cpu"))
+    for m in range(world):
+        comm.add_member(m)
+    ok = True
+    if rank == 0:
+        comm.send_message(caller=0, callee=1, command="NO_OP", message={"hint": 7})   # cloud -> agent, no tensors
+        got = [comm.fetch_message(0, block=True) for _ in range(6)]
+        ok &= [g[0] for g in got] == ["UPLOAD_SCAN"] * 6
+        ok &= all(_same(g[1], _scan(1, i)) for i, g in enumerate(got))
+    else:
+        for i in range(6):
+            comm.send_message(caller=1, callee=0, command="UPLOAD_SCAN", message=_scan(1, i))
+        ok &= comm.fetch_message(1, block=True) == ("NO_OP", {"hint": 7})
+    try:
+        RankCommunicateModule(control_group=None, data_group=None, device=torch.device("cpu")).close()   # a second bus coexists
+    except Exception:
+        ok = False
+    comm.close()
+    q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_communicate_module_separate_data_group_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_two_channel_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res)
