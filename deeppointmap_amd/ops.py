@@ -200,6 +200,7 @@ def ball_query(points: torch.Tensor, lengths: torch.Tensor, centers: torch.Tenso
 
 
 VOXEL_SAMPLER_MAX_CELLS = 1 << 28   # 3 GB of grid per frame; finer grids than that are refused
+VOXEL_SAMPLER_MAX_WORKSPACE = 64 << 30   # ... and so is a batch whose grids together exceed 64 GiB
 
 
 def voxel_sample(points: torch.Tensor, padding: torch.Tensor, K: Optional[int], voxel_size: float = 0.3,
@@ -225,7 +226,11 @@ def voxel_sample(points: torch.Tensor, padding: torch.Tensor, K: Optional[int], 
     cells = int(dims.prod(1).max().item())
     if cells > VOXEL_SAMPLER_MAX_CELLS:
         raise ValueError(f"voxel sampler: {cells} grid cells per frame exceed {VOXEL_SAMPLER_MAX_CELLS}")
-    ws = torch.empty(lib.dpm_voxel_sampler_workspace_bytes(B, N, cells), device=dev, dtype=torch.uint8)
+    ws_bytes = lib.dpm_voxel_sampler_workspace_bytes(B, N, cells)
+    if ws_bytes > VOXEL_SAMPLER_MAX_WORKSPACE:
+        raise ValueError(f"voxel sampler: {B} frames x {cells} grid cells need {ws_bytes >> 20} MiB of grid "
+                         f"(limit {VOXEL_SAMPLER_MAX_WORKSPACE >> 20} MiB): sample fewer frames per call or use a coarser grid")
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     cap = N if K is None else int(K)
     sel = torch.empty(B, cap, device=dev, dtype=torch.int32)
     n_unique = torch.empty(B, device=dev, dtype=torch.int32)
