@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void vox_scatter_kernel(const float *__restric
     const VoxHdr h = hdr[b];
     const long long nc = vox_ncell(h);
     if (!(nc >= 1 && nc <= max_cells)) {  // also catches NaN / inf boxes
-        if (i == 0 && !TIE) hdr[b].over = 1.f;
+        if (i == 0 && !TIE) hdr[b].over = 1.f;  // (this kernel reads lo / X / Y / Z of the header only)
         return;
     }
     if (i >= N) return;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void vox_scatter_kernel(const float *__restric
         atomicAdd(&cnt[cell], 1u);
     } else {
         const unsigned long long best = keys[cell];
-        if ((best >> 32) == (key >> 32) && best != key) hdr[b].pad = 1.f;
+        if ((best >> 32) == (key >> 32) && best != key) hdr[b].pad = 1.f;  // every writer stores the same value; read by later kernels only
     }
 }
 
