@@ -754,6 +754,21 @@ extern "C" size_t dpm_fps_workspace_bytes(int B, int N, int K) {
     return bucket > tree ? bucket : tree;
 }
 
+// Extra (unused) dynamic LDS for the first-level sampling workgroups.  Two batches' launches are in flight (pipeline.py) and a
+// sampling workgroup is bound by instruction issue on its CU: with more than half of a CU's 160 KB of LDS per workgroup the
+// dispatcher cannot put two of them on one CU.  DPM_FPS_LDS_PAD (bytes) overrides the default for experiments.
+static int fps_lds_pad() {
+    static int pad = -1;
+    if (pad < 0) {
+        const char *e = getenv("DPM_FPS_LDS_PAD");
+        int v = e ? atoi(e) : 0;
+        v = v < 0 ? 0 : (v > 120 * 1024 ? 120 * 1024 : v);
+        if (v > 0) (void)hipFuncSetAttribute((const void *)fps_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+        pad = v;
+    }
+    return pad;
+}
+
 static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t *start, int B, int N, int K, int32_t *idx,
                         float *new_xyz, int32_t *new_lengths, void *workspace, int algo, dpm_stream_t stream) {
     DPM_CHECK_ARG(xyz && lengths && idx && new_xyz && new_lengths);
@@ -781,7 +796,7 @@ static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t 
             hipLaunchKernelGGL((fps_bucket_spec_kernel<3, 4>), dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
                                new_lengths, slots);
         else
-            hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
+            hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), fps_lds_pad(), st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
                                new_lengths, slots, start);
         return dpm_launch_status();
     }

@@ -34,6 +34,7 @@
 //    back to a full scan for its nearest point.
 #include "dpm_common.h"
 #include "topk_emulate.h"
+#include <type_traits>
 
 namespace {
 
@@ -44,6 +45,7 @@ constexpr int KMAX = 64;
 constexpr int TMPN = 128;  // scratch entries per wave (>= KMAX + 1 and >= 64)
 constexpr int GDIM = 128;  // grid cells per axis (upper bound)
 constexpr int GRID_MIN_N = 1024;
+constexpr int KNN_TODO_MARK = -2;  // first output slot of a row knn_grid_fast_kernel left to knn_grid_kernel
 
 // LDS scratch is handed to the helpers below as address-space-3 pointers: through generic pointers every access
 // would compile to a FLAT instruction (the address-space check plus both wait counters) instead of ds_read/ds_write.
@@ -474,8 +476,26 @@ __global__ __launch_bounds__(WPB * 64) void knn_hybrid_kernel(const float *__res
 // ---------------------------------------------------------------------------------------------
 struct KnnGrid {  // per frame header in the workspace
     float lox, loy, inv_cs;
-    int g;  // cells per axis
+    int g;       // cells per axis
+    float err2;  // what the expanded-form distance may undershoot the true squared distance by (frame-dependent)
+    int H;       // the (2H+1)^2 cells around a centre's cell contain every point whose computed distance is <= r^2
+    int h;       // half-width of the INNER block knn_grid_fast_kernel tries first (h = H: the block covers the radius)
+    int pad;
 };
+
+// Cell edge of the search grid.  With edge = covering edge (> the radius) the 3x3 cells around a centre hold everything
+// within the radius -- and, on a dense first-stage frame, 15 times K points.  The K nearest sit much closer: within
+// rho_t, the radius that holds about GRID_RHO_POINTS points of a surface of the frame's mean density (4 K for K = 32: a scan
+// is not a surface everywhere, its points spread along z as well, and the centres -- farthest-point samples -- are its
+// outliers: on the benchmark scans the 32nd neighbour of a first-stage centre is 0.033 away in the median, 0.045 at the
+// 90th percentile, with 0.05 the radius).  The fast search therefore looks
+// at an inner block of (2h+1)^2 finer cells whose border is at least rho_t away from the centre, and proves afterwards
+// that the K-th distance found stays inside it.  Three layouts, the one with the fewest points per inner block wins:
+//   m = 1: edge = covering edge,            inner = full = 3x3 (sparse levels: every lower level of the encoder)
+//   m = 2: edge = max(rho_t, cover / 2),     inner 3x3, full 5x5
+//   m = 3: edge = max(rho_t / 2, cover / 3), inner 5x5, full 7x7
+constexpr float GRID_RHO_POINTS = 128.f;
+constexpr float GRID_PI = 3.14159265f;
 
 __global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float *__restrict__ points_all,
                                                               const int32_t *__restrict__ lengths, int N,
@@ -483,7 +503,7 @@ __global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float *__res
                                                               int *__restrict__ start_all,
                                                               float4 *__restrict__ sorted_all,
                                                               int *__restrict__ tie_count) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *tie_count = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) tie_count[0] = 0, tie_count[1] = 0;  // tie queue, todo list
     __shared__ int s_hist[GDIM * GDIM];
     __shared__ float s_red[4][16];
     __shared__ float s_m2[16];
@@ -517,8 +537,21 @@ __global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float *__res
     // the squared magnitude of the coordinates (it is a difference of numbers of size |a|^2 + |b|^2): a point whose
     // computed distance is <= r^2 can truly be sqrt(r^2 + err) away.  The cell edge covers it: 2e-5 for coordinates
     // normalised to the unit ball (what the encoder feeds), scaled up for clouds that are not.
-    if (r2_margin > 0.f) cs_min = fmaxf(cs_min, sqrtf(r2_margin + 2e-5f * fmaxf(1.f, m2)) * 1.002f);
-    const float cs = fmaxf(cs_min, ext / (float)(GDIM - 1));
+    const float err2 = r2_margin > 0.f ? 2e-5f * fmaxf(1.f, m2) : 0.f;
+    if (r2_margin > 0.f) cs_min = fmaxf(cs_min, sqrtf(r2_margin + err2) * 1.002f);
+    float cs = fmaxf(cs_min, ext / (float)(GDIM - 1));  // the covering edge: 3x3 cells hold everything within the radius
+    int H = 1, hin = 1;
+    if (r2_margin > 0.f && len > 0) {  // hybrid query: density-adapted edge (see GRID_RHO_POINTS)
+        const float area = fmaxf(hix - lox, 1e-6f) * fmaxf(hiy - loy, 1e-6f);
+        // bounding-box area: a disc-shaped scan fills pi/4 of it
+        const float rho_t = sqrtf(GRID_RHO_POINTS * (area * (GRID_PI / 4.f)) / (GRID_PI * (float)len));
+        const float floor_cs = ext / (float)(GDIM - 1);
+        const float cs2 = fmaxf(fmaxf(rho_t, cs * 0.5005f), floor_cs), cs3 = fmaxf(fmaxf(rho_t * 0.5f, cs * 0.3337f), floor_cs);
+        float best = 9.f * cs * cs;
+        const float cover = cs;
+        if (cs2 < cover && 9.f * cs2 * cs2 < best) best = 9.f * cs2 * cs2, cs = cs2, H = 2, hin = 1;
+        if (cs3 < cover * 0.5f && 25.f * cs3 * cs3 < best) best = 25.f * cs3 * cs3, cs = cs3, H = 3, hin = 2;
+    }
     const float inv_cs = 1.0f / cs;
     const int g = min(GDIM, (int)(ext * inv_cs) + 1);
     auto cell = [&](float x, float y) -> int {
@@ -551,7 +584,7 @@ __global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float *__res
         run += local[q];
     }
     if (t == 1023) start[GDIM * GDIM] = run;
-    if (t == 0) hdr_all[b] = KnnGrid{lox, loy, inv_cs, g};
+    if (t == 0) hdr_all[b] = KnnGrid{lox, loy, inv_cs, g, err2, H, hin, 0};
     __syncthreads();
     float4 *sorted = sorted_all + (size_t)b * N;
     for (int i = t; i < len; i += 1024) {
@@ -574,22 +607,35 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
                                                             const int32_t *__restrict__ reuse_idx,
                                                             const int32_t *__restrict__ center_src,
                                                             int *__restrict__ tie_count,
-                                                            int32_t *__restrict__ tie_rows) {
+                                                            int32_t *__restrict__ tie_rows,
+                                                            const int *__restrict__ todo_count,
+                                                            const int32_t *__restrict__ todo_rows, int todo_cap, int n_rows) {
     __shared__ float s_d[WPB][CAP];
     __shared__ int s_i[WPB][CAP];
     __shared__ float s_td[WPB][TMPN];
     __shared__ int s_ti[WPB][TMPN];
-    const unsigned bid = xcd_chunked_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     // the wave index is wave-uniform, but the compiler only knows that through readfirstlane: with it the centre,
     // its cell, the cell ranges and the chunk loop live in scalar registers (scalar loads, scalar loop control)
-    const int b = bid / gridDim.x, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int s = (bid % gridDim.x) * WPB + w;
-    if (s >= S) return;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // Two ways to be told which rows (row = frame * S + centre) to search:
+    //  * todo_count == NULL: every row, one wave each (gridDim.x * WPB >= n_rows), frames kept on one XCD;
+    //  * otherwise the rows knn_grid_fast_kernel could not finish: the first min(*todo_count, todo_cap) entries of
+    //    todo_rows, and when more rows failed than the list holds, every row whose first output slot carries the
+    //    fast kernel's mark (KNN_TODO_MARK).  The grid is fixed; waves stride over the work.
+    const int n_list = todo_count ? *todo_count : 0;
+    const bool by_mark = todo_count && n_list > todo_cap;
+    const int n_work = !todo_count || by_mark ? n_rows : n_list;
+    const int n_waves = gridDim.x * WPB;
+    for (int it = (todo_count ? blockIdx.x : (int)xcd_chunked_id(blockIdx.x, gridDim.x)) * WPB + w; it < n_work; it += n_waves) {
+    int row = it;
+    if (todo_count && !by_mark) row = todo_rows[it];
+    if (by_mark && idx_all[(size_t)row * K] != KNN_TODO_MARK) continue;
+    const int b = row / S, s = row - b * S;
     if (reuse_idx) {
         const int src = center_src[(size_t)b * S + s];
         if (src >= 0) {  // this centre is point `src` of the frame: its row of the self-query is the answer
             if (lane < K) idx_all[((size_t)b * S + s) * K + lane] = reuse_idx[((size_t)b * N + src) * K + lane];
-            return;
+            continue;
         }
     }
     const float *pts = points_all + (size_t)b * N * 3;
@@ -599,10 +645,12 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
     const float4 *sorted = sorted_all + (size_t)b * N;
     Ctr c;
     ctr_init(c, centers_all + ((size_t)b * S + s) * 3, r2);
-    const int cx = (int)floorf((c.x - G.lox) * G.inv_cs), cy = (int)floorf((c.y - G.loy) * G.inv_cs);
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.g - 1);
+    // cell coordinates clamped in float first: a centre far outside the grid must not overflow the int conversion
+    const int cx = (int)fminf(fmaxf(floorf((c.x - G.lox) * G.inv_cs), -8.f), (float)(GDIM + 8));
+    const int cy = (int)fminf(fmaxf(floorf((c.y - G.loy) * G.inv_cs), -8.f), (float)(GDIM + 8));
+    const int x0 = max(cx - G.H, 0), x1 = min(cx + G.H, G.g - 1);
     if (x0 <= x1) {
-        for (int yy = max(cy - 1, 0); yy <= min(cy + 1, G.g - 1); ++yy) {
+        for (int yy = max(cy - G.H, 0); yy <= min(cy + G.H, G.g - 1); ++yy) {
             const int lo = start[yy * G.g + x0], hi = start[yy * G.g + x1 + 1];
             // unconditional loads from a clamped slot, the next chunk requested before the current one is offered
             float4 p = lo < hi ? sorted[min(lo + lane, hi - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -630,6 +678,293 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_kernel(const float *__restr
     }
     finish(c, pts, len, N, K, r2, (LdsF)s_d[w], (LdsI)s_i[w], (LdsF)s_td[w], (LdsI)s_ti[w], idx_all + ((size_t)b * S + s) * K,
            tie_count, tie_rows, b * S + s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRID search, fast path: a QUARTER wave per centre, everything in registers.
+//
+// knn_grid_kernel above spends a whole wave on a centre whose answer hangs on ~120 candidates: its time is the fixed
+// instruction count of one wave (candidate lists in LDS, a ballot bit search, several wave reductions), ~1 % of the
+// VALU peak.  Here the 16 lanes of one DPP row own a centre (four centres per wave share every instruction), each lane
+// keeps up to CPL candidates as (key, index) in registers, all reductions are four-step DPP row operations and nothing
+// touches LDS:
+//   * block: the centre's (2H+1)^2 cells when they hold at most QCAP points (then the block contains every point
+//     within the radius and the answer is exact as in knn_grid_kernel); otherwise, H = 2, only the inner 3x3 cells,
+//     accepted when the K-th distance found there is provably smaller than the distance to the block's border
+//     (rho: every point outside the block is at least rho away; the expanded form may undershoot a true squared
+//     distance by err2, both from the grid header).  The rows of the block are contiguous ranges of the sorted
+//     array; a lane walks the concatenation of the (up to five) ranges with stride 16.
+//   * selection: the K-th smallest key by probing count(key < t): three interpolation probes (the number of points
+//     within squared distance d grows linearly in d on a surface), then bisection on the integer keys; a probe
+//     with exactly K keys below it separates the answer and ends the search.  No separator exists iff the K-th and
+//     (K+1)-th keys are equal: the row goes to the tie replay kernel, as in knn_grid_kernel.
+//   * output: unsorted, nearest point in slot 0, slots beyond the radius filled with the nearest (utils.py:85-87).
+// What it cannot finish -- block too populous for the registers, border test failed, nothing within the radius, centre
+// outside the grid, tie queue full -- gets KNN_TODO_MARK in its first slot and a place in the todo list, which
+// knn_grid_kernel works off afterwards.
+// ---------------------------------------------------------------------------------------------
+constexpr int QL = 16;           // lanes per centre (one DPP row)
+constexpr int CPL = 20;          // candidate slots per lane, in groups of QB
+constexpr int QCAP = QL * CPL;   // candidates per centre
+constexpr int QROWS = 5;         // grid rows of a block (inner: h <= 2; full: only while 2H+1 <= 5)
+constexpr int QB = 5;            // slots per group: loaded together, skipped together
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_row(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ int dpp_row_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// reductions over the 16 lanes of a DPP row; every lane of the row gets the result
+__device__ __forceinline__ int row_sum(int v) {
+    v += dpp_row<0xB1>(v), v += dpp_row<0x4E>(v), v += dpp_row<0x141>(v), v += dpp_row<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ int row_min(int v) {
+    v = min(v, dpp_row<0xB1>(v)), v = min(v, dpp_row<0x4E>(v)), v = min(v, dpp_row<0x141>(v)), v = min(v, dpp_row<0x140>(v));
+    return v;
+}
+// inclusive prefix sum along the row (row_shr:1,2,4,8 with zero fill)
+__device__ __forceinline__ int row_scan(int v) {
+    v += dpp_row_zero<0x111>(v), v += dpp_row_zero<0x112>(v), v += dpp_row_zero<0x114>(v), v += dpp_row_zero<0x118>(v);
+    return v;
+}
+// inverse of fkey
+__device__ __forceinline__ float fkey_inv(int k) { return __int_as_float(k >= 0 ? k : (k ^ 0x7fffffff)); }
+
+__global__ __launch_bounds__(WPB * 64) void knn_grid_fast_kernel(const int32_t *__restrict__ lengths,
+                                                                 const float *__restrict__ centers_all, int N, int S, int K,
+                                                                 float r2, const KnnGrid *__restrict__ hdr_all,
+                                                                 const int *__restrict__ start_all,
+                                                                 const float4 *__restrict__ sorted_all,
+                                                                 int32_t *__restrict__ idx_all,
+                                                                 const int32_t *__restrict__ reuse_idx,
+                                                                 const int32_t *__restrict__ center_src,
+                                                                 int *__restrict__ tie_count, int32_t *__restrict__ tie_rows,
+                                                                 int *__restrict__ todo_count, int32_t *__restrict__ todo_rows,
+                                                                 int todo_cap) {
+    constexpr int CPB = WPB * 64 / QL;  // centres per block
+    const unsigned bid = xcd_chunked_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int b = bid / gridDim.x;
+    const int ql = threadIdx.x & (QL - 1);
+    const int s = (bid % gridDim.x) * CPB + (threadIdx.x >> 4);
+    bool live = s < S;                       // row-uniform, like every flag below
+    const int sc = min(s, S - 1);
+    const size_t row = (size_t)b * S + sc;
+    int32_t *out = idx_all + row * K;
+    if (reuse_idx && live) {
+        const int src = center_src[row];
+        if (src >= 0) {  // this centre is point `src` of the frame: its row of the self-query is the answer
+            for (int k = ql; k < K; k += QL) out[k] = reuse_idx[((size_t)b * N + src) * K + k];
+            live = false;
+        }
+    }
+    if (!__ballot(live)) return;
+    const KnnGrid G = hdr_all[b];
+    const int *start = start_all + (size_t)b * (GDIM * GDIM + 1);
+    const float4 *sorted = sorted_all + (size_t)b * N;
+    const float *cp = centers_all + row * 3;
+    const float cx_ = cp[0], cy_ = cp[1], cz_ = cp[2], caa = sq3(cx_, cy_, cz_);
+    const float fx = (cx_ - G.lox) * G.inv_cs, fy = (cy_ - G.loy) * G.inv_cs;
+    const float flx = floorf(fx), fly = floorf(fy);
+    bool todo = false;  // leave this row to knn_grid_kernel
+    // a centre outside the grid (a padded or free-standing one): not for this path (NaN coordinates fail the test too)
+    if (!(flx >= 0.f && flx < (float)G.g && fly >= 0.f && fly < (float)G.g)) todo = live, live = false;
+    const int cx = live ? (int)flx : 0, cy = live ? (int)fly : 0;
+    // ---- the block's rows: [lo_r, lo_r + n_r) of the sorted array, row r = grid row cy + r - 2.  First the inner block
+    //      (h = H: it is the whole block); the full block's offsets are fetched only when a centre of this wave is sparse
+    //      enough to use it
+    int lo[QROWS], n[QROWS];
+    int tot = 0;
+    {
+        const int xa = max(cx - G.h, 0), xb = min(cx + G.h, G.g - 1) + 1;
+#pragma unroll
+        for (int r = 0; r < QROWS; ++r) {
+            lo[r] = 0, n[r] = 0;
+            if (abs(r - 2) > G.h) continue;  // uniform
+            const int yy = cy + r - 2;
+            const int yc = min(max(yy, 0), G.g - 1);
+            const int a = start[yc * G.g + xa], e = start[yc * G.g + xb];
+            lo[r] = a, n[r] = (live && yy >= 0 && yy < G.g) ? e - a : 0, tot += n[r];
+        }
+    }
+    bool inner = G.H > G.h;  // the block does not cover the radius: its answer needs the border test
+    const int full_cells = (2 * G.H + 1) * (2 * G.H + 1), inner_cells = (2 * G.h + 1) * (2 * G.h + 1);
+    const bool want_full = live && inner && 2 * G.H + 1 <= QROWS && tot * full_cells <= QCAP * inner_cells;
+    if (__ballot(want_full)) {
+        int flo[QROWS], fn[QROWS], ftot = 0;
+        const int xa = max(cx - G.H, 0), xb = min(cx + G.H, G.g - 1) + 1;
+#pragma unroll
+        for (int r = 0; r < QROWS; ++r) {
+            flo[r] = 0, fn[r] = 0;
+            if (abs(r - 2) > G.H) continue;  // uniform
+            const int yy = cy + r - 2;
+            const int yc = min(max(yy, 0), G.g - 1);
+            const int a = start[yc * G.g + xa], e = start[yc * G.g + xb];
+            flo[r] = a, fn[r] = (yy >= 0 && yy < G.g) ? e - a : 0, ftot += fn[r];
+        }
+        if (want_full && ftot <= QCAP) {
+#pragma unroll
+            for (int r = 0; r < QROWS; ++r) lo[r] = flo[r], n[r] = fn[r];
+            tot = ftot, inner = false;
+        }
+    }
+    if (live && tot > QCAP) todo = true, live = false;  // too many for the registers
+    if (!live) tot = 0;
+    // lane position q = ql + 16 j in the concatenated rows -> sorted position q + off, off = lo_r - (n_0 + .. + n_{r-1}) for
+    // the row r that q falls into; as a sum of masked steps (from a chain of selects the compiler builds a table in scratch
+    // memory and branches)
+    int cum[QROWS], step[QROWS];
+    {
+        int run = 0, prev = lo[0];
+        cum[0] = 0, step[0] = lo[0];
+#pragma unroll
+        for (int r = 1; r < QROWS; ++r) {
+            run += n[r - 1];
+            cum[r] = run;
+            step[r] = (lo[r] - run) - prev, prev = lo[r] - run;
+        }
+    }
+    int key[CPL], idx[CPL];
+    const int last = max(N - 1, 0);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) key[j] = 0x7fffffff, idx[j] = 0x7fffffff;
+    // Slots in groups of QB; a group no centre of this wave reaches is skipped everywhere below (nsl is wave-uniform).  Inside
+    // a group every load is issued before the first distance is computed -- unconditional 16-byte loads from clamped
+    // positions, pinned by an empty asm so that the compiler neither splits them nor sinks the index word behind the
+    // radius test.
+    int nsl = (tot + QL - 1) / QL;
+    {
+        unsigned long long m = __ballot(nsl > QB) ;
+        nsl = m ? (__ballot(nsl > 2 * QB) ? (__ballot(nsl > 3 * QB) ? 4 * QB : 3 * QB) : 2 * QB) : QB;
+    }
+    auto batch = [&, tot, ql, last](auto J0) __attribute__((always_inline)) {
+        constexpr int j0 = decltype(J0)::value, j1 = j0 + QB;
+        float4 p[QB];
+#pragma unroll
+        for (int j = j0; j < j1; ++j) {
+            const int q = ql + QL * j;
+            int off = step[0];
+#pragma unroll
+            for (int r = 1; r < QROWS; ++r) off += step[r] & -(int)(q >= cum[r]);
+            p[j - j0] = sorted[q < tot ? min(q + off, last) : 0];
+        }
+#pragma unroll
+        for (int j = j0; j < j1; ++j) {
+            float4 &c = p[j - j0];
+            asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
+        }
+#pragma unroll
+        for (int j = j0; j < j1; ++j) {
+            const float4 c = p[j - j0];
+            const float d = exp_dist(cx_, cy_, cz_, caa, c.x, c.y, c.z, sq3(c.x, c.y, c.z));
+            const bool in = (ql + QL * j < tot) && d <= r2;
+            key[j] = in ? fkey(d) : 0x7fffffff;
+            idx[j] = in ? __float_as_int(c.w) : 0x7fffffff;
+        }
+    };
+    batch(std::integral_constant<int, 0>{});
+    if (nsl > QB) batch(std::integral_constant<int, QB>{});
+    if (nsl > 2 * QB) batch(std::integral_constant<int, 2 * QB>{});
+    if (nsl > 3 * QB) batch(std::integral_constant<int, 3 * QB>{});
+    // ---- how many within the radius, and the nearest (smallest key, then smallest index)
+    int cnt = 0, kb = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        if (j % QB == 0 && j >= nsl) break;
+        cnt += key[j] != 0x7fffffff, kb = min(kb, key[j]);
+    }
+    cnt = row_sum(cnt), kb = row_min(kb);
+    int ib = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        if (j % QB == 0 && j >= nsl) break;
+        ib = min(ib, key[j] == kb ? idx[j] : 0x7fffffff);
+    }
+    ib = row_min(ib);
+    if (live && cnt == 0) todo = true, live = false;  // nothing within the radius here: the full search decides
+    // ---- K-th smallest key: probes t with c = count(key < t); invariant c(lo_k) < K < c(hi_k)
+    bool sel = live && cnt > K, exact = false;
+    int lo_k = kb, hi_k = fkey(r2) + 1, c_lo = 0, c_hi = cnt;
+    for (int it = 0; __ballot(sel && !exact && (unsigned)hi_k - (unsigned)lo_k > 1u); ++it) {
+        const bool act = sel && !exact && (unsigned)hi_k - (unsigned)lo_k > 1u;
+        int t;
+        if (it < 3) {  // interpolate in the distance domain
+            const float dl = fmaxf(fkey_inv(lo_k), 0.f), dh = fkey_inv(hi_k);
+            const float td = dl + (dh - dl) * ((float)(K - c_lo) / (float)(c_hi - c_lo));
+            t = fkey(td);
+            t = (t <= lo_k || t >= hi_k) ? lo_k + (int)(((unsigned)hi_k - (unsigned)lo_k) >> 1) : t;
+        } else {
+            t = lo_k + (int)(((unsigned)hi_k - (unsigned)lo_k) >> 1);
+        }
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            if (j % QB == 0 && j >= nsl) break;
+            c += key[j] < t;
+        }
+        c = row_sum(c);
+        if (act) {
+            if (c == K) exact = true, hi_k = t;
+            else if (c < K) lo_k = t, c_lo = c;
+            else hi_k = t, c_hi = c;
+        }
+    }
+    // separator: keys below it are the answer (all valid keys when no selection was needed)
+    const int sep = sel ? hi_k : 0x7fffffff;
+    const bool tie = sel && !exact;
+    // ---- inner block: is everything at or below the bound inside it?
+    if (live && inner && !tie) {
+        const float u = fx - flx, v = fy - fly;
+        const float m = (float)G.h + fminf(fminf(u, 1.f - u), fminf(v, 1.f - v)) - 1e-3f;  // cell units to the border
+        const float rho = m / G.inv_cs;
+        const float bound = sel ? fkey_inv(sep) : r2;  // sep >= the K-th distance
+        if (!((bound + G.err2) * 1.004f < rho * rho)) todo = true, live = false;
+    }
+    if (live && tie) {  // exact replay of torch.topk's choice by the tie kernel (it rewrites the whole row)
+        int slot = 0;
+        if (ql == 0) slot = atomicAdd(tie_count, 1);
+        slot = __shfl(slot, (threadIdx.x & 63) & ~(QL - 1), 64);  // from the row's first lane
+        if (slot < TIE_CAP) {
+            if (ql == 0) tie_rows[slot] = (int)row;
+        } else {
+            todo = true;  // queue full: resolved in place by knn_grid_kernel
+        }
+        live = false;
+    }
+    {   // one atomic per wave for the rows left to the full search
+        const unsigned long long tm = __ballot(todo && ql == 0);
+        if (tm) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == __builtin_ctzll(tm)) base = atomicAdd(todo_count, __popcll(tm));
+            base = __shfl(base, __builtin_ctzll(tm), 64);
+            if (todo && ql == 0) {
+                out[0] = KNN_TODO_MARK;
+                const int slot = base + __popcll(tm & ((1ull << lane) - 1ull));
+                if (slot < todo_cap) todo_rows[slot] = (int)row;
+            }
+        }
+    }
+    if (!live) return;
+    // ---- output: nearest first, then the other selected candidates, then the nearest again as filler
+    int mine = 0;
+    bool take[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        take[j] = false;
+        if (j >= nsl) continue;
+        take[j] = key[j] < sep && !(key[j] == kb && idx[j] == ib);
+        mine += take[j];
+    }
+    int pos = 1 + row_scan(mine) - mine;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        if (j % QB == 0 && j >= nsl) break;
+        if (take[j]) out[pos] = idx[j], ++pos;
+    }
+    const int nsel = min(cnt, K);
+    if (ql == 0) out[0] = ib;
+    for (int k = nsel + ql; k < K; k += QL) out[k] = ib;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1102,7 +1437,7 @@ extern "C" int dpm_ball_query(const float *points, const int32_t *lengths, const
 extern "C" size_t dpm_knn_workspace_bytes(int B, int N) {
     if (N < GRID_MIN_N) return 0;
     return 1024 + sizeof(KnnGrid) * (size_t)B + sizeof(int) * (size_t)B * (GDIM * GDIM + 1) +
-           (size_t)B * (size_t)N * sizeof(float4) + 256 + sizeof(int32_t) * (size_t)TIE_CAP;
+           (size_t)B * (size_t)N * sizeof(float4) + 256 + sizeof(int32_t) * (size_t)TIE_CAP + sizeof(int32_t) * (size_t)B * (size_t)N;
 }
 
 namespace {
@@ -1110,8 +1445,10 @@ struct KnnWs {  // layout of the grid workspace (dpm_knn_workspace_bytes)
     KnnGrid *hdr;
     int *start;
     float4 *sorted;
-    int *tie_count;  // [0] = queued rows; the list follows
+    int *tie_count;  // [0] = queued tie rows, [1] = rows the fast search left to the full one; the lists follow
     int32_t *tie_rows;
+    int32_t *todo_rows;
+    int todo_cap;
 };
 KnnWs carve(void *workspace, int B, int N) {
     KnnWs w;
@@ -1124,6 +1461,8 @@ KnnWs carve(void *workspace, int B, int N) {
     p = (p + sizeof(float4) * (size_t)B * (size_t)N + 255) & ~(uintptr_t)255;
     w.tie_count = (int *)p;
     w.tie_rows = (int32_t *)(p + 64);
+    w.todo_rows = w.tie_rows + TIE_CAP;
+    w.todo_cap = (size_t)B * (size_t)N < (size_t)0x7fffffff ? (int)((size_t)B * (size_t)N) : 0x7fffffff;
     return w;
 }
 void launch_grid_build(const float *points, const int32_t *lengths, int B, int N, double radius, const KnnWs &w,
@@ -1134,11 +1473,29 @@ void launch_grid_build(const float *points, const int32_t *lengths, int B, int N
     hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, st, points, lengths, N, cs_min, (float)(radius * radius),
                        w.hdr, w.start, w.sorted, w.tie_count);
 }
+// DPM_KNN_FAST=0: every row through the one-wave-per-centre search (the round-2 path; A/B measurements)
+bool knn_fast_enabled() {
+    const char *e = getenv("DPM_KNN_FAST");  // read per call: tests flip it inside one process
+    return e ? atoi(e) != 0 : true;
+}
 int launch_grid_search(const float *points, const int32_t *lengths, const float *centers, int B, int N, int S, int K,
                        float r2, int32_t *idx, const KnnWs &w, const int32_t *reuse_idx, const int32_t *center_src,
                        hipStream_t st) {
-    hipLaunchKernelGGL(knn_grid_kernel, dim3(dpm_cdiv(S, WPB), B), dim3(WPB * 64), 0, st, points, lengths, centers, N,
-                       S, K, r2, w.hdr, w.start, w.sorted, idx, reuse_idx, center_src, w.tie_count, w.tie_rows);
+    const long long rows = (long long)B * S;
+    if (rows > 0x7fffffffLL / KMAX) return DPM_EUNSUPPORTED;
+    if (knn_fast_enabled()) {
+        // a quarter wave per centre; what it cannot finish is listed for the full search (few rows: a fixed small grid)
+        hipLaunchKernelGGL(knn_grid_fast_kernel, dim3(dpm_cdiv(S, WPB * 64 / QL), B), dim3(WPB * 64), 0, st, lengths, centers, N, S,
+                           K, r2, w.hdr, w.start, w.sorted, idx, reuse_idx, center_src, w.tie_count, w.tie_rows, w.tie_count + 1,
+                           w.todo_rows, w.todo_cap);
+        hipLaunchKernelGGL(knn_grid_kernel, dim3((unsigned)(rows / WPB + 1 < 2048 ? rows / WPB + 1 : 2048)), dim3(WPB * 64), 0, st, points, lengths,
+                           centers, N, S, K, r2, w.hdr, w.start, w.sorted, idx, reuse_idx, center_src, w.tie_count, w.tie_rows,
+                           (const int *)(w.tie_count + 1), (const int32_t *)w.todo_rows, w.todo_cap, (int)rows);
+    } else {
+        hipLaunchKernelGGL(knn_grid_kernel, dim3(dpm_cdiv(rows, WPB)), dim3(WPB * 64), 0, st, points, lengths, centers, N,
+                           S, K, r2, w.hdr, w.start, w.sorted, idx, reuse_idx, center_src, w.tie_count, w.tie_rows,
+                           (const int *)nullptr, (const int32_t *)nullptr, 0, (int)rows);
+    }
     if ((long long)K * 64 <= (long long)N)  // torch.topk's partial_sort regime: heap-select replay of the queued rows
         hipLaunchKernelGGL(knn_tie_kernel, dim3(2048), dim3(TIE_T), 0, st, points, lengths, centers, N, S, K, r2,
                            w.tie_count, w.tie_rows, idx);

@@ -27,3 +27,16 @@ def timed(name, fn, reps=5):
 
 timed("SA0  N=65536 S=4096 r=0.05 K=32", lambda: ops.knn_hybrid(xyz, lengths, new_xyz, 32, 0.05))
 timed("LA0  N=4096  S=4096 r=0.10 K=32", lambda: ops.knn_hybrid(new_xyz, new_len, new_xyz, 32, 0.1))
+
+# the quarter-wave search against the one-wave-per-centre search: identical sets on every row
+def sets(a):
+    return torch.sort(a, dim=-1).values
+for name, args in (("SA0", (xyz, lengths, new_xyz, 32, 0.05)), ("LA0", (new_xyz, new_len, new_xyz, 32, 0.1))):
+    os.environ["DPM_KNN_FAST"] = "1"
+    a = ops.knn_hybrid(*args)
+    os.environ["DPM_KNN_FAST"] = "0"
+    b = ops.knn_hybrid(*args)
+    timed(name + " one wave per centre", lambda: ops.knn_hybrid(*args))
+    os.environ["DPM_KNN_FAST"] = "1"
+    bad = (sets(a) != sets(b)).any(-1)
+    print(name, "rows differing:", int(bad.sum()), "of", bad.numel(), "slot0 differing:", int((a[..., 0] != b[..., 0]).sum()))
