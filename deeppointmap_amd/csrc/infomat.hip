@@ -33,7 +33,8 @@ struct PairArgs {
 struct GridHdr {       // lives at the start of each workspace slice
     float lox, loy, inv_cs;
     int gx, gy, ncell;
-    int pad[2];
+    int H;             // the (2H+1)^2 cells around a query's cell contain every point within the radius (1 or 2)
+    int qexp;          // coordinates enter the moments as integers rint(v * 2^qexp) (see nn1_match_kernel)
 };
 
 __device__ __forceinline__ const float *pair_p1(const PairArgs &a, int p) {
@@ -47,41 +48,56 @@ __device__ __forceinline__ int *pair_count(const PairArgs &a, int p) { return (i
 __device__ __forceinline__ float4 *pair_sorted(const PairArgs &a, int p) {
     return (float4 *)(a.ws + (size_t)p * a.ws_stride + 256 + sizeof(int) * (size_t)(GMAX * GMAX + 1) + 12);
 }
-// per-block partial moments [cdiv(N1,256)][10], after the sorted points
-__device__ __forceinline__ double *pair_partial(const PairArgs &a, int p) {
-    return (double *)(pair_sorted(a, p) + a.N2);
+// per-block partial moments [cdiv(N1,256)][10] (64-bit integers), after the sorted points
+__device__ __forceinline__ long long *pair_partial(const PairArgs &a, int p) {
+    return (long long *)(pair_sorted(a, p) + a.N2);
 }
 
-__global__ __launch_bounds__(1024) void grid_setup_kernel(PairArgs A, float radius) {
+__global__ __launch_bounds__(1024) void grid_setup_kernel(PairArgs A, float radius, int fine) {
     const int pair = blockIdx.x;
     const float *p2 = pair_p2(A, pair);
     const int N2 = A.N2;
     GridHdr *hdr = pair_hdr(A, pair);
-    __shared__ float red[4][16];
+    __shared__ float red[5][16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    float lox = __builtin_inff(), loy = lox, hix = -lox, hiy = -lox;
+    float lox = __builtin_inff(), loy = lox, hix = -lox, hiy = -lox, amax = 0.f;
     for (int i = t; i < N2; i += 1024) {
-        const float x = p2[i], y = p2[(size_t)N2 + i];
+        const float x = p2[i], y = p2[(size_t)N2 + i], z = p2[2 * (size_t)N2 + i];
         lox = fminf(lox, x), hix = fmaxf(hix, x), loy = fminf(loy, y), hiy = fmaxf(hiy, y);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         lox = fminf(lox, __shfl_xor(lox, off, 64)), loy = fminf(loy, __shfl_xor(loy, off, 64));
         hix = fmaxf(hix, __shfl_xor(hix, off, 64)), hiy = fmaxf(hiy, __shfl_xor(hiy, off, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, off, 64));
     }
-    if (lane == 0) red[0][w] = lox, red[1][w] = loy, red[2][w] = hix, red[3][w] = hiy;
+    if (lane == 0) red[0][w] = lox, red[1][w] = loy, red[2][w] = hix, red[3][w] = hiy, red[4][w] = amax;
     __syncthreads();
     if (t == 0) {
         for (int k = 1; k < 16; ++k) {
             lox = fminf(lox, red[0][k]), loy = fminf(loy, red[1][k]);
             hix = fmaxf(hix, red[2][k]), hiy = fmaxf(hiy, red[3][k]);
+            amax = fmaxf(amax, red[4][k]);
         }
         const float ext = fmaxf(fmaxf(hix - lox, hiy - loy), 1e-6f);
-        const float cs = fmaxf(radius, ext / (float)(GMAX - 1));  // cell edge >= radius: 3x3 search is exact
-        hdr->lox = lox, hdr->loy = loy, hdr->inv_cs = 1.0f / cs;
+        // cell edge = half the radius (5x5 cells cover it: a scan's nearest neighbour is a fraction of the radius away, and
+        // the 5x5 block of half-size cells holds 25/36 of the 3x3 block of full-size ones), unless that needs more cells per
+        // axis than the grid has; then, and with fine == 0, edge >= radius and 3x3 cells
+        float cs = fmaxf(radius * 0.5005f, ext / (float)(GMAX - 1));
+        int H = 2;
+        if (!fine || cs >= radius) cs = fmaxf(radius, ext / (float)(GMAX - 1)), H = 1;
+        hdr->lox = lox, hdr->loy = loy, hdr->inv_cs = 1.0f / cs, hdr->H = H;
         hdr->gx = min(GMAX, (int)((hix - lox) / cs) + 1);
         hdr->gy = min(GMAX, (int)((hiy - loy) / cs) + 1);
         hdr->ncell = hdr->gx * hdr->gy;
+        // fixed-point scale of the moments: |v * 2^qexp| < 2^bits with bits such that N1 squares still fit 63 bits
+        int lg = 0;
+        while (lg < 31 && (1ll << lg) < (long long)A.N1) ++lg;
+        const int bits = min(21, (62 - lg) / 2);
+        int e = 0;
+        (void)frexpf(fmaxf(amax, 1e-30f), &e);  // amax < 2^e
+        hdr->qexp = bits - e;
     }
 }
 
@@ -110,7 +126,32 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float inv_cs, int g
 // points that fall into earlier slabs, so slabs need no communication and there is no global atomic at all
 // (the three-kernel count / scan / scatter version spent 0.35 ms per launch in device-scope atomics).
 constexpr int SLABS = 8;
-constexpr int SLAB_CELLS = GMAX * GMAX / SLABS;  // 32768 counters = 128 KB of LDS
+constexpr int SLAB_CELLS = GMAX * GMAX / SLABS;  // 32768 32-bit counters = 128 KB of LDS
+
+// Counters come in two widths.  For scans of up to 65 536 points a counter -- and the cursor of a non-empty cell -- fits 16
+// bits once point 0 is kept out of the histogram (it is added back in the scan and placed first in its cell by the thread
+// that scans that cell): two counters per word, added to with one 32-bit LDS atomic on the right half, 65 536 cells per
+// slab (a 120 m x 120 m scan on half-metre cells is ONE slab; every further slab streams all points again).  Larger scans
+// use 32-bit counters.  A cursor that reaches 65 536 carries into its neighbour's half: that is the cell holding the scan's
+// last point, and every cell behind it is empty and never used as a cursor.
+__device__ __forceinline__ void cnt_inc(int *cnt, int c, bool pack) {
+    if (pack) atomicAdd((unsigned *)&cnt[c >> 1], 1u << ((c & 1) * 16));
+    else atomicAdd(&cnt[c], 1);
+}
+__device__ __forceinline__ int cnt_take(int *cnt, int c, bool pack) {  // post-increment of a cursor
+    if (pack) {
+        const unsigned sh = (c & 1) * 16;
+        return (int)((atomicAdd((unsigned *)&cnt[c >> 1], 1u << sh) >> sh) & 0xffffu);
+    }
+    return atomicAdd(&cnt[c], 1);
+}
+__device__ __forceinline__ int cnt_get(const int *cnt, int c, bool pack) {
+    return pack ? (int)((const unsigned short *)cnt)[c] : cnt[c];
+}
+__device__ __forceinline__ void cnt_set(int *cnt, int c, int v, bool pack) {
+    if (pack) ((unsigned short *)cnt)[c] = (unsigned short)v;
+    else cnt[c] = v;
+}
 
 __global__ __launch_bounds__(1024) void grid_build_kernel(PairArgs A) {
     int pair, slab;
@@ -126,13 +167,16 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(PairArgs A) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int ncell = hdr->ncell, gx = hdr->gx, gy = hdr->gy;
     const float lox = hdr->lox, loy = hdr->loy, inv_cs = hdr->inv_cs;
-    // as few slabs as the LDS allows (one for any grid up to 32768 cells, i.e. 180 m x 180 m at the 1 m radius):
-    // every slab streams all points, so extra slabs only cost; the surplus workgroups leave at once
-    const int used = (ncell + SLAB_CELLS - 1) / SLAB_CELLS;
+    const bool pack = N2 <= 65536;
+    const int cell0 = cell_coord(p2[N2], loy, inv_cs, gy) * gx + cell_coord(p2[0], lox, inv_cs, gx);  // point 0's cell
+    const int cap = pack ? 2 * SLAB_CELLS : SLAB_CELLS;
+    // as few slabs as the LDS allows: every slab streams all points, so extra slabs only cost; the surplus workgroups
+    // leave at once
+    const int used = (ncell + cap - 1) / cap;
     if (slab >= used) return;
-    const int per = (ncell + used - 1) / used;
+    const int per = (((ncell + used - 1) / used) + 1) & ~1;  // even: a packed word belongs to one slab
     const int c0 = min(slab * per, ncell), c1 = min(c0 + per, ncell), nc = c1 - c0;
-    for (int c = t; c < nc; c += 1024) cnt[c] = 0;
+    for (int c = t; c < (pack ? (nc + 1) / 2 : nc); c += 1024) cnt[c] = 0;
     if (t == 0) s_before = 0;
     __syncthreads();
     int before = 0;
@@ -149,18 +193,19 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(PairArgs A) {
             if (i0 + u * 1024 >= N2) break;
             const int cell = cell_coord(ys[u], loy, inv_cs, gy) * gx + cell_coord(xs[u], lox, inv_cs, gx);
             if (cell < c0) ++before;
-            else if (cell < c1) atomicAdd(&cnt[cell - c0], 1);
+            else if (cell < c1 && !(pack && i0 + u * 1024 == 0)) cnt_inc(cnt, cell - c0, pack);
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
     if (lane == 0 && before) atomicAdd(&s_before, before);
     __syncthreads();
-    // exclusive scan of the slab's counters (base = points of earlier slabs) -> cell start offsets
-    const int chunk = (nc + 1023) / 1024;
+    // exclusive scan of the slab's counters (base = points of earlier slabs) -> cell start offsets; a thread's run of cells
+    // starts on an even cell, so the halves of a packed word have one writer
+    const int chunk = (((nc + 1023) / 1024) + 1) & ~1;
     const int a = min(t * chunk, nc), b = min(a + chunk, nc);
     int sum = 0;
-    for (int c = a; c < b; ++c) sum += cnt[c];
+    for (int c = a; c < b; ++c) sum += cnt_get(cnt, c, pack) + (pack && c0 + c == cell0);
     int inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -172,8 +217,10 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(PairArgs A) {
     int run = s_before + inc - sum;
     for (int k = 0; k < w; ++k) run += wsum[k];
     for (int c = a; c < b; ++c) {
-        const int v = cnt[c];
-        cnt[c] = run, start[c0 + c] = run;
+        const bool first = pack && c0 + c == cell0;
+        const int v = cnt_get(cnt, c, pack) + first;
+        if (first) sorted[run] = make_float4(p2[0], p2[N2], p2[2 * (size_t)N2], __int_as_float(0));
+        cnt_set(cnt, c, run + first, pack), start[c0 + c] = run;
         run += v;
     }
     if (slab == used - 1 && t == 0) start[ncell] = N2;
@@ -190,8 +237,8 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(PairArgs A) {
             const int i = i0 + u * 1024;
             if (i >= N2) break;
             const int cell = cell_coord(ys[u], loy, inv_cs, gy) * gx + cell_coord(xs[u], lox, inv_cs, gx);
-            if (cell >= c0 && cell < c1) {
-                const int pos = atomicAdd(&cnt[cell - c0], 1);
+            if (cell >= c0 && cell < c1 && !(pack && i == 0)) {
+                const int pos = cnt_take(cnt, cell - c0, pack);
                 sorted[pos] = make_float4(xs[u], ys[u], zs[u], __int_as_float(i));
             }
         }
@@ -207,27 +254,59 @@ __device__ __forceinline__ float quad_min(float v) {
 }
 
 // FOUR lanes per query: they scan consecutive candidates of the same cell range, so one 64-byte request serves
-// the quad (a lane-per-query scan issues 64 unrelated 16-byte requests per load instruction and is bound by the
-// texture-address unit, not by bytes).  A block still covers 256 queries, each quad taking four of them in turn.
-__global__ __launch_bounds__(256) void nn1_moments_kernel(PairArgs A, float r2) {
+// the quad (a lane-per-query scan issues 64 unrelated 16-byte requests per load instruction).  A block covers 256
+// queries, each quad taking four of them in turn.
+// Round 2's kernel was bound by VALU issue (PMC: vector ALU busy 98 % of the time); this one is laid out for few
+// instructions per candidate and, once those were gone, for the memory system:
+//  * the (2H+1) grid rows around the query's cell are (2H+1) contiguous ranges of the sorted array (cells cx-H .. cx+H of
+//    one row are neighbours in memory); all range ends are fetched up front, the first eight candidates of the three
+//    nearest rows are requested together, and the running best is ONE 64-bit key (distance bits, original index):
+//    smaller key = nearer, then smaller index -- one compare and two selects per candidate (193 M -> 105 M vector
+//    instructions per 64-pair launch);
+//  * the rows two cells away are pruned by an exact lower bound (cell-unit distance to the row, shrunk by a margin for
+//    the rounding of the cell assignment);
+//  * the queries are walked in the CELL ORDER of the source scan's own grid when another pair of the batch has built one of
+//    it (consecutive-frame edges: always): neighbouring quads then read the same rows and the 32 KB L1 serves them; in
+//    index order every load went to the L2 (355 -> 250 us);
+//  * the moments are summed as 64-bit integers (see the end of the kernel), so the result does not depend on the order the
+//    queries are walked in.
+__global__ __launch_bounds__(256) void nn1_match_kernel(PairArgs A, float r2, int ordered) {
     int pair, blk;
     pair_block(blk, pair);
     const float *p1 = pair_p1(A, pair);
-    const int N1 = A.N1;
+    const float *p2 = pair_p2(A, pair);
+    const int N1 = A.N1, N2 = A.N2;
     const float *Rt = A.Rt + (size_t)pair * A.rt_stride;  // 12 floats: R row-major, T
     const GridHdr *hdr = pair_hdr(A, pair);
     const int *start = pair_count(A, pair);
     const float4 *sorted = pair_sorted(A, pair);
-    __shared__ double sred[4][10];
+    __shared__ int s_qp;
+    __shared__ long long sred[4][10];
     const int quad = threadIdx.x >> 2, ql = threadIdx.x & 3;
-    const int gx = hdr->gx, gy = hdr->gy;
+    // the pair (if any) whose target is this pair's source scan: its sorted array is the source scan in cell order
+    if (threadIdx.x == 0) s_qp = -1;
+    __syncthreads();
+    if (ordered && A.f1 && A.f2 && N1 == N2)
+        for (int t = threadIdx.x; t < (int)gridDim.y; t += 256)
+            if (A.f2[t] == A.f1[pair]) atomicMax(&s_qp, t);
+    __syncthreads();
+    const float4 *qsorted = s_qp >= 0 ? pair_sorted(A, s_qp) : nullptr;
+    const int gx = hdr->gx, gy = hdr->gy, H = hdr->H;
     const float inv_cs = hdr->inv_cs, cs = 1.0f / inv_cs, lox = hdr->lox, loy = hdr->loy;
     const float k2 = cs * cs * (1.f - 1e-5f);
-    double m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int NR = 5;  // rows of the largest block (H <= 2), visited nearest first: 0, -1, +1, -2, +2
+    int win[4] = {-1, -1, -1, -1};  // original index of the match of the quad's j-th query (-1: none within the radius)
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = blk * 256 + j * 64 + quad;
         if (i >= N1) break;  // uniform inside a quad
-        const float x = p1[i], y = p1[(size_t)N1 + i], z = p1[2 * (size_t)N1 + i];
+        float x, y, z;
+        if (qsorted) {
+            const float4 q4 = qsorted[i];
+            x = q4.x, y = q4.y, z = q4.z;
+        } else {
+            x = p1[i], y = p1[(size_t)N1 + i], z = p1[2 * (size_t)N1 + i];
+        }
         // R @ pcd1 + T in fp32 (sgemm k-order fma chain, then the broadcast add)
         const float qx = fmaf(Rt[2], z, fmaf(Rt[1], y, Rt[0] * x)) + Rt[9];
         const float qy = fmaf(Rt[5], z, fmaf(Rt[4], y, Rt[3] * x)) + Rt[10];
@@ -235,107 +314,120 @@ __global__ __launch_bounds__(256) void nn1_moments_kernel(PairArgs A, float r2) 
         const float fx = (qx - lox) * inv_cs, fy = (qy - loy) * inv_cs;  // position in cell units
         const float flx = floorf(fx), fly = floorf(fy);
         const int cx = (int)fmaxf(fminf(flx, 1e6f), -1e6f), cy = (int)fmaxf(fminf(fly, 1e6f), -1e6f);
-        // start offsets of the 3x3 neighbourhood, loaded up front (12 independent loads).  Cells of one grid row
-        // are contiguous in `sorted`, so rs[r][k] .. rs[r][k+1] is cell (cx-1+k, cy-1+r); columns outside the
-        // grid collapse to empty ranges through the clamp, rows outside the grid are all-zero.
-        int rs[3][4];
+        // range ends of the rows, all requested before the first is used.  Columns outside the grid collapse through the
+        // clamp, rows outside the grid are empty.
+        const int xa = min(max(cx - H, 0), gx), xb = min(max(cx + H + 1, 0), gx);
+        int rlo[NR], rhi[NR];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int yy = cy - 1 + r;
-            const bool in = yy >= 0 && yy < gy;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) rs[r][k] = in ? start[yy * gx + min(max(cx - 1 + k, 0), gx)] : 0;
+        for (int r = 0; r < NR; ++r) {
+            const int k = (r + 1) / 2 * ((r & 1) ? -1 : 1);  // 0, -1, +1, -2, +2
+            const int yy = cy + k;
+            const bool in = yy >= 0 && yy < gy && (r < 3 || H > 1);
+            const int yc = min(max(yy, 0), gy - 1);
+            rlo[r] = in ? start[yc * gx + xa] : 0, rhi[r] = in ? start[yc * gx + xb] : 0;
         }
-        // Distances (cell units) from the query to the neighbouring columns / rows, shrunk by a margin that
-        // covers the fp32 rounding of the cell assignment: (d - margin)^2 * cs^2 * (1 - 1e-5) is a strict lower
-        // bound of the computed distance to any point stored there, so skipping a cell whose bound exceeds the
-        // best distance so far (or radius^2 -- farther matches are discarded anyway) never changes the result.
         const float mg = 1e-3f;
-        const float dl = fmaxf(fx - flx - mg, 0.f), dr = fmaxf(flx + 1.f - fx - mg, 0.f);
-        const float dd = fmaxf(fy - fly - mg, 0.f), du = fmaxf(fly + 1.f - fy - mg, 0.f);
-        const float l2 = dl * dl * k2, rr2 = dr * dr * k2, d2 = dd * dd * k2, u2 = du * du * k2;
-        float best = __builtin_inff();
-        int bi = 0x7fffffff;
-        float bx = 0, by = 0, bz = 0;
-        // five segments visited as ONE flat loop (own cell, left, right, row below, row above): a quad moves on
-        // as soon as its own segment is exhausted, so a wave costs max-over-quads of the candidates actually
-        // visited instead of the sum over nine cells of the per-cell maxima.  p, e, seg are quad-uniform.
-        int seg = 0, p = 0, e = 0;
-        for (;;) {
-            while (p >= e && seg < 5) {
-                const float bound = fminf(quad_min(best), r2);
-                if (seg == 0) {
-                    p = rs[1][1], e = rs[1][2];
-                } else if (seg == 1) {
-                    p = rs[1][0], e = l2 > bound ? p : rs[1][1];
-                } else if (seg == 2) {
-                    p = rs[1][2], e = rr2 > bound ? p : rs[1][3];
-                } else if (seg == 3) {
-                    p = (l2 + d2 > bound) ? rs[0][1] : rs[0][0];
-                    e = d2 > bound ? p : ((rr2 + d2 > bound) ? rs[0][2] : rs[0][3]);
-                } else {
-                    p = (l2 + u2 > bound) ? rs[2][1] : rs[2][0];
-                    e = u2 > bound ? p : ((rr2 + u2 > bound) ? rs[2][2] : rs[2][3]);
+        const float below = fy - fly, above = fly + 1.f - fy;  // cell units to the lower / upper edge of the query's row
+        unsigned long long best = ~0ull;
+        auto offer = [&](const float4 t, bool ok) {
+            const float dx = qx - t.x, dy = qy - t.y, dz = qz - t.z;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(t.w);
+            best = (ok && key < best) ? key : best;
+        };
+        // candidates [p, hi) of one row from position `from` on, two per lane and trip
+        auto rest = [&](int from, int hi) {
+            for (int p = from; p < hi; p += 8) {
+                const float4 t0 = sorted[p], t1 = sorted[min(p + 4, hi - 1)];  // unconditional, the second from a clamped slot
+                offer(t0, true), offer(t1, p + 4 < hi);
+            }
+        };
+        // The query's own row and its two neighbours: the first eight candidates of each (two per lane) are requested
+        // together -- six loads in flight instead of a chain of dependent round trips (the kernel waits for memory, not
+        // for the ALU) -- rows with more than eight finish in a loop.
+        {
+            float4 t[3][2];
+            bool ok[3][2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int p = rlo[r] + ql + 4 * u;
+                    ok[r][u] = p < rhi[r];
+                    t[r][u] = sorted[ok[r][u] ? p : 0];
                 }
-                ++seg;
             }
-            if (p >= e) break;
-            // branch-free body: an unconditional load from a clamped slot (p < e here, so e - 1 is a valid one) and
-            // selects; the lanes of a quad past the end of the segment re-read its last point and are masked out
-            // NU candidates per lane and trip (4 NU per quad): their loads are in flight together
-            constexpr int NU = 2;  // 3 and 4 measured slower: most segments hold fewer than eight candidates
-            const int pp = p + ql;
-            p += 4 * NU;
-            float4 tc[NU];
 #pragma unroll
-            for (int u = 0; u < NU; ++u) tc[u] = sorted[min(pp + 4 * u, e - 1)];
+            for (int r = 0; r < 3; ++r) offer(t[r][0], ok[r][0]), offer(t[r][1], ok[r][1]);
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const float dx = qx - tc[u].x, dy = qy - tc[u].y, dz = qz - tc[u].z;
-                const float d = (dx * dx + dy * dy) + dz * dz;
-                const int oi = __float_as_int(tc[u].w);
-                const bool take = (pp + 4 * u < e) & ((d < best) | ((d == best) & (oi < bi)));
-                best = take ? d : best, bi = take ? oi : bi;
-                bx = take ? tc[u].x : bx, by = take ? tc[u].y : by, bz = take ? tc[u].z : bz;
-            }
+            for (int r = 0; r < 3; ++r) rest(rlo[r] + ql + 8, rhi[r]);
         }
-        // quad-wide arg-best: (smallest distance, then smallest original index), with the winner's coordinates
+        // the rows two cells away, pruned by an exact lower bound of the distance to anything stored there
+        if (H > 1) {
+            const float bd = best == ~0ull ? r2 : fminf(__uint_as_float((unsigned)(best >> 32)), r2);
+            const float g0 = fmaxf(below + 1.f - mg, 0.f), g1 = fmaxf(above + 1.f - mg, 0.f);
+            const int h3 = (g0 * g0 * k2 > bd) ? 0 : rhi[3], h4 = (g1 * g1 * k2 > bd) ? 0 : rhi[4];
+            const int p3 = rlo[3] + ql, p4 = rlo[4] + ql;
+            const float4 a0 = sorted[p3 < h3 ? p3 : 0], a1 = sorted[p3 + 4 < h3 ? p3 + 4 : 0];
+            const float4 b0 = sorted[p4 < h4 ? p4 : 0], b1 = sorted[p4 + 4 < h4 ? p4 + 4 : 0];
+            offer(a0, p3 < h3), offer(a1, p3 + 4 < h3), offer(b0, p4 < h4), offer(b1, p4 + 4 < h4);
+            rest(p3 + 8, h3), rest(p4 + 8, h4);
+        }
+        // quad-wide best
 #pragma unroll
         for (int step = 0; step < 2; ++step) {
-            const float od = step ? quad_xor2(best) : quad_xor1(best);
-            const int oi = __float_as_int(step ? quad_xor2(__int_as_float(bi)) : quad_xor1(__int_as_float(bi)));
-            const float ox = step ? quad_xor2(bx) : quad_xor1(bx), oy = step ? quad_xor2(by) : quad_xor1(by);
-            const float oz = step ? quad_xor2(bz) : quad_xor1(bz);
-            if (od < best || (od == best && oi < bi)) best = od, bi = oi, bx = ox, by = oy, bz = oz;
+            const float blo = __int_as_float((int)(unsigned)best), bhi = __int_as_float((int)(unsigned)(best >> 32));
+            const unsigned olo = (unsigned)__float_as_int(step ? quad_xor2(blo) : quad_xor1(blo));
+            const unsigned ohi = (unsigned)__float_as_int(step ? quad_xor2(bhi) : quad_xor1(bhi));
+            const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+            best = o < best ? o : best;
         }
-        if (ql == 0 && best <= r2) {
-            const double X = bx, Y = by, Z = bz;
-            m[0] += 1.0, m[1] += X, m[2] += Y, m[3] += Z, m[4] += X * X, m[5] += Y * Y, m[6] += Z * Z;
-            m[7] += X * Y, m[8] += X * Z, m[9] += Y * Z;
+        win[j] = (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= r2) ? (int)(unsigned)best : -1;
+    }
+    // The matched target points of the lane's (up to) four queries, fetched together.  Their moments are summed as INTEGERS
+    // (coordinates rounded to 2^-qexp: 21 significant bits of the scan's largest coordinate, 3e-5 m on a 60 m scan, with
+    // errors that average out over tens of thousands of terms; the reference itself sums in fp32): integer addition is
+    // associative, so the result depends neither on the order the queries are walked in nor on the scheduling-dependent
+    // order of the points inside a grid cell.
+    long long m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (ql == 0) {
+        const float qs = ldexpf(1.f, hdr->qexp);
+        float X[4], Y[4], Z[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oi = max(win[j], 0);
+            X[j] = p2[oi], Y[j] = p2[(size_t)N2 + oi], Z[j] = p2[2 * (size_t)N2 + oi];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (win[j] < 0) continue;
+            const long long x = (long long)__float2int_rn(X[j] * qs), y = (long long)__float2int_rn(Y[j] * qs),
+                            z = (long long)__float2int_rn(Z[j] * qs);
+            m[0] += 1, m[1] += x, m[2] += y, m[3] += z, m[4] += x * x, m[5] += y * y, m[6] += z * z;
+            m[7] += x * y, m[8] += x * z, m[9] += y * z;
         }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-        double v = m[k];
+        long long v = m[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if (lane == 0) sred[w][k] = v;
     }
     __syncthreads();
-    // one partial per block, summed in a fixed order by the finalize kernel: no same-address fp64 atomics
-    // (256 blocks of a pair hammering one cache line was the kernel's real bottleneck) and a reproducible result
+    // one partial per block, summed by the finalize kernel: no same-address atomics
     if (threadIdx.x < 10)
         pair_partial(A, pair)[(size_t)blk * 10 + threadIdx.x] =
             (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
 }
 
 __global__ __launch_bounds__(64) void infomat_finalize_kernel(PairArgs A) {
-    const double *part = pair_partial(A, blockIdx.x);
+    const long long *part = pair_partial(A, blockIdx.x);
     const int nblk = (A.N1 + 255) / 256, lane = threadIdx.x;
-    __shared__ double s[10];
+    __shared__ long long s[10];
     for (int k = 0; k < 10; ++k) {
-        double v = 0.0;
+        long long v = 0;
         for (int b = lane; b < nblk; b += 64) v += part[(size_t)b * 10 + k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -344,8 +436,11 @@ __global__ __launch_bounds__(64) void infomat_finalize_kernel(PairArgs A) {
     __syncthreads();
     if (lane != 0) return;
     float *out = A.out + (size_t)blockIdx.x * A.out_stride;
-    const double n = s[0], x = s[1], y = s[2], z = s[3], xx = s[4], yy = s[5], zz = s[6], xy = s[7], xz = s[8],
-                 yz = s[9];
+    const int qexp = pair_hdr(A, blockIdx.x)->qexp;
+    const double u = ldexp(1.0, -qexp), u2 = ldexp(1.0, -2 * qexp);
+    const double n = (double)s[0], x = (double)s[1] * u, y = (double)s[2] * u, z = (double)s[3] * u, xx = (double)s[4] * u2,
+                 yy = (double)s[5] * u2, zz = (double)s[6] * u2, xy = (double)s[7] * u2, xz = (double)s[8] * u2,
+                 yz = (double)s[9] * u2;
     const double G[36] = {zz + yy, -xy,     -xz,     0,  -z, y,   //
                           -xy,     zz + xx, -yz,     z,  0,  -x,  //
                           -xz,     -yz,     yy + xx, -y, x,  0,   //
@@ -359,7 +454,7 @@ __global__ __launch_bounds__(64) void infomat_finalize_kernel(PairArgs A) {
 
 static size_t ws_slice_bytes(int N1, int N2) {
     size_t b = 256 + sizeof(int) * (size_t)(GMAX * GMAX + 1) + 12 + sizeof(float4) * (size_t)N2 +
-               10 * sizeof(double) * (size_t)dpm_cdiv(N1, 256);
+               10 * sizeof(long long) * (size_t)dpm_cdiv(N1, 256);
     return (b + 255) & ~(size_t)255;
 }
 
@@ -368,14 +463,17 @@ extern "C" size_t dpm_infomat_workspace_bytes(int n_pairs, int N1, int N2) {
 }
 
 static int launch_grid(PairArgs A, int n_pairs, double radius, hipStream_t st) {
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(n_pairs), dim3(1024), 0, st, A, (float)radius);
+    const char *fine = getenv("DPM_NN1_FINE");  // 0: cells of one radius and 3x3 blocks (the round-2 layout; A/B measurements)
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(n_pairs), dim3(1024), 0, st, A, (float)radius, fine ? atoi(fine) : 1);
     hipLaunchKernelGGL(grid_build_kernel, dim3(SLABS, n_pairs), dim3(1024), 0, st, A);
     return dpm_launch_status();
 }
 
 static int launch_search(PairArgs A, int n_pairs, double radius, hipStream_t st) {
-    hipLaunchKernelGGL(nn1_moments_kernel, dim3(dpm_cdiv(A.N1, 256), n_pairs), dim3(256), 0, st, A,
-                       (float)(radius * radius));
+    if (getenv("DPM_ABLATE_NN1")) return DPM_OK;  // timing experiments only
+    const char *ord = getenv("DPM_NN1_ORDERED");  // 0: queries in index order (A/B measurements)
+    hipLaunchKernelGGL(nn1_match_kernel, dim3(dpm_cdiv(A.N1, 256), n_pairs), dim3(256), 0, st, A,
+                       (float)(radius * radius), ord ? atoi(ord) : 1);
     hipLaunchKernelGGL(infomat_finalize_kernel, dim3(n_pairs), dim3(64), 0, st, A);
     return dpm_launch_status();
 }

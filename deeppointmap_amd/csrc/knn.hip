@@ -1496,6 +1496,7 @@ int launch_grid_search(const float *points, const int32_t *lengths, const float 
                            S, K, r2, w.hdr, w.start, w.sorted, idx, reuse_idx, center_src, w.tie_count, w.tie_rows,
                            (const int *)nullptr, (const int32_t *)nullptr, 0, (int)rows);
     }
+    if (getenv("DPM_ABLATE_TIE")) return dpm_launch_status();  // timing experiments only: tied rows keep the plain selection
     if ((long long)K * 64 <= (long long)N)  // torch.topk's partial_sort regime: heap-select replay of the queued rows
         hipLaunchKernelGGL(knn_tie_kernel, dim3(2048), dim3(TIE_T), 0, st, points, lengths, centers, N, S, K, r2,
                            w.tie_count, w.tie_rows, idx);
