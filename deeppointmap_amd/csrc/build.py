@@ -21,7 +21,6 @@ SOURCES = {
     "knn.hip": [],
     "encoder_ops.hip": [],
     "gemm.hip": [],
-    "gemm_bf16x3.hip": [],
     "group_mlp.hip": [],
     "decoder_ops.hip": [],
     "infomat.hip": [],

@@ -419,313 +419,6 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
 #endif
 }
 
-// ------------------------------------------------------------------------------------------
-// BUCKET algorithm with SPECULATIVE MULTI-PICK rounds.  The runner-up of an arg-max round is the next pick in
-// ~98 % of the rounds (the largest closest-distances sit in different, far-apart holes of the sampling), and the
-// third-best is usually the one after.  A round therefore takes the top KC bucket-level candidates q1..qKC of ONE
-// reduction, loads every bucket any of them can change ONCE (one memory round trip instead of KC), applies them
-// in sequence in registers (v_j = min(v_{j-1}, |x - q_j|^2)) and proves afterwards which prefix really is the
-// exact pick sequence:
-//   q_{j+1} is the next pick iff (a) its own distance is untouched by q_1..q_j (checked on the candidate points with
-//   the very expression the update uses) and (b) no bucket changed by q_1..q_j still holds a value >= c_{j+1}
-//   (q_{j+1} itself excluded): all other buckets were <= c_{j+1} before and cannot have grown.  Ties count as
-//   failures, so a confirmed pick is the unique maximum and the smallest-index rule is never in play.
-// (b) needs one more workgroup exchange (LDS + barrier, no memory).  Only level-1 results (q1 is certain) are
-// stored at once; speculative levels wait in registers and are written when confirmed.  A wave that would need more
-// than MAXA buckets in registers flags an overflow and the round falls back to a single pick.  Picks, order and
-// stored distances are bit-identical to the one-pick-per-round kernel above.
-// STATUS: exact on every fixture and on adversarial clouds (lattices, duplicates, collinear points), and it needs
-// 2.1x (KC = 2) to 2.8x (KC = 3) fewer rounds on the 65 536-point scans -- but a round costs ~9 000 cycles against
-// ~4 100 (top-KC reductions, the second exchange), so it is 20 % SLOWER today and is opt-in (algo = 3).  The
-// measured phase split (scripts/fps_stats.py with ALGO=3) says where a tuned version has to save.
-// (A second variant, one pick per round with the runner-up's buckets prefetched global -> LDS, was measured too:
-// 92 % of the rounds hit, 82 % of the bucket updates found their data on chip -- and the kernel got slower, 9.6 ms
-// against 6.2: a round ends at the barrier, so ONE wave with a miss makes it as long as before, and with ~12
-// buckets per round a fully served round is the exception.)
-// ------------------------------------------------------------------------------------------
-template <int KC, int MAXA>
-__global__ __launch_bounds__(FB) void fps_bucket_spec_kernel(const float *__restrict__ xyz_all,
-                                                             const int32_t *__restrict__ lengths, int N, int K,
-                                                             const float4 *__restrict__ pts_all,
-                                                             float *__restrict__ closest_all,
-                                                             int32_t *__restrict__ idx_all,
-                                                             float *__restrict__ new_xyz_all,
-                                                             int32_t *__restrict__ new_len, int slots) {
-    constexpr int NW = FB / 64;
-    constexpr int OB = 2048;   // picks buffered in LDS between flushes to global memory
-    static_assert(NW * KC <= 64, "one lane per exchanged candidate");
-    __shared__ float s_cv[2][NW * KC], s_cx[2][NW * KC], s_cy[2][NW * KC], s_cz[2][NW * KC];  // parity-buffered
-    __shared__ int s_ci[2][NW * KC];
-    __shared__ float s_lm[NW][KC];
-    __shared__ int s_over[2];
-    __shared__ int s_oidx[OB];
-    __shared__ float s_oxyz[OB][3];
-
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const float *xyz = xyz_all + (size_t)b * N * 3;
-    const size_t fstride = slots ? (size_t)slots : (size_t)N;  // slots != 0: the Sort-Tile-Recursive packing (see fps_bucket_kernel)
-    const float4 *pts = pts_all + (size_t)b * fstride;
-    float *closest = closest_all + (size_t)b * fstride;
-    int32_t *idx = idx_all + (size_t)b * K;
-    float *new_xyz = new_xyz_all + (size_t)b * K * 3;
-    const int true_len = min(max(lengths[b], 0), N);
-    const int kn = min(true_len, K);
-    const int len = slots ? (true_len > 0 ? slots : 0) : true_len;
-    const int nb = (len + 63) >> 6;
-    const bool mine = lane * NW + w < nb;
-
-    float bx0 = 0.f, by0 = 0.f, bz0 = 0.f, bx1 = 0.f, by1 = 0.f, bz1 = 0.f;
-    for (int l = 0; l * NW + w < nb; ++l) {
-        const int q = (l * NW + w) * 64 + lane;
-        float x0 = __builtin_inff(), y0 = x0, z0 = x0, x1 = -x0, y1 = -x0, z1 = -x0;
-        if (q < len) {
-            const float4 p = pts[q];
-            if (__float_as_int(p.w) != 0x7fffffff) x0 = x1 = p.x, y0 = y1 = p.y, z0 = z1 = p.z;
-        }
-        x0 = -wave_max_dpp(-x0), y0 = -wave_max_dpp(-y0), z0 = -wave_max_dpp(-z0);
-        x1 = wave_max_dpp(x1), y1 = wave_max_dpp(y1), z1 = wave_max_dpp(z1);
-        if (lane == l) bx0 = x0, by0 = y0, bz0 = z0, bx1 = x1, by1 = y1, bz1 = z1;
-    }
-    if (t == 0) {
-        idx[0] = 0;  // slot 0 is index 0 even for an empty frame (utils.py:249-250)
-        new_xyz[0] = xyz[0], new_xyz[1] = xyz[1], new_xyz[2] = xyz[2];
-        new_len[b] = max(kn, 1);
-        s_over[0] = s_over[1] = 0;
-    }
-    float bmax = __builtin_inff();  // every closest distance starts at +inf
-    int bidx = 0x7fffffff;
-    float wx = 0.f, wy = 0.f, wz = 0.f;  // coordinates of this bucket's current best point
-
-    // candidates of the running round, wave-uniform: point, value before the round, original index
-    float qx[KC], qy[KC], qz[KC], qc[KC];
-    int qi[KC];
-    int nc = 1;                // candidates this round; q[0] is the certain pick (already recorded)
-    qx[0] = xyz[0], qy[0] = xyz[1], qz[0] = xyz[2], qc[0] = __builtin_inff(), qi[0] = 0;
-#pragma unroll
-    for (int j = 1; j < KC; ++j) qx[j] = qy[j] = qz[j] = 0.f, qc[j] = -1.f, qi[j] = 0x7fffffff;
-    int r = 1;                 // picks known so far (slots 0 .. r-1)
-    int flushed = 1;           // slots below this are in global memory
-    int par = 0;               // round parity: selects the exchange buffers
-    __syncthreads();
-
-    auto record = [&](int slot, int gi, float x, float y, float z) {
-        if (t == 0) {
-            const int o = slot & (OB - 1);
-            s_oidx[o] = gi, s_oxyz[o][0] = x, s_oxyz[o][1] = y, s_oxyz[o][2] = z;
-        }
-    };
-    auto flush = [&](int upto) {  // uniform: write slots [flushed, upto) to global memory
-        __syncthreads();
-        for (int q = flushed + t; q < upto; q += FB) {
-            const int o = q & (OB - 1);
-            idx[q] = s_oidx[o];
-            new_xyz[3 * q] = s_oxyz[o][0], new_xyz[3 * q + 1] = s_oxyz[o][1], new_xyz[3 * q + 2] = s_oxyz[o][2];
-        }
-        __syncthreads();
-        flushed = upto;
-    };
-
-#ifdef DPM_FPS_STATS
-    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = clock64();
-#endif
-    while (r < kn) {
-        FPS_T(5);
-        // ---- activity of my bucket against every candidate (box distance with the point-distance expression)
-        unsigned actm = 0;  // bit j: candidate j may change my bucket
-        if (mine) {
-#pragma unroll
-            for (int j = 0; j < KC; ++j) {
-                if (j < nc) {
-                    const float cx = fminf(fmaxf(qx[j], bx0), bx1), cy = fminf(fmaxf(qy[j], by0), by1),
-                                cz = fminf(fmaxf(qz[j], bz0), bz1);
-                    if (sqdist(qx[j], qy[j], qz[j], cx, cy, cz) < bmax) actm |= 1u << j;
-                }
-            }
-        }
-        unsigned long long m = __ballot(actm != 0);
-        const int nact = __popcll(m);
-        const bool over = nact > MAXA;   // wave-uniform
-        if (over && nc > 1 && lane == 0) s_over[par] = 1;
-
-        FPS_T(0);
-        // ---- held buckets (register path): up to MAXA, all loads first
-        int hl[MAXA];                 // owner lane of the held bucket (-1: empty slot)
-        unsigned ha[MAXA];            // its activity mask
-        float4 hp[MAXA];
-        float hv[MAXA][KC + 1];       // v_0 (stored value) .. v_KC
-        float lm[KC];                 // wave-local validation maxima: lm[j] = max after picks 0..j over changed buckets
-#pragma unroll
-        for (int j = 0; j < KC; ++j) lm[j] = -1.f;
-        if (!over) {
-            unsigned long long mm = m;
-#pragma unroll
-            for (int a = 0; a < MAXA; ++a) {
-                hl[a] = mm ? __builtin_ctzll(mm) : -1;
-                if (mm) mm &= mm - 1;
-                ha[a] = hl[a] >= 0 ? (unsigned)lane_i((int)actm, hl[a]) : 0u;
-                const int q = ((hl[a] >= 0 ? hl[a] : 0) * NW + w) * 64 + lane;
-                const bool ok = hl[a] >= 0 && q < len;
-                hp[a] = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
-                hv[a][0] = -1.f;
-                if (ok) hp[a] = pts[q], hv[a][0] = closest[q];
-            }
-#pragma unroll
-            for (int a = 0; a < MAXA; ++a) {
-                if (hl[a] < 0) continue;  // uniform
-                const bool ok = hv[a][0] >= 0.f;
-                const int oi = __float_as_int(hp[a].w);
-#pragma unroll
-                for (int j = 0; j < KC; ++j) {
-                    float v = hv[a][j];
-                    if (j < nc && ((ha[a] >> j) & 1u) && ok) v = fminf(v, sqdist(qx[j], qy[j], qz[j], hp[a].x, hp[a].y, hp[a].z));
-                    hv[a][j + 1] = v;
-                    // validation maximum after picks 0..j: only buckets changed so far count, the next candidate
-                    // itself is left out (it is allowed to keep its value)
-                    if (j + 1 < nc && (ha[a] & ((2u << j) - 1u))) {
-                        const float vv = (ok && oi != qi[j + 1]) ? v : -1.f;
-                        lm[j] = fmaxf(lm[j], wave_max_dpp(vv));
-                    }
-                }
-            }
-        } else {
-            // ---- overflow path: apply the certain pick to every bucket it can change, the old way
-            unsigned long long m0 = __ballot((actm & 1u) != 0);
-            while (m0) {
-                const int l0 = __builtin_ctzll(m0);
-                m0 &= m0 - 1;
-                const int q0 = (l0 * NW + w) * 64 + lane;
-                const bool ok0 = q0 < len;
-                float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f);
-                float c0 = 0.f;
-                if (ok0) p0 = pts[q0], c0 = closest[q0];
-                const int o0 = ok0 ? __float_as_int(p0.w) : 0x7fffffff;
-                float v0 = -1.f;
-                if (ok0) {
-                    const float d = sqdist(qx[0], qy[0], qz[0], p0.x, p0.y, p0.z);
-                    if (d < c0) closest[q0] = d;
-                    v0 = fminf(d, c0);
-                }
-                float vmax;
-                const int L = wave_argbest(v0, o0, vmax);
-                const int bi = lane_i(o0, L);
-                const float px = lane_f(p0.x, L), py = lane_f(p0.y, L), pz = lane_f(p0.z, L);
-                if (lane == l0) bmax = vmax, bidx = bi, wx = px, wy = py, wz = pz;
-            }
-        }
-        FPS_T(1);
-        // ---- validation exchange
-        int jstar = 1;
-        if (nc > 1) {
-            if (lane == 0) {
-#pragma unroll
-                for (int j = 0; j < KC; ++j) s_lm[w][j] = lm[j];
-            }
-            lds_barrier();
-            const bool any_over = s_over[par] != 0;
-            const float mine_lm = s_lm[lane & (NW - 1)][0];
-            float g1 = row16_max_f(mine_lm);
-            g1 = lane_f(g1, 0);
-            bool ok1 = !any_over && g1 < qc[1];
-            if (ok1) jstar = 2;
-            if (KC > 2 && ok1 && nc > 2) {
-                float g2 = row16_max_f(s_lm[lane & (NW - 1)][1]);
-                g2 = lane_f(g2, 0);
-                if (g2 < qc[2]) jstar = 3;
-                if (KC > 3 && jstar == 3 && nc > 3) {
-                    float g3 = row16_max_f(s_lm[lane & (NW - 1)][2]);
-                    g3 = lane_f(g3, 0);
-                    if (g3 < qc[3]) jstar = 4;
-                }
-            }
-        }
-        FPS_T(2);
-        // ---- commit the held buckets at level jstar
-        if (!over) {
-#pragma unroll
-            for (int a = 0; a < MAXA; ++a) {
-                if (hl[a] < 0) continue;                                  // uniform
-                if (!(ha[a] & ((1u << jstar) - 1u))) continue;            // untouched by the confirmed picks (uniform)
-                float vfin = hv[a][1];
-#pragma unroll
-                for (int j = 2; j <= KC; ++j)
-                    if (j <= jstar) vfin = hv[a][j];
-                const bool ok = hv[a][0] >= 0.f;
-                const int q = (hl[a] * NW + w) * 64 + lane;
-                if (ok && vfin < hv[a][0]) closest[q] = vfin;
-                const int oi = ok ? __float_as_int(hp[a].w) : 0x7fffffff;
-                float vmax;
-                const int L = wave_argbest(ok ? vfin : -1.f, oi, vmax);
-                const int bi = lane_i(oi, L);
-                const float px = lane_f(hp[a].x, L), py = lane_f(hp[a].y, L), pz = lane_f(hp[a].z, L);
-                if (lane == hl[a]) bmax = vmax, bidx = bi, wx = px, wy = py, wz = pz;
-            }
-        }
-        FPS_T(3);
-        // confirmed speculative picks become known picks
-#pragma unroll
-        for (int j = 1; j < KC; ++j)
-            if (j < jstar) record(r + j - 1, qi[j], qx[j], qy[j], qz[j]);
-        r += jstar - 1;
-        if (r >= kn) break;
-        if (r - flushed + KC + 1 > OB) flush(r);
-
-        // ---- reduction: my wave's top-KC buckets -> LDS -> global top-KC (every wave, redundantly)
-        {
-            float v = mine ? bmax : -1.f;
-#pragma unroll
-            for (int j = 0; j < KC; ++j) {
-                float vmax;
-                const int L = wave_argbest(v, bidx, vmax);
-                const int bi = lane_i(bidx, L);
-                const float px = lane_f(wx, L), py = lane_f(wy, L), pz = lane_f(wz, L);
-                if (lane == 0) {
-                    const int e = w * KC + j;
-                    s_cv[par][e] = vmax, s_ci[par][e] = vmax >= 0.f ? bi : 0x7fffffff;
-                    s_cx[par][e] = px, s_cy[par][e] = py, s_cz[par][e] = pz;
-                }
-                if (lane == L) v = -1.f;
-            }
-            if (t == 0) s_over[par ^ 1] = 0;  // the flag of the NEXT round; its last readers passed two barriers ago
-        }
-        lds_barrier();
-        FPS_T(4);
-        {
-            float v = lane < NW * KC ? s_cv[par][lane] : -1.f;
-            const int vi = lane < NW * KC ? s_ci[par][lane] : 0x7fffffff;
-#pragma unroll
-            for (int j = 0; j < KC; ++j) {
-                float vmax;
-                const int L = wave_argbest(v, vi, vmax);
-                qc[j] = vmax, qi[j] = lane_i(vi, L);
-                qx[j] = s_cx[par][L], qy[j] = s_cy[par][L], qz[j] = s_cz[par][L];
-                if (lane == L) v = -1.f;
-            }
-        }
-        record(r, qi[0], qx[0], qy[0], qz[0]);  // the arg-max itself is always exact
-        r += 1;
-        par ^= 1;
-        // speculative candidates: valid values, inside the budget, and untouched by the candidates before them
-        nc = 1;
-#pragma unroll
-        for (int j = 1; j < KC; ++j) {
-            bool good = nc == j && qc[j] >= 0.f && r + j - 1 < kn;
-#pragma unroll
-            for (int i = 0; i < j; ++i)
-                good = good && !(sqdist(qx[i], qy[i], qz[i], qx[j], qy[j], qz[j]) < qc[j]);
-            if (good) nc = j + 1;
-        }
-    }
-#ifdef DPM_FPS_STATS
-    if (b == 0 && lane == 0)
-        for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long *)pts_all - 28 + i, (unsigned long long)tacc[i] / NW);
-#endif
-    flush(min(r, kn));
-    for (int q = max(kn, 1) + t; q < K; q += FB) {
-        idx[q] = -1;
-        new_xyz[3 * q] = 0.f, new_xyz[3 * q + 1] = 0.f, new_xyz[3 * q + 2] = 0.f;
-    }
-}
-
 template <int BLOCK, int PPT, bool REG>
 int launch(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx, float *new_xyz,
            int32_t *new_len, float *ws, hipStream_t st, const int32_t *start = nullptr) {
@@ -740,46 +433,30 @@ int launch(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_
 size_t dpm_fps_str_bucket_workspace_bytes(int B, int N);
 int dpm_fps_str_bucket_sort(const float *xyz, const int32_t *lengths, int B, int N, float4 *pts, float *closest, float4 *tmp,
                             hipStream_t st);
-size_t dpm_fps_tree_workspace_bytes(int B, int N);
-int dpm_fps_tree_launch(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx, float *new_xyz,
-                        int32_t *new_lengths, void *workspace, hipStream_t st);
 
 extern "C" size_t dpm_fps_workspace_bytes(int B, int N, int K) {
     (void)K;
-    // bucket algorithms: float4 sorted points + closest, per frame; tree algorithm: see fps_tree.hip
+    // bucket algorithms: float4 sorted points + closest, per frame (Sort-Tile-Recursive packing: see fps_tree.hip)
     const size_t bucket = (size_t)B * (size_t)N * (sizeof(float4) + sizeof(int32_t)) + 512;
-    size_t tree = N > 16384 && N <= 65536 ? dpm_fps_tree_workspace_bytes(B, N) : 0;
     const size_t strb = N > 16384 && N <= 65536 ? dpm_fps_str_bucket_workspace_bytes(B, N) : 0;
-    tree = tree > strb ? tree : strb;
-    return bucket > tree ? bucket : tree;
+    return bucket > strb ? bucket : strb;
 }
 
-// Extra (unused) dynamic LDS for the first-level sampling workgroups.  Two batches' launches are in flight (pipeline.py) and a
-// sampling workgroup is bound by instruction issue on its CU: with more than half of a CU's 160 KB of LDS per workgroup the
-// dispatcher cannot put two of them on one CU.  DPM_FPS_LDS_PAD (bytes) overrides the default for experiments.
-static int fps_lds_pad() {
-    static int pad = -1;
-    if (pad < 0) {
-        const char *e = getenv("DPM_FPS_LDS_PAD");
-        int v = e ? atoi(e) : 0;
-        v = v < 0 ? 0 : (v > 120 * 1024 ? 120 * 1024 : v);
-        if (v > 0) (void)hipFuncSetAttribute((const void *)fps_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, v);
-        pad = v;
-    }
-    return pad;
-}
-
+// algo: 0 = by size; 1 = plain kernel (any N); 2 = bucket kernel over Z-ordered grid cells (N <= 65 536); 5 = bucket kernel
+// over the Sort-Tile-Recursive packing (16 384 < N <= 65 536; the default there).  Rounds 1-2 also carried a speculative
+// multi-pick kernel (3 / 6 / 7) and a one-wave-per-frame tree kernel (4): exact, measured slower in every setting for two
+// rounds, removed in round 3 (git history: csrc/fps.hip, csrc/fps_tree.hip before "FPS: experimental variants removed").
 static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t *start, int B, int N, int K, int32_t *idx,
                         float *new_xyz, int32_t *new_lengths, void *workspace, int algo, dpm_stream_t stream) {
     DPM_CHECK_ARG(xyz && lengths && idx && new_xyz && new_lengths);
     DPM_CHECK_ARG(B >= 1 && N >= 1 && K >= 1);
     DPM_CHECK_ARG(algo >= 0 && algo <= 7);
+    if (algo == 3 || algo == 4 || algo == 6 || algo == 7) return DPM_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (start && (algo == 3 || algo == 4 || algo == 6 || algo == 7)) return DPM_EUNSUPPORTED;  // start index: algos 1, 2, 5
     // beyond 65 536 points per frame (no shipped pipeline produces such frames: raw scans are voxel-sampled first) the
     // bucket kernels' one-bucket-per-lane layout ends; the plain kernel with `closest` in the workspace takes over
-    if (algo == 0) algo = (N > 16384 && N <= 65536) ? 5 : (N > 16384 && N <= 64 * MAXBUCKETS ? 2 : 1);  // 5: shortest chain (1.05 us per pick); 4: fewest instructions
-    if (algo >= 5) {  // (6 / 7: the speculative multi-pick kernel, two / three picks per round) the bucket kernel over the Sort-Tile-Recursive packing of fps_tree.hip (fewer buckets survive a round)
+    if (algo == 0) algo = (N > 16384 && N <= 65536) ? 5 : (N > 16384 && N <= 64 * MAXBUCKETS ? 2 : 1);
+    if (algo == 5) {  // the bucket kernel over the Sort-Tile-Recursive packing of fps_tree.hip (fewer buckets survive a round)
         DPM_CHECK_ARG(workspace != nullptr);
         if (N <= 16384 || N > 65536) return DPM_EUNSUPPORTED;
         const int slots = 65536;
@@ -789,21 +466,9 @@ static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t 
         float4 *tmp = (float4 *)(((uintptr_t)(closest + (size_t)B * slots) + 255) & ~(uintptr_t)255);
         const int rc = dpm_fps_str_bucket_sort(xyz, lengths, B, N, pts, closest, tmp, st);
         if (rc != DPM_OK) return rc;
-        if (algo == 6)
-            hipLaunchKernelGGL((fps_bucket_spec_kernel<2, 4>), dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
-                               new_lengths, slots);
-        else if (algo == 7)
-            hipLaunchKernelGGL((fps_bucket_spec_kernel<3, 4>), dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
-                               new_lengths, slots);
-        else
-            hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), fps_lds_pad(), st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
-                               new_lengths, slots, start);
+        hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
+                           new_lengths, slots, start);
         return dpm_launch_status();
-    }
-    if (algo == 4) {  // one wave per frame over a two-level box tree (fps_tree.hip)
-        DPM_CHECK_ARG(workspace != nullptr);
-        if (N <= 16384 || N > 65536) return DPM_EUNSUPPORTED;
-        return dpm_fps_tree_launch(xyz, lengths, B, N, K, idx, new_xyz, new_lengths, workspace, st);
     }
     if (algo >= 2) {
         if (N > 64 * MAXBUCKETS) return DPM_EUNSUPPORTED;
@@ -815,12 +480,8 @@ static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t 
 #endif
         float *closest = (float *)(pts + (size_t)B * N);
         hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, pts, closest);
-        if (algo == 3)  // experimental: two picks per round (see the kernel's header); exact, not yet faster
-            hipLaunchKernelGGL((fps_bucket_spec_kernel<2, 4>), dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx,
-                               new_xyz, new_lengths, 0);
-        else
-            hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx,
-                               new_xyz, new_lengths, 0, start);
+        hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx,
+                           new_xyz, new_lengths, 0, start);
         return dpm_launch_status();
     }
     float *ws = (float *)workspace;

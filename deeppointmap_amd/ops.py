@@ -354,17 +354,6 @@ def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radi
     return out
 
 
-GEMM_MODE = os.environ.get("DPM_GEMM", "f32")  # "bf16x3": route big projections through csrc/gemm_bf16x3.hip (experimental)
-
-
-def split_bf16x3(W: torch.Tensor) -> torch.Tensor:
-    """fp32 weight -> (3, *W.shape) bf16 bit patterns (int16): W = hi + mid + lo exactly."""
-    _chk(W, torch.float32, "W")
-    planes = torch.empty((3,) + tuple(W.shape), device=W.device, dtype=torch.int16)
-    _lib.check(_lib.load().dpm_split_bf16x3(_ptr(W), W.numel(), _ptr(planes), _stream(W)), "dpm_split_bf16x3")
-    return planes
-
-
 def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x (..., Cin) (last dim contiguous rows), W (Cout, Cin[,1[,1]]) -> (..., Cout).
@@ -393,16 +382,6 @@ def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     if residual is not None:
         r2 = residual.reshape(-1, Cout)
         _chk(r2, torch.float32, "residual")
-    if (GEMM_MODE == "bf16x3" and (R // 128) * (Cout // 128) >= 256 and Cin >= 128 and Cin % 32 == 0 and Cout % 128 == 0
-            and W.dim() >= 2 and W.is_contiguous()):
-        # experimental (DPM_GEMM=bf16x3): exact three-term bf16 split on the bf16 matrix pipe, fp32-level accuracy
-        Wp = _derived("bf16x3", (W,), lambda: split_bf16x3(W))
-        st = _lib.load().dpm_linear_bf16x3(_ptr(x2), x2.stride(0), _ptr(Wp), Cin, Cout * Cin, _ptr(bias), _ptr(r2),
-                                           Cout if r2 is not None else 0, _ptr(o2), o2.stride(0), R, Cin, Cout, act, _stream(x))
-        if st == 0:
-            return out
-        if st != -2:
-            _lib.check(st, "dpm_linear_bf16x3")
     _lib.check(_lib.load().dpm_linear(_ptr(x2), x2.stride(0), _ptr(W), ldw, _ptr(bias), _ptr(r2),
                                       Cout if r2 is not None else 0, _ptr(o2), o2.stride(0), R, Cin, Cout, act,
                                       _stream(x)), "dpm_linear")

@@ -76,9 +76,9 @@ size_t dpm_fps_workspace_bytes(int B, int N, int K);
 int dpm_fps(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
             float *new_xyz, int32_t *new_lengths, void *workspace, dpm_stream_t stream);
 /* same, with the algorithm forced: 0 = auto (1 up to 16 384 points, 5 up to 65 536, 1 again beyond), 1 = register / brute force,
- * 2 = bucket-pruned over Z-ordered grid cells, 3 = 2 with speculative two-picks-per-round, 4 = one wave per frame over a
- * two-level box tree (16 384 < N <= 65 536), 5 = the bucket kernel over the Sort-Tile-Recursive packing of 4 (same range),
- * 6 / 7 = 5 with two / three speculative picks per round.  All give identical bits; the tests run all of them. */
+ * 2 = bucket-pruned over Z-ordered grid cells (N <= 65 536), 5 = the bucket kernel over a Sort-Tile-Recursive packing
+ * (16 384 < N <= 65 536).  All give identical bits; the tests run all of them.  3, 4, 6, 7 (speculative multi-pick rounds,
+ * one-wave tree: exact but slower, removed in round 3) return DPM_EUNSUPPORTED. */
 int dpm_fps_ex(const float *xyz, const int32_t *lengths, int B, int N, int K, int32_t *idx,
                float *new_xyz, int32_t *new_lengths, void *workspace, int algo, dpm_stream_t stream);
 /* `random_start_point=True` (utils.py:248): frame b starts from point start[b] (clamped to its valid points) instead of
@@ -234,16 +234,6 @@ int dpm_layernorm(const float *x, int ldx, const float *pre, const float *gamma,
 int dpm_linear_layernorm(const float *x, int ldx, const float *W, int ldw, const float *bias, const float *pre,
                          const float *gamma, const float *beta, const float *post, float *out, int ldo, int R, int Cin,
                          int Cout, int act, dpm_stream_t stream);
-
-/* The same Conv1d(k=1)/nn.Linear contraction through the bf16 matrix pipe with fp32-level accuracy: each fp32 operand
- * is split exactly into three bf16 terms and the product is formed from the six term pairs above 2^-24 of its magnitude
- * (csrc/gemm_bf16x3.hip).  dpm_split_bf16x3 prepares a weight once: planes = 3 x n bf16 (hi | mid | lo);
- * dpm_linear_bf16x3 takes it with row stride ldw and plane stride plane_stride (elements).  Cin % 32 == 0, Cout % 4 == 0;
- * DPM_EUNSUPPORTED otherwise (run dpm_linear). */
-int dpm_split_bf16x3(const float *W, long long n, uint16_t *planes, dpm_stream_t stream);
-int dpm_linear_bf16x3(const float *x, int ldx, const uint16_t *w_planes, int ldw, long long plane_stride, const float *bias,
-                      const float *residual, int ldr, float *out, int ldo, int R, int Cin, int Cout, int act,
-                      dpm_stream_t stream);
 
 /* FeaturePropagation interpolation (network/encoder/pointnext.py:199-216): for each fine point
  * the 3 nearest valid coarse points (expanded-form distance), w_j = (1/max(d_j,1e-8))/sum;

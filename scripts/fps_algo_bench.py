@@ -1,5 +1,5 @@
-"""First-stage FPS (64 frames x 65 536 points -> 4096) per algorithm: 2 = bucket-pruned, 3 = speculative multi-pick,
-4 = one wave per frame over the box tree, 5 = bucket kernel over the Sort-Tile-Recursive packing."""
+"""First-stage FPS (64 frames x 65 536 points -> 4096) per algorithm: 2 = bucket kernel over grid cells, 5 = over the STR packing
+(16 384 < N <= 65 536)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deeppointmap_amd import synthetic, ops
@@ -8,7 +8,7 @@ pts, _ = synthetic.frames(B, 65536)
 xyz = pts.transpose(1, 2).contiguous().cuda()
 lens = torch.full((B,), 65536, dtype=torch.int32, device="cuda")
 ref = None
-for algo in (2, 3, 4, 5, 6, 7):
+for algo in (2, 5):
     for _ in range(2):
         out = ops.fps(xyz, lens, 4096, algo=algo)
     torch.cuda.synchronize()

@@ -44,7 +44,7 @@ def knn_rows_ok(idx_gpu, points, centers, radius, tol=4e-6):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("algo", [1, 2])
 def test_fps_bit_exact_vs_reference_fixtures(ops, algo):
     g = load_golden("fps.npz")
     names = sorted({k.rsplit(".", 1)[0] for k in g if k.endswith(".points")})
@@ -56,7 +56,7 @@ def test_fps_bit_exact_vs_reference_fixtures(ops, algo):
         assert int(nl[0]) == min(length, K)
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("algo", [0, 1, 2, 5])
 def test_fps_full_size_synthetic_bit_exact(ops, algo):
     g = load_golden("fps.npz")
     pts = synthetic.frame(0).t().contiguous()
@@ -72,7 +72,7 @@ def test_fps_batched_ragged_and_ties(ops):
     pts = torch.rand(B, N, 3, generator=gen)
     pts[1] = torch.round(pts[1] * 8) / 8  # heavy ties: first-index rule must hold
     lens = [20000, 20000, 17001, 300, 1]
-    for algo in (1, 2, 3, 4, 5):
+    for algo in (1, 2, 5):
         idx, new, nl = ops.fps(pts.to(DEV), _lengths(lens), K, algo=algo)
         for b in range(B):
             want = O.fps_indices_fast(pts[b], lens[b], K)
@@ -81,8 +81,8 @@ def test_fps_batched_ragged_and_ties(ops):
         assert nl.cpu().tolist() == [min(l, K) for l in lens]
 
 
-def test_fps_speculative_rounds_on_adversarial_clouds(ops):
-    """algo 3 takes several picks per round and proves them afterwards; clouds built to break the proof's premises:
+def test_fps_bucket_kernels_on_adversarial_clouds(ops):
+    """the bucket kernels prune by bounding boxes; clouds built to stress the pruning and the first-index rule:
     a lattice (every distance tied many times over), two far clusters with duplicates (equal maxima in different
     buckets), points on a line (candidates that change each other), and a K close to the cloud size."""
     gen = torch.Generator().manual_seed(9)
@@ -97,35 +97,33 @@ def test_fps_speculative_rounds_on_adversarial_clouds(ops):
     pts = torch.stack([lattice, clusters, line, uniform])
     for K, lens in ((2500, [N, N, N, N]), (20000, [N, 25000, N, 20001])):
         wants = [O.fps_indices_fast(pts[b], lens[b], K) for b in range(4)]
-        for algo in (3, 4, 5):  # multi-pick rounds; one-wave tree; buckets over the STR packing
+        for algo in (2, 5):  # buckets over grid cells; buckets over the STR packing
             idx, new, nl = ops.fps(pts.to(DEV), _lengths(lens), K, algo=algo)
             for b in range(4):
                 assert torch.equal(idx[b].cpu().long(), wants[b]), (algo, K, b)
                 assert torch.equal(new[b].cpu(), O.gather_masked(pts[b], wants[b]))
 
 
-def test_fps_tree_ragged_batch_full_size(ops):
-    """algo 4 (one wave per frame over the Sort-Tile-Recursive box tree): full-size frames of different valid lengths
+def test_fps_str_packing_ragged_batch_full_size(ops):
+    """algo 5 (bucket kernel over the Sort-Tile-Recursive packing): full-size frames of different valid lengths
     in one launch, including lengths that leave slabs and leaves partly empty, and K beyond a short frame."""
     pts, _ = synthetic.frames(4, 65536)
     pts = pts.transpose(1, 2).contiguous()
     pts[3] = torch.round(pts[3] * 64) / 64  # quantised copy: many exactly equal distances
     lens = [65536, 40001, 16385, 65535]
-    for algo in (4, 5):
+    for algo in (5,):
         idx, new, nl = ops.fps(pts.to(DEV), _lengths(lens), 4096, algo=algo)
         for b in range(4):
             want = O.fps_indices_fast(pts[b], lens[b], 4096)
             assert torch.equal(idx[b].cpu().long(), want), (algo, b)
             assert torch.equal(new[b].cpu(), O.gather_masked(pts[b], want))
-    idx2, _, nl2 = ops.fps(pts[:, :17000].contiguous().to(DEV), _lengths([17000, 100, 0, 1]), 300, algo=4)
     ref2, _, _ = ops.fps(pts[:, :17000].contiguous().to(DEV), _lengths([17000, 100, 0, 1]), 300, algo=2)
-    assert torch.equal(idx2, ref2)  # an empty frame keeps slot 0 = index 0 (utils.py:249-250), like the other kernels
+    # an empty frame keeps slot 0 = index 0 (utils.py:249-250)
     idx5, _, nl5 = ops.fps(pts[:, :17000].contiguous().to(DEV), _lengths([17000, 100, 0, 1]), 300, algo=5)
     assert torch.equal(idx5, ref2) and nl5.cpu().tolist() == [300, 100, 1, 1]
     for b, l in enumerate([17000, 100, 0, 1]):
         if l > 0:
-            assert torch.equal(idx2[b].cpu().long(), O.fps_indices_fast(pts[b, :17000], l, 300)), b
-    assert nl2.cpu().tolist() == [300, 100, 1, 1]
+            assert torch.equal(idx5[b].cpu().long(), O.fps_indices_fast(pts[b, :17000], l, 300)), b
 
 
 def test_fps_beyond_65536_points_per_frame(ops):
@@ -584,26 +582,3 @@ def test_c_abi_from_a_program_without_torch():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert "c abi gpu ok" in out.stdout
-
-
-def test_linear_bf16x3_split_is_exact_and_fp32_accurate(ops):
-    """csrc/gemm_bf16x3.hip (opt-in, DPM_GEMM=bf16x3): the three-term bf16 split reproduces the fp32 weight bit for bit
-    and the six-product contraction is as close to fp64 as the fp32-MFMA kernel."""
-    from deeppointmap_amd import _lib
-    lib = _lib.load()
-    gen = torch.Generator().manual_seed(3)
-    for R, K, N in [(5000, 256, 768), (4097, 64, 132), (300, 1024, 64)]:
-        x = (torch.randn(R, K, generator=gen) * 3).to(DEV)
-        W = (torch.randn(N, K, generator=gen) / K ** 0.5).to(DEV)
-        b, res = torch.randn(N, generator=gen).to(DEV), torch.randn(R, N, generator=gen).to(DEV)
-        Wp = ops.split_bf16x3(W)
-        terms = [(Wp[i].to(torch.int32) << 16).view(torch.float32).double() for i in range(3)]
-        assert torch.equal((terms[0] + terms[1] + terms[2]).float(), W)
-        out = torch.empty(R, N, device=DEV)
-        _lib.check(lib.dpm_linear_bf16x3(ops._ptr(x), K, ops._ptr(Wp), K, N * K, ops._ptr(b), ops._ptr(res), N, ops._ptr(out), N,
-                                         R, K, N, 1, ops._stream(x)), "dpm_linear_bf16x3")
-        ref = (x.double() @ W.double().T + b.double() + res.double()).relu()
-        f32 = ops.linear(x, W, b, act=1, residual=res)
-        scale = float(ref.abs().max())
-        e3, e32 = float((out.double() - ref).abs().max()) / scale, float((f32.double() - ref).abs().max()) / scale
-        assert e3 < 2e-6 and e3 < 2 * e32 + 1e-7, (R, K, N, e3, e32)
