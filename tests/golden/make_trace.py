@@ -16,6 +16,11 @@ loop candidates exist).  Recorded per call, in call order:
   info  : calculate_information_matrix_from_pcd(src scan, dst scan, SE3) -> 6x6.  NEITHER reference branch of this
           function runs here (pytorch3d and open3d are absent): the call sites are the reference's, the VALUES come
           from the oracle restatement of utils.py:72-104 -- "parity unpinned" for this one function, as in DESIGN.md.
+  optim : PoseGraph.optim() as loop_closure.py:294-307 reaches it after a verified loop edge: the graph exactly as
+          __optim_open3d would hand it to open3d (pose_graph.py:565-608: key-frame tokens + SE3_pred, every non-'locz' edge
+          with inv(edge.SE3) and its information matrix, reference node = smallest token).  open3d is absent, so the
+          call is RECORDED and skipped: the poses stay what odometry + scan-to-map made them (which is what every other
+          entry of this trace was recorded with), and the optimiser's VALUES stay unpinned.
   final : exit code per step and every scan's SE3_pred (the trajectory).
 
 A descriptor matrix handed to registration_forward is a column-wise selection of key-frame descriptors whose xyz
@@ -105,7 +110,7 @@ def main():
         loop_detection_gnss_distance=-1, loop_detection_pred_distance=1e9, loop_detection_rotation_min=0.0,
         loop_detection_translation_min=0.0, loop_detection_prob_acpt_threshold=0.0, loop_detection_candidates_num=1,
         registration_sample_loop=0.5, loop_detection_confidence_acpt_threshold=0.0,
-        enable_global_optimization=False, global_optimization_gap=0))
+        enable_global_optimization=True, global_optimization_gap=0))
     enc, dec = RefEncoder(cfg).eval(), RefDecoder(cfg).eval()
     enc.load_state_dict(procedural_state_dict(encoder_shapes(cfg)), strict=True)
     dec.load_state_dict(procedural_state_dict(decoder_shapes(cfg)), strict=True)
@@ -184,6 +189,24 @@ def main():
 
     dec.registration_forward, dec.loop_detection_forward, pg.global_map_query_graph = reg, loop, tile
 
+    def optim(blocking=True):
+        k = len(calls)
+        calls.append(("optim", k))
+        scans = [s for s in pg.get_all_scans() if s.type != "non-keyframe"]
+        toks = [s.token for s in scans]
+        edges = [e for e in pg.get_all_edges() if e.type != "locz" and e.src_scan_token in toks and e.dst_scan_token in toks]
+        out[f"c{k}.tokens"] = np.array(toks, np.int32)
+        out[f"c{k}.SE3"] = torch.stack([s.SE3_pred for s in scans])
+        out[f"c{k}.edge_src"] = np.array([e.src_scan_token for e in edges], np.int32)
+        out[f"c{k}.edge_dst"] = np.array([e.dst_scan_token for e in edges], np.int32)
+        out[f"c{k}.edge_type"] = np.array([e.type for e in edges])
+        out[f"c{k}.edge_T"] = torch.stack([torch.linalg.inv(e.SE3) for e in edges])         # pose_graph.py:593
+        out[f"c{k}.edge_info"] = torch.stack([torch.as_tensor(e.information_mat).float() for e in edges])
+        out[f"c{k}.reference"] = min(toks)
+        print(f"  optim() on {len(toks)} key-frames, {len(edges)} edges ({sum(e.type == 'loop' for e in edges)} loop)", flush=True)
+        return len(toks), len(edges), 0.0
+    pg.optim = optim
+
     def enc_hook(mod, args, res):
         coor, fea, _ = res
         d = torch.cat([fea[0], coor[0] * 60.0], 0)
@@ -247,7 +270,7 @@ def main():
     np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
     kinds = [c[0] for c in calls]
     print(f"slam_trace.npz: {os.path.getsize(path) / 1024:.0f} KiB, {len(calls)} calls: " +
-          ", ".join(f"{k} x{kinds.count(k)}" for k in ("enc", "reg", "loop", "tile", "info")))
+          ", ".join(f"{k} x{kinds.count(k)}" for k in ("enc", "reg", "loop", "tile", "info", "optim")))
 
 
 if __name__ == "__main__":

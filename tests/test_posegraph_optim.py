@@ -171,3 +171,40 @@ def test_g2o_round_trip(tmp_path):
         assert (s, d) == (s2, d2)
         np.testing.assert_allclose(T2, T, atol=1e-9)
         np.testing.assert_allclose(info2, info, atol=1e-12)
+
+
+def test_optimiser_on_the_graphs_the_reference_hands_to_open3d():
+    """tests/golden/slam_trace.npz records the eight PoseGraph.optim() calls of the reference's SlamSystem.step run
+    (loop_closure.py:294-307 -> pose_graph.py:565-608): key-frame tokens and poses, every odometry / loop edge with the
+    transformation and information matrix the reference would give open3d, reference node = smallest token.  open3d is
+    absent, so there is no expected OUTPUT (parity unpinned); what is held here is the call site: the native
+    solver takes exactly that graph, keeps the reference node, lowers the objective open3d minimises, agrees with its numpy
+    statement and with the token-level entry point."""
+    from conftest import load_golden
+    g = load_golden("slam_trace.npz")
+    kinds = [str(k) for k in g["call_kinds"]]
+    calls = [k for k, kind in enumerate(kinds) if kind == "optim"]
+    assert len(calls) == 8
+    for k in calls:
+        toks = [int(t) for t in g[f"c{k}.tokens"]]
+        index = {t: i for i, t in enumerate(toks)}
+        poses = g[f"c{k}.SE3"].astype(np.float64)
+        edges = [(index[int(s)], index[int(d)], X.astype(np.float64), info.astype(np.float64))
+                 for s, d, X, info in zip(g[f"c{k}.edge_src"], g[f"c{k}.edge_dst"], g[f"c{k}.edge_T"], g[f"c{k}.edge_info"])]
+        kinds_e = [str(t) for t in g[f"c{k}.edge_type"]]
+        assert kinds_e.count("loop") >= 1 and kinds_e.count("odom") == len(toks) - 1 and int(g[f"c{k}.reference"]) == min(toks)
+        ref = index[min(toks)]
+        out, st = PG.global_optimization(poses, edges, reference_node=ref, return_stats=True)
+        assert np.isfinite(out).all()
+        np.testing.assert_array_equal(out[ref], poses[ref])
+        assert st["second"]["residual"] <= st["first"]["residual_start"] * (1 + 1e-9)   # never worse than what it was given
+        want, _ = PN.global_optimization(poses, edges, reference_node=ref, return_stats=True)
+        np.testing.assert_allclose(out, want, atol=1e-7)
+        # the token-level entry (edge.SE3 = inverse of the open3d transformation, pose_graph.py:593)
+        nodes = {t: g[f"c{k}.SE3"][i] for t, i in index.items()}
+        tok_edges = [(int(s), int(d), np.linalg.inv(X.astype(np.float64)), info) for s, d, X, info in
+                     zip(g[f"c{k}.edge_src"], g[f"c{k}.edge_dst"], g[f"c{k}.edge_T"], g[f"c{k}.edge_info"])]
+        got, diff = PG.optimize_pose_graph(nodes, tok_edges)
+        for t, i in index.items():
+            np.testing.assert_allclose(got[t], out[i], atol=2e-5)
+        assert diff >= 0.0

@@ -36,7 +36,7 @@ def test_trace_shape():
     g = load_golden("slam_trace.npz")
     kinds = [str(k) for k in g["call_kinds"]]
     assert kinds.count("enc") == 15 and kinds.count("reg") == 40 and kinds.count("loop") == 12
-    assert kinds.count("tile") == 38 and kinds.count("info") == 40
+    assert kinds.count("tile") == 38 and kinds.count("info") == 40 and kinds.count("optim") == 8
     shapes = {(g[f"c{k}.src_tok"].size, g[f"c{k}.dst_tok"].size) for k, kind in enumerate(kinds) if kind == "reg"}
     assert (256, 256) in shapes and (3584, 256) in shapes and (1536, 2304) in shapes
     assert (g["codes"] == 0).all()  # every step ended in EXIT_CODE.acpt: key-frame + scan-to-map + loop closure
@@ -78,9 +78,7 @@ def test_hip_replays_the_whole_trace(trace, cfg_full):
     frames = [T(g[f"frame{i}"]) for i in range(11)]
     frame_of = {int(g[f"s{s}.token"]): int(g[f"s{s}.frame"]) for s in range(len(g["order"]))}
     worst = dict(enc=0.0, dT=0.0, dR=0.0, loop=0.0, tile=0.0, info=0.0)
-    sd_dec = {k: v.detach().cpu() for k, v in dec.flat().items()}
-    ill = []  # registrations whose inlier cut is decided at fp32 rounding level (see O.solve_svd)
-    own = {}  # our own descriptors per scan token, for the end-to-end odometry check below
+    own = {}  # our own descriptors per scan token, for the free-running pass below
     for s in range(len(g["order"])):
         k0, k1 = g[f"s{s}.calls"]
         for k in range(k0, k1):
@@ -97,17 +95,9 @@ def test_hip_replays_the_whole_trace(trace, cfg_full):
                 src, dst = rebuild(g, desc, k, "src"), rebuild(g, desc, k, "dst")
                 R, T_, conf, rmse = dec.registration_forward(src, dst, num_sample=float(g[f"c{k}.num_sample"]))
                 dT, dR = float((T_.cpu() - T(g[f"c{k}.T"])).norm()), rot_angle(R.cpu(), g[f"c{k}.R"])
-                if not (dT < TOL_T and dR < TOL_R):
-                    # The reference's inlier loop keeps residuals <= mean + 3 std (decoder.py:247-251).  When a residual
-                    # sits ON that cut to within fp32 rounding, the answer depends on the order of additions -- the
-                    # reference itself would flip with another BLAS.  Such a call must show that margin in the oracle's
-                    # replay of the very same inputs; it is then held to "one inlier more or fewer".
-                    tr = {}
-                    O.registration_forward(sd_dec, cfg_full, src, dst, float(g[f"c{k}.num_sample"]), trace=tr)
-                    assert min(tr["margins"]) < 1e-5, (k, src.shape, dst.shape, dT, dR, tr["margins"])
-                    assert abs(conf.numel() - int(g[f"c{k}.n_conf"])) <= 2 and dT < 0.05 and dR < 5e-3, (k, dT, dR)
-                    ill.append((k, min(tr["margins"]), dT))
-                    continue
+                # every one of the 40 registrations within the north-star tolerance, no exceptions (rounds 1-2 carried an escape
+                # for calls whose inlier cut sits on a residual to within fp32 rounding; it was never taken on the trace)
+                assert dT < TOL_T and dR < TOL_R, (k, tuple(src.shape), tuple(dst.shape), dT, dR)
                 assert conf.numel() == int(g[f"c{k}.n_conf"]), (k, conf.numel(), int(g[f"c{k}.n_conf"]))
                 assert abs(simvec_to_num(conf) - float(g[f"c{k}.conf30"])) < 1e-4 and abs(rmse - float(g[f"c{k}.rmse"])) < 1e-4
                 worst["dT"], worst["dR"] = max(worst["dT"], dT), max(worst["dR"], dR)
@@ -128,9 +118,45 @@ def test_hip_replays_the_whole_trace(trace, cfg_full):
                 want = g[f"c{k}.G"]
                 assert G.device.type == "cpu" and tuple(G.shape) == (6, 6)
                 worst["info"] = max(worst["info"], float(np.abs(G.numpy() - want).max() / np.abs(want).max()))
-    print("trace replay, worst deviations:", worst, "| ill-conditioned inlier cuts (call, margin, dT):", ill)
-    assert len(ill) <= 4, ill
+    print("trace replay, worst deviations:", worst)
     assert worst["enc"] < 5e-4 and worst["loop"] < 2e-5 and worst["tile"] < 3e-5 and worst["info"] < 1e-3
+
+    # ---- free-running pass: nothing but the scans and the call STRUCTURE comes from the recording.  Our descriptors feed
+    # our odometry registration; its pose places the new scan; our map tile (our descriptors, our poses, centred on our pose
+    # of the previous key-frame) feeds our scan-to-map registration; its pose is the scan's final one (core.py:369-393,
+    # mapping.py:136-170,193-197: with global optimisation off nothing else moves a pose).  The trajectory that comes out is
+    # held to the reference's (`final_SE3`, recoder.py:76-97 writes exactly these).
+    from deeppointmap_amd.registration import PoseTool
+    store2, pose = MapTileStore(dev), {}
+    chain = []
+    for s in range(len(g["order"])):
+        tok_new = int(g[f"s{s}.token"])
+        store2.put(tok_new, own[tok_new])
+        k0, k1 = g[f"s{s}.calls"]
+        regs = [k for k in range(k0, k1) if kinds[k] == "reg"]
+        if not regs:
+            pose[tok_new] = torch.eye(4)
+            continue
+        k_odo, k_s2m = regs[0], regs[1]
+        assert kinds[k_odo + 1] == "info" and kinds[k_s2m - 1] == "tile" and kinds[k_s2m + 1] == "info"
+        tok_old = int(g[f"c{k_odo + 1}.src"])
+        assert int(g[f"c{k_odo + 1}.dst"]) == tok_new and int(g[f"c{k_s2m + 1}.src"]) == tok_old
+        R, T_, _, _ = dec.registration_forward(own[tok_old], own[tok_new], num_sample=float(g[f"c{k_odo}.num_sample"]))
+        pose[tok_new] = pose[tok_old] @ PoseTool.SE3(R.cpu(), T_.cpu()).inverse()          # mapping.py:112
+        toks = [int(t) for t in g[f"c{k_s2m - 1}.tokens"]]
+        tile, tok = store2.tile(toks, [pose[t] for t in toks], pose[tok_old])              # mapping.py:141-145
+        src = tile[:, (tok != tok_new).to(dev)]
+        assert src.shape[1] == g[f"c{k_s2m}.src_tok"].size
+        R, T_, _, _ = dec.registration_forward(src, own[tok_new].to(dev), num_sample=float(g[f"c{k_s2m}.num_sample"]))
+        pose[tok_new] = pose[tok_old] @ PoseTool.SE3(R.cpu(), T_.cpu()).inverse()          # mapping.py:193-195
+        chain.append((float((T_.cpu() - T(g[f"c{k_s2m}.T"])).norm()), rot_angle(R.cpu(), g[f"c{k_s2m}.R"])))
+    final = {int(t): T(x) for t, x in zip(g["final_tokens"], g["final_SE3"])}
+    dev_t = max(float((pose[t][:3, 3] - final[t][:3, 3]).norm()) for t in final)
+    dev_r = max(rot_angle(pose[t][:3, :3], final[t][:3, :3].numpy()) for t in final)
+    print(f"free-running trajectory over {len(final)} scans: worst position {dev_t:.2e} m, worst rotation {dev_r:.2e} rad; "
+          f"worst single scan-to-map edge {max(c[0] for c in chain):.2e} m / {max(c[1] for c in chain):.2e} rad")
+    # the whole trajectory -- 14 chained edges -- within the tolerance of ONE registration (measured: 2.6e-6 m, 1.8e-8 rad)
+    assert dev_t < TOL_T and dev_r < TOL_R, (dev_t, dev_r)
 
 
 @pytest.mark.gpu
