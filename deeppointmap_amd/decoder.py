@@ -16,6 +16,7 @@ the three SLAM threads of the reference can share one instance (system/core.py:5
 """
 from __future__ import annotations
 
+import threading
 from typing import Dict, List, Tuple, Union
 
 import torch
@@ -37,6 +38,15 @@ class Decoder(ParamTree):
         self.tau = args.loss.tau
         self._dim_t: Dict[str, torch.Tensor] = {}
         self.stack_sides = True   # M != N: one launch per row-wise layer over both sides (False: the per-side loop)
+        # One-pair registrations (the reference's own call: odometry.py:108-110, mapping.py:153-155, loop_closure.py:239-242)
+        # are ~50 small launches whose enqueue takes longer than their execution.  A shape (M, N, k) that keeps coming back is
+        # captured once as a HIP graph over static input / output buffers and replayed from then on: same kernels, same
+        # launch arguments, bit-identical results, one host call.  Per thread (the reference shares one Decoder between its
+        # odometry / mapping / loop threads, core.py:55-57) and bounded: the least recently used graph gives its memory back.
+        self.graph_min_hits = 2   # eager calls of a shape before it is captured (0 = never capture)
+        self.graph_max = 6        # captured shapes kept per decoder
+        self._graphs: Dict[tuple, dict] = {}
+        self._graph_lock = threading.Lock()
         self.eval()
 
     # -- helpers -------------------------------------------------------------------------------
@@ -316,6 +326,44 @@ class Decoder(ParamTree):
             pairs = (src_frame, dst_frame) if order is None else (src_frame, dst_frame, order)
             return self._register(descriptors, None, num_sample, header_out, pairs=pairs)
 
+    # -- captured one-pair registrations ---------------------------------------------------------
+    def _weights_stamp(self):
+        return tuple((p.data_ptr(), p._version) for p in self._flat.values())
+
+    def _graph_entry(self, key, M: int, N: int, num_sample, dev):
+        """The graph of shape `key`, captured now if the shape has been seen often enough; None = run eagerly."""
+        with self._graph_lock:
+            e = self._graphs.get(key)
+            if e is None:
+                e = self._graphs[key] = dict(hits=0, graph=None, used=0)
+            e["hits"] += 1
+            e["used"] = max((v["used"] for v in self._graphs.values()), default=0) + 1
+            if e["graph"] is not None:
+                if e["stamp"] == self._weights_stamp():
+                    return e
+                e["graph"] = None            # the weights moved or changed: capture again
+            if self.graph_min_hits <= 0 or e["hits"] <= self.graph_min_hits:
+                return None
+            live = [k for k, v in self._graphs.items() if v["graph"] is not None]
+            if len(live) >= self.graph_max:  # make room: drop the least recently used graph (its private pool is freed)
+                old = min(live, key=lambda k: self._graphs[k]["used"])
+                self._graphs.pop(old)
+        src = torch.zeros(1, self.in_channel + 3, M, device=dev, dtype=torch.float32)
+        dst = torch.zeros(1, self.in_channel + 3, N, device=dev, dtype=torch.float32)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                res = self._register(src, dst, num_sample)
+        except Exception:  # noqa: BLE001  (a shape whose kernels cannot be captured keeps running eagerly)
+            with self._graph_lock:
+                e["hits"] = -(1 << 30)
+            return None
+        torch.cuda.current_stream(dev).wait_stream(side)
+        e.update(graph=g, src=src, dst=dst, res=res, stamp=self._weights_stamp())
+        return e
+
     @torch.no_grad()
     def registration_forward(self, src_descriptor: torch.Tensor, dst_descriptor: torch.Tensor,
                              src_padding_mask=None, dst_padding_mask=None,
@@ -328,8 +376,24 @@ class Decoder(ParamTree):
             src_descriptor, dst_descriptor = src_descriptor.unsqueeze(0), dst_descriptor.unsqueeze(0)
         assert src_descriptor.shape[0] == 1, "batch size in inference must be 1"
         with torch.cuda.device(dev):
-            res = self._register(src_descriptor, dst_descriptor, num_sample, header_out, trace,
-                                 masks=(src_padding_mask, dst_padding_mask))[0]
+            entry = None
+            plain = (src_padding_mask is None and dst_padding_mask is None and trace is None and header_out is None and
+                     src_descriptor.ndim == 3 and dst_descriptor.ndim == 3 and dst_descriptor.shape[0] == 1 and
+                     src_descriptor.shape[1] == self.in_channel + 3 == dst_descriptor.shape[1] and
+                     isinstance(num_sample, (int, float)) and not torch.cuda.is_current_stream_capturing())
+            if plain and self.graph_min_hits > 0:
+                M, N = src_descriptor.shape[2], dst_descriptor.shape[2]
+                k = self._num_pairs(num_sample, M, N)   # raises on an unsupported num_sample, as the eager path does
+                if k >= 1:
+                    entry = self._graph_entry((M, N, k, dev.index, threading.get_ident()), M, N, num_sample, dev)
+            if entry is not None:
+                entry["src"].copy_(src_descriptor, non_blocking=True)
+                entry["dst"].copy_(dst_descriptor, non_blocking=True)
+                entry["graph"].replay()
+                res = entry["res"][0].clone()           # the static buffer belongs to the next replay
+            else:
+                res = self._register(src_descriptor, dst_descriptor, num_sample, header_out, trace,
+                                     masks=(src_padding_mask, dst_padding_mask))[0]
             head = res[:ops.RES_HDR].cpu()  # the one host sync of the call: rmse is a python float in the contract
         n_in, rmse = int(head[14]), float(head[12])
         R, T, cf = res[0:9].view(3, 3), res[9:12].view(3, 1), res[ops.RES_HDR:ops.RES_HDR + n_in]

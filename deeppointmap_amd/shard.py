@@ -38,9 +38,10 @@ def gather_to_root(t: torch.Tensor, root: int = 0) -> Optional[torch.Tensor]:
         out = gather_to_root(t.cpu(), root)
         return out.to(t.device) if out is not None else None
     if rank == root:
-        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.gather(t, gather_list=list(out.unbind(0)), dst=root)
-        return out.reshape((world * t.shape[0],) + tuple(t.shape[1:]))
+        # one tensor of its own per rank (not views of one buffer: a collective is handed plain allocations), joined after
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.gather(t, gather_list=parts, dst=root)
+        return torch.cat(parts, dim=0)
     dist.gather(t, gather_list=None, dst=root)
     return None
 
@@ -68,6 +69,8 @@ def exchange_halo(last_desc: torch.Tensor, last_pcd: Optional[torch.Tensor]):
     against its predecessor).  Sends (descriptor (131,S), scan (3,N) or None) to rank+1, returns what rank-1 sent --
     one point-to-point message per rank and step (134 KB + 786 KB at 65 536 points).  Rank 0 receives the last frame of
     the whole window: the predecessor of ITS first frame in the NEXT step (the caller keeps it until then)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return last_desc, last_pcd  # one rank: its own last frame precedes its next block
     world, rank = dist.get_world_size(), dist.get_rank()
     parts = [last_desc.reshape(-1)] + ([last_pcd.reshape(-1)] if last_pcd is not None else [])
     flat = torch.cat(parts).contiguous()
