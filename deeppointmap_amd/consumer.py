@@ -56,7 +56,8 @@ class Rank0Consumer:
         self.store = MapTileStore(self.device)
         self.type: Dict[int, str] = {}                 # token -> 'full' (key-frame) | 'non-keyframe'
         self.poses: Dict[int, torch.Tensor] = {}       # token -> SE3_pred (4,4) CPU
-        self.edges: Dict[Tuple[int, int], dict] = {}   # (src, dst) -> SE3, type, information, confidence, rmse (insertion order!)
+        self.edges: Dict[Tuple[int, int], dict] = {}   # (src, dst) -> SE3, type, information, confidence, rmse
+        self.adj: Dict[int, List[Tuple[int, dict]]] = {}   # token -> (neighbour, edge) in edge insertion order
         self.desc: Dict[int, torch.Tensor] = {}        # key-frames and the last frame: descriptors on the device
         self.last_known_keyframe: Optional[int] = None
         self.last_known_anyframe: Optional[int] = None
@@ -80,15 +81,15 @@ class Rank0Consumer:
     def keyframes(self) -> List[int]:
         return [t for t, ty in self.type.items() if ty != "non-keyframe"]
 
+    def _add_edge(self, src: int, dst: int, edge: dict) -> None:
+        self.edges[(src, dst)] = edge
+        self.adj.setdefault(src, []).append((dst, edge))
+        self.adj.setdefault(dst, []).append((src, edge))
+
     def _neighbors(self, tok: int, kinds) -> List[int]:
-        out = []
-        for (a, b), e in self.edges.items():           # PoseGraph.get_neighbor_tokens: edge insertion order
-            if e["type"] in kinds:
-                if a == tok:
-                    out.append(b)
-                elif b == tok:
-                    out.append(a)
-        return out
+        """PoseGraph.get_neighbor_tokens filtered by edge type: the other ends of the scan's edges, in the order the edges
+        entered the graph (the reference walks its edge dict; an adjacency list per scan gives the same order)"""
+        return [n for n, e in self.adj.get(tok, ()) if e["type"] in kinds]
 
     def graph_search(self, tok: int, level: int = 5, kinds=("odom", "loop"), max_k: int = 16) -> List[int]:
         """PoseGraph.graph_search (pose_graph.py:513-542)"""
@@ -105,7 +106,7 @@ class Rank0Consumer:
         return list(found)
 
     def add_loop_edge(self, src: int, dst: int, SE3: torch.Tensor, information=None, confidence: float = 1.0, rmse: float = 0.0):
-        self.edges[(src, dst)] = dict(SE3=SE3.clone(), type="loop", information=information, confidence=confidence, rmse=rmse)
+        self._add_edge(src, dst, dict(SE3=SE3.clone(), type="loop", information=information, confidence=confidence, rmse=rmse))
 
     def optimise(self, tokens: Optional[List[int]] = None) -> None:
         """PoseGraph.optim on the key-frames (all, or `tokens`) and the non-'locz' edges between them."""
@@ -200,14 +201,14 @@ class Rank0Consumer:
         if code != ACPT:
             self.type[tok] = "non-keyframe"
             self.last_known_anyframe = tok
-            self.edges[(edge["src"], tok)] = dict(edge, type="locz")
+            self._add_edge(edge["src"], tok, dict(edge, type="locz"))
             self.since_kf, self.chain_ok = edge["SE3"].clone(), True
             self.codes.append(code)
             return code
         self.type[tok] = "full"
         self.store.put(tok, self.desc[tok])
         self.last_known_anyframe = self.last_known_keyframe = tok
-        self.edges[(edge["src"], tok)] = dict(edge)
+        self._add_edge(edge["src"], tok, dict(edge))
         self.stats["keyframes"] += 1
         new = self._scan_to_map(tok, edge)
         if new["rmse"] <= self.args["edge_rmse_drop"] or new["rmse"] <= edge["rmse"]:     # mapping.py:193-201
