@@ -19,8 +19,12 @@ own process.  Same four methods, same return values.  A message travels in two p
     group's backend is nccl (device tensors go as they are, received on the receiver's current device), the control
     group itself otherwise (tensors staged through the host; a tensor that left a GPU arrives on the receiver's GPU
     when it has one).  The receives are posted only after the preamble announced them and the sends right after it, so
-    both sides of an RCCL transfer always exist.  Payloads flow toward one direction per pair at a time (agents upload,
-    the cloud answers with bare commands), as in the reference.
+    both sides of an RCCL transfer always exist.  On the RCCL channel every call of this process -- the caller's sends, the
+    receiver threads' receives -- takes ONE lock (a communicator must not be entered from two threads at once), and tensor
+    payloads may only travel toward a LOWER member id: that is the reference's traffic (agents upload to the cloud, member
+    0, core.py:411-422; the cloud answers with bare commands), and it makes the wait-for relation between blocked sends and
+    receives acyclic -- two ranks that sent payloads to each other at the same moment would each hold their lock in a send
+    whose receive the other cannot post.  A payload in the other direction raises; it has to go over a gloo data channel.
 
 Per (sender, receiver) pair messages arrive in the order they were sent; between different senders the order is arrival
 order, as with the reference's thread-fed queues.  `close()` ends the receiver threads (every member calls it: it is a
@@ -111,8 +115,8 @@ class RankCommunicateModule:
         self.agents = set()
         self.logger: List[tuple] = []
         self.queue: "Queue[Tuple[str, Any]]" = Queue()
-        self._send_lock = threading.Lock()      # one message at a time per process on the channels
-        self._data_lock = threading.Lock()      # RCCL calls of the receiver threads, one at a time
+        self._send_lock = threading.Lock()      # one message at a time per process on the control channel
+        self._nccl_lock = threading.Lock()      # EVERY RCCL call of this process (sends and receives), one at a time
         self._threads: Dict[int, threading.Thread] = {}
         self._closed = False
         self._errors: List[BaseException] = []
@@ -170,6 +174,9 @@ class RankCommunicateModule:
     # -- transport -----------------------------------------------------------------------------------------------
     def _send(self, callee: int, command: str, message: Any) -> None:
         blob, tensors = _pack(command, message)
+        if tensors and self.data_is_nccl and callee >= self.rank:
+            raise ValueError(f"tensor payloads on the RCCL data channel travel toward lower member ids only (member {self.rank} -> "
+                             f"{callee}): see the module header; use a gloo data group for this message")
         payload = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
         with self._send_lock:
             dist.send(torch.tensor([payload.numel(), len(tensors)], dtype=torch.int64), dst=self._global(callee), group=self.control)
@@ -179,7 +186,8 @@ class RankCommunicateModule:
                 if self.data_is_nccl:
                     if not t.is_cuda:
                         t = t.to(self.device)
-                    dist.send(t, dst=self._global(callee, self.data), group=self.data)
+                    with self._nccl_lock:
+                        dist.send(t, dst=self._global(callee, self.data), group=self.data)
                 else:
                     dist.send(t.cpu(), dst=self._global(callee), group=self.data)
 
@@ -196,7 +204,7 @@ class RankCommunicateModule:
                     on_gpu = self.data_is_nccl or (slot.was_cuda and self.device.type == "cuda")
                     if self.data_is_nccl:
                         t = torch.empty(slot.shape, dtype=slot.dtype, device=self.device)
-                        with self._data_lock:
+                        with self._nccl_lock:
                             dist.recv(t, src=self._global(peer, self.data), group=self.data)
                             torch.cuda.current_stream(self.device).synchronize()
                         if not slot.was_cuda:

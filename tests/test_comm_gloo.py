@@ -106,6 +106,16 @@ def _two_channel_worker(rank, world, port, q):
         for i in range(6):
             comm.send_message(caller=1, callee=0, command="UPLOAD_SCAN", message=_scan(1, i))
         ok &= comm.fetch_message(1, block=True) == ("NO_OP", {"hint": 7})
+    # the RCCL channel's rule (module header): tensor payloads only toward lower member ids, refused BEFORE anything is
+    # sent; bare commands go either way.  (RCCL itself cannot run here: the flag is flipped on the gloo-backed module.)
+    comm.data_is_nccl = True
+    try:
+        if rank == 0:
+            comm.send_message(caller=0, callee=1, command="UPLOAD_SCAN", message=_scan(0, 0))
+            ok = False
+    except ValueError:
+        pass
+    comm.data_is_nccl = False
     try:
         RankCommunicateModule(control_group=None, data_group=None, device=torch.device("cpu")).close()   # a second bus coexists
     except Exception:
