@@ -1399,8 +1399,15 @@ extern "C" int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int l
     DPM_CHECK_ARG(src_xyz && dst_xyz && conf && workspace && result && batch >= 1);
     DPM_CHECK_ARG(!offsets || (src_idx && dst_idx));
     DPM_CHECK_ARG(k >= 1 && ld_src >= 3 && ld_dst >= 3 && num_iter >= 1 && (!header || header_stride >= RES_HDR));
-    if (k > 6000) return DPM_EUNSUPPORTED;  // the 2k weights + replay scratch live in LDS: 24 B per pair
+    // the 2k weights + replay scratch live in dynamic LDS, 24 B per pair, next to the kernel's static arrays: what fits the
+    // CU's 160 KB bounds k (about 6000 on gfx950; the decoder asks for at most 4096)
     const size_t kabsch_lds = (sizeof(VI) + 4) * 2 * (size_t)k;
+    static size_t kabsch_static = 0;
+    if (!kabsch_static) {
+        hipFuncAttributes fa;
+        kabsch_static = hipFuncGetAttributes(&fa, (const void *)corr_kabsch_kernel) == hipSuccess ? fa.sharedSizeBytes + 1 : 8 * 1024;
+    }
+    if (kabsch_static + kabsch_lds > 160 * 1024) return DPM_EUNSUPPORTED;
     if (kabsch_lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)corr_kabsch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kabsch_lds);
         if (e != hipSuccess) return (int)e;

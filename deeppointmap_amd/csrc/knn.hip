@@ -1522,10 +1522,23 @@ extern "C" int dpm_knn_hybrid_reuse(const float *points, const int32_t *lengths,
         launch_grid_build(points, lengths, B, N, radius, w, st);
         return launch_grid_search(points, lengths, centers, B, N, S, K, r2, idx, w, reuse_idx, center_src, st);
     }
-    const int nth_rows = (long long)K * 64 > (long long)N;  // torch.topk's nth_element regime: tied rows are replayed
-    hipLaunchKernelGGL(knn_hybrid_kernel, dim3(dpm_cdiv(S, WPB * CPW), B), dim3(WPB * 64),
-                       nth_rows ? (sizeof(VI) + 4) * (size_t)WPB * N : 0, st, points, lengths, centers, N, S, K, r2, idx, reuse_idx,
-                       center_src, nth_rows);
+    int nth_rows = (long long)K * 64 > (long long)N;  // torch.topk's nth_element regime: tied rows are replayed
+    // The replay keeps a row of N (value, index) pairs + scratch per wave in dynamic LDS, next to the kernel's static lists.
+    // A frame too long for what is left of the CU's 160 KB (about 1900 points; the encoder sends frames from 1024 points on
+    // to the grid search, so only a forced brute-force call gets here) runs without it: tied rows then keep the smaller index.
+    size_t dyn = nth_rows ? (sizeof(VI) + 4) * (size_t)WPB * N : 0;
+    if (dyn) {
+        static size_t static_lds = 0;
+        if (!static_lds) {
+            hipFuncAttributes fa;
+            static_lds = hipFuncGetAttributes(&fa, (const void *)knn_hybrid_kernel) == hipSuccess ? fa.sharedSizeBytes : 72 * 1024;
+        }
+        if (static_lds + dyn > 160 * 1024) nth_rows = 0, dyn = 0;
+        else if (dyn > 32 * 1024)
+            (void)hipFuncSetAttribute((const void *)knn_hybrid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    }
+    hipLaunchKernelGGL(knn_hybrid_kernel, dim3(dpm_cdiv(S, WPB * CPW), B), dim3(WPB * 64), dyn, st, points, lengths, centers, N, S,
+                       K, r2, idx, reuse_idx, center_src, nth_rows);
     return dpm_launch_status();
 }
 

@@ -306,7 +306,17 @@ int levenberg_marquardt(Graph &g, const Criteria &crit, double *stats) {
     while (!stop) {
         int lm = 0;
         while (true) {
-            if (!solve_damped(g, H, lam, b, delta)) return DPM_EINVAL;
+            if (!solve_damped(g, H, lam, b, delta)) {
+                // the damped matrix is not positive definite (a degenerate or indefinite information matrix): more damping,
+                // as after a rejected step; out of tries, the pass ends with the poses it has (open3d reports a failed solve
+                // and carries on with the current poses as well)
+                lam = std::max(lam * ni, 1e-12 * std::max(hmax, 1.0)), ni *= 2.0;
+                if (++lm >= crit.max_iteration_lm) {
+                    stop = true;
+                    break;
+                }
+                continue;
+            }
             stop = stop || norm2(delta) < crit.min_relative_increment * (norm2(x) + crit.min_relative_increment);
             if (!stop) {
                 for (int i = 0; i < g.n; ++i) {
@@ -356,8 +366,19 @@ extern "C" int dpm_posegraph_optimize(const double *poses, int n, const int32_t 
     DPM_CHECK_ARG(n >= 0 && E >= 0 && out_poses && stats && (n == 0 || poses) && (E == 0 || (src && dst && X && info)));
     DPM_CHECK_ARG(n == 0 || (reference_node >= 0 && reference_node < n));
     for (int k = 0; k < E; ++k) DPM_CHECK_ARG(src[k] >= 0 && src[k] < n && dst[k] >= 0 && dst[k] < n);
+    for (size_t i = 0; i < (size_t)16 * n; ++i) DPM_CHECK_ARG(std::isfinite(poses[i]));
+    for (size_t i = 0; i < (size_t)16 * E; ++i) DPM_CHECK_ARG(std::isfinite(X[i]));
+    // the assembly reads an information matrix as symmetric: hand it its symmetric part (callers drop non-finite edges)
+    std::vector<double> info_sym((size_t)36 * E);
+    for (int k = 0; k < E; ++k)
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+                const double v = 0.5 * (info[(size_t)36 * k + 6 * r + c] + info[(size_t)36 * k + 6 * c + r]);
+                DPM_CHECK_ARG(std::isfinite(v));
+                info_sym[(size_t)36 * k + 6 * r + c] = v;
+            }
     Graph g;
-    g.n = n, g.E = E, g.src = src, g.dst = dst, g.info = info;
+    g.n = n, g.E = E, g.src = src, g.dst = dst, g.info = info_sym.data();
     g.poses.assign(poses, poses + (size_t)16 * n);
     g.Xinv.resize((size_t)16 * E);
     for (int k = 0; k < E; ++k) inv_rigid(X + (size_t)16 * k, &g.Xinv[(size_t)16 * k]);

@@ -41,8 +41,12 @@ class Decoder(ParamTree):
         # One-pair registrations (the reference's own call: odometry.py:108-110, mapping.py:153-155, loop_closure.py:239-242)
         # are ~50 small launches whose enqueue takes longer than their execution.  A shape (M, N, k) that keeps coming back is
         # captured once as a HIP graph over static input / output buffers and replayed from then on: same kernels, same
-        # launch arguments, bit-identical results, one host call.  Per thread (the reference shares one Decoder between its
-        # odometry / mapping / loop threads, core.py:55-57) and bounded: the least recently used graph gives its memory back.
+        # launch arguments, bit-identical results, one host call.  Bounded: the least recently used graph gives its memory
+        # back.  A capture is an event for the whole process on this runtime -- another thread that synchronises or allocates
+        # meanwhile fails with "operation not permitted when stream is capturing" (measured with three threads on one
+        # Decoder, in every capture mode) -- so shapes are only captured while the process has ONE Python thread: the
+        # reference's single-thread SlamSystem.step, bench.py, the rank-0 consumer.  Its multi-thread mode (one Decoder
+        # shared by the odometry / mapping / loop threads, core.py:55-57) keeps launching eagerly.
         self.graph_min_hits = 2   # eager calls of a shape before it is captured (0 = never capture)
         self.graph_max = 6        # captured shapes kept per decoder
         self._graphs: Dict[tuple, dict] = {}
@@ -342,7 +346,7 @@ class Decoder(ParamTree):
                 if e["stamp"] == self._weights_stamp():
                     return e
                 e["graph"] = None            # the weights moved or changed: capture again
-            if self.graph_min_hits <= 0 or e["hits"] <= self.graph_min_hits:
+            if self.graph_min_hits <= 0 or e["hits"] <= self.graph_min_hits or threading.active_count() > 1:
                 return None
             live = [k for k, v in self._graphs.items() if v["graph"] is not None]
             if len(live) >= self.graph_max:  # make room: drop the least recently used graph (its private pool is freed)
@@ -354,7 +358,7 @@ class Decoder(ParamTree):
         side.wait_stream(torch.cuda.current_stream(dev))
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="relaxed"):
                 res = self._register(src, dst, num_sample)
         except Exception:  # noqa: BLE001  (a shape whose kernels cannot be captured keeps running eagerly)
             with self._graph_lock:

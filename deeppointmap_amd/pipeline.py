@@ -55,6 +55,7 @@ class HotPath:
         # instead of the batch's own last frame (the single-GPU ring, which costs the same and needs no hand-over)
         self.chain = False
         self._halo = None      # (descriptor, scan) of the frame before the next batch
+        self._no_predecessor = False
         self._side = None      # side HIP streams for the software pipeline (submit / flush)
         self._pending = None
         self._rings = {}
@@ -74,6 +75,9 @@ class HotPath:
         F = desc.shape[0] - 1
         last = (desc[F - 1], pcd_m[F - 1] if pcd_m is not None else None)
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # the very first batch of a chain (on rank 0) has no predecessor: slot F is filled with the batch's own last frame so
+        # that the kernels have something to read, and register() marks edge 0 as void (see `_void_first`)
+        self._no_predecessor = self._halo is None and (not multi or dist.get_rank() == 0)
         if multi:
             got = exchange_halo(*last)
             if dist.get_rank() == 0:  # what arrives is the end of the whole window: the predecessor for the NEXT step
@@ -85,6 +89,15 @@ class HotPath:
                                (last[0].clone(), last[1].clone() if last[1] is not None else None))
         desc[F].copy_(use[0])
         return use[1]
+
+    @staticmethod
+    def _void_first(table: torch.Tensor) -> None:
+        """Edge row 0 of a chain's first batch: there is no frame before frame 0, so the row carries no edge -- identity pose,
+        rmse +inf, zero correspondences / inliers, zero information.  Consumers skip a row with n_inlier == 0 and infinite rmse
+        (Rank0Consumer never reads the row of the first scan of its graph)."""
+        row = torch.zeros(table.shape[1], device=table.device, dtype=table.dtype)
+        row[0], row[4], row[8], row[12] = 1.0, 1.0, 1.0, float("inf")
+        table[0].copy_(row)
 
     @torch.no_grad()
     def register(self, desc: torch.Tensor, pcd_m: Optional[torch.Tensor], pairs, table: Optional[torch.Tensor] = None,
@@ -152,8 +165,15 @@ class HotPath:
         desc = self.extract(points, padding)
         F = points.shape[0]
         halo_pcd = self._hand_over(desc, pcd_m) if self.chain else None
+        void = self.chain and self._no_predecessor
         pairs, index = self._ring_pairs(F, desc.device, self.chain)
         edges, table = self.register(desc, pcd_m, pairs, materialize=materialize, pair_index=index, halo_pcd=halo_pcd)
+        if void:
+            self._void_first(table)
+            if edges:
+                dev = desc.device
+                edges[0] = Edge(pairs[0][0], pairs[0][1], torch.eye(3, device=dev), torch.zeros(3, 1, device=dev),
+                                torch.empty(0, device=dev), float("inf"), None)
         return desc[:F], edges, table
 
     # -- streaming mode: software pipeline over consecutive batches ----------------------------------------
@@ -249,14 +269,15 @@ class HotPath:
                     halo_pcd.record_stream(sb)
             desc_ready = main.record_event()
         desc.record_stream(sb)
-        reg, self._pending["reg"] = self._pending["reg"], (desc, desc_ready, pcd_m, halo_pcd if self.chain else None)
+        reg, self._pending["reg"] = self._pending["reg"], (desc, desc_ready, pcd_m, halo_pcd if self.chain else None,
+                                                       self.chain and self._no_predecessor)
         return self._register_on_b(reg) if reg is not None else None
 
     def _register_on_b(self, reg):
         dev = self.encoder.device
         main = torch.cuda.current_stream(dev)
         sb = self._side["reg"]
-        desc, desc_ready, scans, halo_pcd = reg
+        desc, desc_ready, scans, halo_pcd, void = reg
         F = desc.shape[0] - (1 if self.chain else 0)
         pairs, index = self._ring_pairs(F, dev, self.chain)
         with torch.cuda.stream(sb):
@@ -266,6 +287,8 @@ class HotPath:
                 pcd_m, grids, grids_ready = scans
                 sb.wait_event(grids_ready)
             _, table = self.register(desc, pcd_m, pairs, materialize=False, pair_index=index, grids=grids, halo_pcd=halo_pcd)
+            if void:
+                self._void_first(table)
             done = sb.record_event()
         table.record_stream(main)
         # Results are handed out ONE call later (`_hand_out`): the caller's stream -- which is also the feature stage's --

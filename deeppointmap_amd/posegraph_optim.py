@@ -128,8 +128,11 @@ def optimize_pose_graph(node_SE3: Dict[int, np.ndarray], edges: List[Tuple[int, 
     index = {t: i for i, t in enumerate(tokens)}
     base = min(tokens) if base_token is None else base_token
     poses = np.stack([np.asarray(node_SE3[t], dtype=np.float64) for t in tokens]) if tokens else np.zeros((0, 4, 4))
+    # edges with a non-finite transformation or information matrix (a zero-pair registration returns NaN poses, as the
+    # reference's does) say nothing about the graph: they are left out, as hanging edges are
     packed = [(index[s], index[d], np.linalg.inv(np.asarray(T, dtype=np.float64)), np.asarray(info, dtype=np.float64))
-              for s, d, T, info in edges if s in index and d in index]
+              for s, d, T, info in edges if s in index and d in index
+              and np.isfinite(np.asarray(T, dtype=np.float64)).all() and np.isfinite(np.asarray(info, dtype=np.float64)).all()]
     refined = global_optimization(poses, packed, reference_node=index[base]) if tokens else poses
     out = {t: refined[i].astype(np.float32) for t, i in index.items()}
     diff = [float(np.linalg.norm(poses[i][:3, 3].astype(np.float32) - out[t][:3, 3])) for t, i in index.items()]

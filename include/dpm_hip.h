@@ -313,7 +313,9 @@ int dpm_mean_rows(const float *x, int B, int R, int C, float *out, int ldo, dpm_
  * offsets == NULL: src_xyz/dst_xyz/conf are taken as k ready-made correspondences (rows) and
  * only _solve_transformation_SVD runs.  `batch` independent pairs: offsets (batch,2k,3), indices
  * and conf (batch,k), coordinates at src_xyz + b*stride_src, result (batch, 20+2k), header rows
- * header_stride floats apart. */
+ * header_stride floats apart.  Limit: the 2k weights and the torch.topk replay scratch live in LDS (24 B per pair next to
+ * the kernel's static arrays, together at most the CU's 160 KB: k up to about 6000 on gfx950); beyond that
+ * DPM_EUNSUPPORTED. */
 size_t dpm_kabsch_workspace_bytes(int batch, int k);
 int dpm_corr_kabsch(const float *offsets, const float *src_xyz, int ld_src, long long stride_src,
                     const float *dst_xyz, int ld_dst, long long stride_dst, const int32_t *src_idx,

@@ -374,3 +374,42 @@ def test_map_vs_map_registration_vs_oracle(dec, cfg_full, sd_dec):
     dT, dR = float((Tt.cpu() - To).norm()), rot_angle(R.cpu(), Ro)
     assert dT < 1e-4 and dR < 1e-4, (dT, dR)
     assert conf.shape[0] == co.shape[0] and abs(rmse - ro) < 1e-3
+
+
+@pytest.mark.gpu
+def test_registration_forward_replays_a_captured_graph_bit_for_bit(cfg_full):
+    """A one-pair shape that keeps coming back is captured as a HIP graph (decoder.py: `graph_min_hits`) and replayed: R, T,
+    the inlier confidences and rmse must be the eager launches' bits, for fresh inputs too, at the three shapes of a SLAM
+    step's registrations; new weights invalidate the graph."""
+    import threading
+    from deeppointmap_amd.decoder import Decoder
+    from deeppointmap_amd.weights import init_procedural
+    if threading.active_count() > 1:
+        pytest.skip("graphs are only captured in single-threaded processes (decoder.py)")
+    dev = torch.device("cuda:0")
+    dec = init_procedural(Decoder(cfg_full)).to(dev)
+    gen = torch.Generator().manual_seed(11)
+
+    def pair(M, N):
+        return (torch.cat([torch.rand(128, M, generator=gen), 60 * torch.randn(3, M, generator=gen)]).to(dev),
+                torch.cat([torch.rand(128, N, generator=gen), 60 * torch.randn(3, N, generator=gen)]).to(dev))
+
+    for M, N in ((256, 256), (1024, 256), (768, 512)):
+        inputs = [pair(M, N) for _ in range(5)]
+        dec.graph_min_hits = 0
+        eager = [dec.registration_forward(s, d, num_sample=0.5) for s, d in inputs]
+        dec.graph_min_hits = 2
+        replay = [dec.registration_forward(s, d, num_sample=0.5) for s, d in inputs]
+        assert any(v["graph"] is not None for k, v in dec._graphs.items() if k[:2] == (M, N))
+        for e, r in zip(eager, replay):
+            assert torch.equal(e[0], r[0]) and torch.equal(e[1], r[1]) and torch.equal(e[2], r[2]) and e[3] == r[3]
+    # weights edited in place: the captured graph would still read the right memory, but the stamp says "changed" and the
+    # shape is captured again
+    s, d = pair(256, 256)
+    before = dec.registration_forward(s, d, num_sample=0.5)
+    with torch.no_grad():
+        dec.p("similarity_head.2.weight").mul_(1.5)
+    after = dec.registration_forward(s, d, num_sample=0.5)
+    dec.graph_min_hits = 0
+    want = dec.registration_forward(s, d, num_sample=0.5)
+    assert torch.equal(after[0], want[0]) and torch.equal(after[1], want[1]) and not torch.equal(before[2], after[2])

@@ -208,3 +208,26 @@ def test_optimiser_on_the_graphs_the_reference_hands_to_open3d():
         for t, i in index.items():
             np.testing.assert_allclose(got[t], out[i], atol=2e-5)
         assert diff >= 0.0
+
+
+def test_degenerate_edges_do_not_abort_the_optimisation():
+    """a NaN edge (zero-pair registration) is left out at the token level; an indefinite information matrix makes the damped
+    system non-positive-definite: the solver raises the damping instead of giving up, and returns finite poses"""
+    rng = np.random.default_rng(5)
+    gt, init, edges = _loop(6, rng)
+    tokens = list(range(10, 16))
+    nodes = {t: init[i].astype(np.float32) for i, t in enumerate(tokens)}
+    ref_edges = [(tokens[s], tokens[d], np.linalg.inv(X), info) for s, d, X, info in edges]
+    clean, _ = PG.optimize_pose_graph(nodes, ref_edges)
+    bad = ref_edges + [(tokens[1], tokens[4], np.full((4, 4), np.nan), np.eye(6)), (tokens[0], tokens[3], np.eye(4), np.full((6, 6), np.nan))]
+    got, _ = PG.optimize_pose_graph(nodes, bad)
+    for t in tokens:
+        np.testing.assert_array_equal(got[t], clean[t])
+    indefinite = list(edges)
+    s, d, X, info = indefinite[2]
+    indefinite[2] = (s, d, X, -info)                    # pulls the wrong way: H is not SPD at small damping
+    out = PG.global_optimization(init, indefinite, reference_node=0)
+    assert np.isfinite(out).all()
+    asym = [(s, d, X, info + np.triu(np.ones((6, 6)), 1)) for s, d, X, info in edges]     # only the symmetric part counts
+    sym = [(s, d, X, info + 0.5 * (np.triu(np.ones((6, 6)), 1) + np.tril(np.ones((6, 6)), -1))) for s, d, X, info in edges]
+    np.testing.assert_allclose(PG.global_optimization(init, asym), PG.global_optimization(init, sym), atol=1e-12)
