@@ -16,6 +16,7 @@ the three SLAM threads of the reference can share one instance (system/core.py:5
 """
 from __future__ import annotations
 
+import copy
 import threading
 from typing import Dict, List, Tuple, Union
 
@@ -52,6 +53,20 @@ class Decoder(ParamTree):
         self._graphs: Dict[tuple, dict] = {}
         self._graph_lock = threading.Lock()
         self.eval()
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(decoder) (infer_multiagents.py:100,112-113 makes one copy per agent): parameters and settings are
+        copied, captured graphs and their lock are not -- a copy captures its own."""
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_graphs":
+                new.__dict__[k] = {}
+            elif k == "_graph_lock":
+                new.__dict__[k] = threading.Lock()
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     # -- helpers -------------------------------------------------------------------------------
     @property
