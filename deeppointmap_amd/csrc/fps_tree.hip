@@ -102,10 +102,35 @@ __global__ __launch_bounds__(SB) void fps_tree_sort_kernel(const float *__restri
     if (len == 0) return;
 
     float lox = __builtin_inff(), loy = __builtin_inff(), hix = -__builtin_inff(), hiy = -__builtin_inff();
-    for (int i = t; i < len; i += SB) {
-        const float x = xyz[3 * i], y = xyz[3 * i + 1];
+    // every pass fetches UB elements per thread before it uses the first (unconditional loads from clamped positions):
+    // 64 dependent round trips per thread and pass otherwise -- five passes of them made this kernel a latency chain
+    constexpr int UB = 8;
+    auto for_points = [&](auto &&fn) {   // fn(original index, x, y, z)
+        for (int i0 = t; i0 < len; i0 += SB * UB) {
+            float xs[UB], ys[UB], zs[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int i = min(i0 + u * SB, len - 1);
+                xs[u] = xyz[3 * i], ys[u] = xyz[3 * i + 1], zs[u] = xyz[3 * i + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (i0 + u * SB < len) fn(i0 + u * SB, xs[u], ys[u], zs[u]);
+        }
+    };
+    auto for_sorted = [&](auto &&fn) {   // fn(position, element of the x-sorted array)
+        for (int p0 = t; p0 < len; p0 += SB * UB) {
+            float4 e[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) e[u] = f.tmp[min(p0 + u * SB, len - 1)];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (p0 + u * SB < len) fn(p0 + u * SB, e[u]);
+        }
+    };
+    for_points([&](int, float x, float y, float) {
         lox = fminf(lox, x), hix = fmaxf(hix, x), loy = fminf(loy, y), hiy = fmaxf(hiy, y);
-    }
+    });
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         lox = fminf(lox, __shfl_xor(lox, off, 64));
@@ -126,7 +151,7 @@ __global__ __launch_bounds__(SB) void fps_tree_sort_kernel(const float *__restri
     auto ybin = [&](float y) { return min(max((int)((y - loy) * syc), 0), YB - 1); };
 
     // ---- pass 1: counting sort by x bin into tmp (x, y, z, original index)
-    for (int i = t; i < len; i += SB) atomicAdd(&s_hist[xbin(xyz[3 * i])], 1);
+    for_points([&](int, float x, float, float) { atomicAdd(&s_hist[xbin(x)], 1); });
     __syncthreads();
     {
         const int c0 = s_hist[4 * t], c1 = s_hist[4 * t + 1], c2 = s_hist[4 * t + 2], c3 = s_hist[4 * t + 3];
@@ -148,11 +173,10 @@ __global__ __launch_bounds__(SB) void fps_tree_sort_kernel(const float *__restri
         s_hist[4 * t + 3] = excl + c0 + c1 + c2;
     }
     __syncthreads();
-    for (int i = t; i < len; i += SB) {
-        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    for_points([&](int i, float x, float y, float z) {
         const int pos = atomicAdd(&s_hist[xbin(x)], 1);
         f.tmp[pos] = make_float4(x, y, z, __int_as_float(i));
-    }
+    });
     __threadfence_block();
     __syncthreads();
 
@@ -163,7 +187,7 @@ __global__ __launch_bounds__(SB) void fps_tree_sort_kernel(const float *__restri
     const int slab_pts = lps * LEAF;
     for (int c = t; c < nsx * YB; c += SB) s_hist[c] = 0;
     __syncthreads();
-    for (int pos = t; pos < len; pos += SB) atomicAdd(&s_hist[(pos / slab_pts) * YB + ybin(f.tmp[pos].y)], 1);
+    for_sorted([&](int pos, const float4 e) { atomicAdd(&s_hist[(pos / slab_pts) * YB + ybin(e.y)], 1); });
     __syncthreads();
     {
         // 32 threads per slab, 16 bins each; exclusive scan inside the slab
@@ -187,8 +211,7 @@ __global__ __launch_bounds__(SB) void fps_tree_sort_kernel(const float *__restri
     }
     __syncthreads();
     const float s0x = xyz[0], s0y = xyz[1], s0z = xyz[2];  // the first pick is index 0 (utils.py:249-250)
-    for (int pos = t; pos < len; pos += SB) {
-        const float4 p = f.tmp[pos];
+    for_sorted([&](int pos, const float4 p) {
         const int slab = pos / slab_pts;
         const int j = atomicAdd(&s_hist[slab * YB + ybin(p.y)], 1);
         const int tile = j >> 6;
@@ -202,7 +225,7 @@ __global__ __launch_bounds__(SB) void fps_tree_sort_kernel(const float *__restri
             f.pts[q] = make_float4(p.x, p.y, p.z, sqdist(s0x, s0y, s0z, p.x, p.y, p.z));
             f.orig[q] = __float_as_int(p.w);
         }
-    }
+    });
 }
 
 }  // namespace

@@ -512,11 +512,26 @@ __global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float *__res
     const float *pts = points_all + (size_t)b * N * 3;
     const int len = min(max(lengths[b], 0), N);
     float lox = __builtin_inff(), loy = lox, hix = -lox, hiy = -lox, m2 = 0.f;
-    for (int i = t; i < len; i += 1024) {
-        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    // every pass over the frame fetches UB points per thread before it uses the first (unconditional loads from clamped
+    // positions): a pass is 64 dependent round trips per thread otherwise -- the kernel is a latency chain on 64 CUs
+    constexpr int UB = 8;
+    auto for_points = [&](auto &&fn) {
+        for (int i0 = t; i0 < len; i0 += 1024 * UB) {
+            float xs[UB], ys[UB], zs[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int i = min(i0 + u * 1024, len - 1);
+                xs[u] = pts[3 * i], ys[u] = pts[3 * i + 1], zs[u] = pts[3 * i + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (i0 + u * 1024 < len) fn(i0 + u * 1024, xs[u], ys[u], zs[u]);
+        }
+    };
+    for_points([&](int, float x, float y, float z) {
         lox = fminf(lox, x), hix = fmaxf(hix, x), loy = fminf(loy, y), hiy = fmaxf(hiy, y);
         m2 = fmaxf(m2, sq3(x, y, z));
-    }
+    });
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         lox = fminf(lox, __shfl_xor(lox, off, 64)), loy = fminf(loy, __shfl_xor(loy, off, 64));
@@ -559,7 +574,7 @@ __global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float *__res
         const int cy = min(max((int)floorf((y - loy) * inv_cs), 0), g - 1);
         return cy * g + cx;
     };
-    for (int i = t; i < len; i += 1024) atomicAdd(&s_hist[cell(pts[3 * i], pts[3 * i + 1])], 1);
+    for_points([&](int, float x, float y, float) { atomicAdd(&s_hist[cell(x, y)], 1); });
     __syncthreads();
     // exclusive scan over the counters, 16 per thread
     constexpr int PER = GDIM * GDIM / 1024;
@@ -587,11 +602,10 @@ __global__ __launch_bounds__(1024) void knn_grid_build_kernel(const float *__res
     if (t == 0) hdr_all[b] = KnnGrid{lox, loy, inv_cs, g, err2, H, hin, 0};
     __syncthreads();
     float4 *sorted = sorted_all + (size_t)b * N;
-    for (int i = t; i < len; i += 1024) {
-        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    for_points([&](int i, float x, float y, float z) {
         const int pos = atomicAdd(&s_hist[cell(x, y)], 1);
         sorted[pos] = make_float4(x, y, z, __int_as_float(i));
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
