@@ -35,7 +35,7 @@ while time.time() - t0 < budget and not bad:
                         O.fps_indices(xyz[b], int(lens[b]), K, start=int(start[b])) for b in range(B)]) \
         if (start is None or N * K < 3e7) else None
     if want is not None:
-        algos = [0] if start is not None else ([0, 1, 2] if N <= 16384 else [0, 2, 4, 5])
+        algos = [0] if start is not None else ([0, 1, 2] if N <= 16384 else [0, 2, 5])
         for a in algos:
             got = ops.fps(xyz.to(dev), lens.to(dev), K, algo=a, start=None if start is None else start.to(dev))[0].cpu().long()
             w = want.clone()

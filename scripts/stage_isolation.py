@@ -76,7 +76,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
 occ = ctypes.CDLL(os.path.join(d, "libocc.so"))
 occ.launch_occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
 so = torch.cuda.Stream(device=dev)
-for wgs, threads, lds in ((128, 1024, 33408), (128, 256, 33408), (128, 1024, 0)):
+for wgs, threads, lds in ((128, 1024, 33408), (128, 512, 33408), (128, 256, 33408), (128, 1024, 0), (64, 1024, 33408)):
     torch.cuda.synchronize()
     # 100 MHz constant clock: 25 ms per launch, relaunched back to back on the side stream
     for _ in range(8):
