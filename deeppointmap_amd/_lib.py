@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must precede the CDLL below: libdpm_hip.so has to
 from ctypes import c_char_p, c_double, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdpm_hip.so")
+LIB_PATH = os.environ.get("DPM_LIB") or os.path.join(_HERE, "libdpm_hip.so")  # DPM_LIB: an experimental build (scripts/)
 
 P, I, D, LL = c_void_p, c_int, c_double, c_longlong
 
