@@ -905,7 +905,9 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_fast_kernel(const int32_t *
         if (it < 12) {  // interpolate in the distance domain (simulated on the benchmark scans: 6.9 probes per wave against 9.1
                        // with three interpolations + bisection; bisection afterwards bounds the tie case)
             const float dl = fmaxf(fkey_inv(lo_k), 0.f), dh = fkey_inv(hi_k);
-            const float td = dl + (dh - dl) * ((float)(K - c_lo) / (float)(c_hi - c_lo));
+            // (the probe is a guess that is clamped into the bracket below: a reciprocal approximation instead of an IEEE
+            // division, ten instructions fewer per probe)
+            const float td = dl + (dh - dl) * ((float)(K - c_lo) * __builtin_amdgcn_rcpf((float)(c_hi - c_lo)));
             t = fkey(td);
             t = (t <= lo_k || t >= hi_k) ? lo_k + (int)(((unsigned)hi_k - (unsigned)lo_k) >> 1) : t;
         } else {
