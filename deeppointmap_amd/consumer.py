@@ -1,33 +1,43 @@
-"""The sequential part of the SLAM front/back end that stays on rank 0 after the frame-sharded encode: what
-SlamSystem.step does with a new scan once its descriptors and its speculative odometry edge exist (reference
-system/core.py:382-407):
+"""The sequential part of the SLAM front / back end that stays on rank 0 after the frame-sharded encode: everything
+SlamSystem.step does with a new scan once its descriptors exist (reference system/core.py:382-407), with every
+registration, loop-detection batch, map tile and information matrix on the device path:
 
+  * OdometryThread (odometry.py:76-131): the key-frame of the graph neighbourhood nearest to the last known pose is the
+    registration partner; edge.SE3 = registration^-1, information matrix from the two full clouds;
   * MappingThread.valid_check (mapping.py:52-83): an edge below `edge_confidence_drop` or above `edge_rmse_drop` drops its
-    scan; after `max_continuous_drop_scan` drops in a row the best of the bag is recovered;
+    scan; the `max_continuous_drop_scan`-th drop in a row is accepted instead ('recover': the reference picks the best of
+    the bag into LOCAL names and then carries on with the scan at hand -- so do we);
   * MappingThread.keyframe_check (mapping.py:85-134): the new pose = key-frame pose @ edge; the scan is a key-frame unless a
     key-frame of the graph neighbourhood (PoseGraph.graph_search: breadth first over odometry / loop edges, five levels, at
     most 16 scans; pose_graph.py:513-542) lies within `key_frame_distance` (fixed, or 'auto': the running ratio of
     mapping.py:86-92);
   * MappingThread.scan_to_map_adjustment (mapping.py:136-170) for every key-frame: the tile of the same graph neighbourhood
-    (device resident: maptile.MapTileStore), centred on the previous key-frame, minus the new scan's own columns, registered
-    against the new scan; accepted under mapping.py:193-201;
-  * the pose-graph optimisation that follows loop closures (loop_closure.py:294-307).  Loop DETECTION is not rebuilt here:
-    `add_loop_edge` takes edges from whoever ran it (tests: the reference's recorded ones); bench.py, which only needs the
-    cost of the optimiser, closes a loop over the last `optimize_every` key-frames.
+    within 20 m (pose_graph.py:471-511; device resident: maptile.MapTileStore), centred on the previous key-frame, minus
+    the new scan's own columns, registered against the new scan; accepted under mapping.py:193-201;
+  * LoopThread.process (loop_closure.py:56-307) for every key-frame: candidates = key-frames outside the trusted zones and
+    inside the search radius, one `loop_detection_forward` batch, the top-k above the probability threshold; for each, the
+    two neighbourhood tiles with the shared scans dealt to the nearer side, one map-to-map registration, the information
+    matrix of the two scans; verification by confidence and by the disagreement with the graph path; accepted edges enter
+    the graph and the optimiser runs under the reference's gap / flag rules;
+  * PoseGraph.optim (pose_graph.py:565-658): every key-frame, every non-'locz' edge, reference node = the oldest scan; the
+    non-key-frames are re-hung on their key-frames afterwards.  The solver is posegraph_optim (open3d's algorithm restated:
+    parity unpinned); `optimiser=` replaces it (tests record the call and return nothing).
 
-It consumes what shard.gather_step_results delivers -- descriptors (n,131,S) and edge rows (n,EDGE_FLOATS) in sequence
-order.  One difference of the sharded path is visible here: the ranks register every frame against its PREDECESSOR
-(speculatively, before anybody knows which frames become key-frames), the reference against the last KEY-frame
-(odometry.py:82-97).  While the predecessor is the key-frame the two are the same edge; otherwise the edge to the key-frame is
-the product of the consecutive edges since then (`exact_odometry=True` re-registers against the key-frame on this rank
-instead, as the reference would: one more 256 x 256 registration per non-key-frame).
+Two ways in.  `push(tok, desc, row, pcd)` consumes what shard.gather_step_results delivers -- descriptors and edge rows in
+sequence order.  One difference of the sharded path is visible there: the ranks register every frame against its
+PREDECESSOR (speculatively, before anybody knows which frames become key-frames), the reference against a key-frame.  While
+the predecessor is that key-frame the two are the same edge; otherwise the edge to the key-frame is the product of the
+consecutive edges since then (`exact_odometry=True`, or `row=None`, registers against the key-frame on this rank instead, as
+the reference would: one more 256 x 256 registration).  `step(desc, pcd)` is the reference's own flow for one agent: no
+rows, tokens counted here.
 
 This is the Amdahl term of the multi-GPU path: bench.py reports its cost per gathered step for N > 1.
 """
 from __future__ import annotations
 
 import time
-from typing import Dict, List, Optional, Tuple
+from math import sqrt
+from typing import Callable, Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -38,34 +48,52 @@ from .posegraph_optim import optimize_pose_graph
 from .registration import PoseTool, simvec_to_num
 
 ACPT, DROP, DIST = "acpt", "drop", "dist"  # EXIT_CODE of the reference (system/modules/utils.py)
+TRANS_STD, ROT_STD = 0.4, 0.5              # LoopThread.TRANS_STD / ROT_STD (loop_closure.py:16-17)
 
 
 def default_slam_args() -> dict:
-    """configs/infer/DeepPointMap_B_Main_SemanticKITTI.yaml:63-80 (mapping part)"""
-    return dict(edge_confidence_drop=0.60, edge_rmse_drop=0.50, max_continuous_drop_scan=5,
+    """configs/infer/DeepPointMap_B_Main_SemanticKITTI.yaml:63-97"""
+    return dict(coor_scale=60, odometer_candidates_num=1, registration_sample_odometer=0.5,
+                edge_confidence_drop=0.60, edge_rmse_drop=0.50, max_continuous_drop_scan=5,
                 continuous_drop_scan_strategy="recover", key_frame_distance="auto", key_frame_distance_0=10.0,
-                enable_s2m_adjust=True, registration_sample_mapping=0.5, registration_sample_odometer=0.5)
+                enable_s2m_adjust=True, registration_sample_mapping=0.5,
+                enable_loop_closure=True, loop_detection_gap=0, loop_detection_transaction_gap=10.0,
+                loop_detection_trust_range=3, loop_detection_gnss_distance=-1, loop_detection_pred_distance=100.0,
+                loop_detection_rotation_min=30.0, loop_detection_translation_min=10.0,
+                loop_detection_prob_acpt_threshold=0.7, loop_detection_candidates_num=1, registration_sample_loop=0.5,
+                loop_detection_confidence_acpt_threshold=0.6, enable_global_optimization=True, global_optimization_gap=0)
 
 
 class Rank0Consumer:
     def __init__(self, decoder, device, slam_args: Optional[dict] = None, optimize_every: int = 0,
-                 exact_odometry: bool = False):
+                 exact_odometry: bool = False, agent_id: int = 0, loop_targets: str = "self",
+                 optimiser: Optional[Callable] = None, keep_log: bool = False):
+        """optimize_every > 0: bench.py's stand-in for a loop closure (it only needs the optimiser's cost): every that many
+        key-frames an edge closes the window and the window is optimised; the reference's own loop closure is then off
+        unless `slam_args` turns it on."""
         self.decoder, self.device = decoder, torch.device(device)
         self.args = dict(default_slam_args(), **(slam_args or {}))
+        if optimize_every and "enable_loop_closure" not in (slam_args or {}):
+            self.args["enable_loop_closure"] = False
         self.optimize_every, self.exact_odometry = optimize_every, exact_odometry
+        self.agent_id, self.loop_targets, self.optimiser, self.keep_log = agent_id, loop_targets, optimiser, keep_log
         self.store = MapTileStore(self.device)
-        self.type: Dict[int, str] = {}                 # token -> 'full' (key-frame) | 'non-keyframe'
+        self.type: Dict[int, str] = {}                 # token -> 'full' (key-frame) | 'non-keyframe', in insertion order
         self.poses: Dict[int, torch.Tensor] = {}       # token -> SE3_pred (4,4) CPU
         self.edges: Dict[Tuple[int, int], dict] = {}   # (src, dst) -> SE3, type, information, confidence, rmse
         self.adj: Dict[int, List[Tuple[int, dict]]] = {}   # token -> (neighbour, edge) in edge insertion order
-        self.desc: Dict[int, torch.Tensor] = {}        # key-frames and the last frame: descriptors on the device
+        self.desc: Dict[int, torch.Tensor] = {}        # key-frames and the scan at hand: descriptors on the device
+        self.pcd: Dict[int, torch.Tensor] = {}         # full clouds (3,N) in metres on the device, when the caller has them
         self.last_known_keyframe: Optional[int] = None
         self.last_known_anyframe: Optional[int] = None
+        self.key_frame_num = 0
         self.n_frames = 0
         self.codes: List[str] = []
         self.tiles: List[List[int]] = []               # token order of every scan-to-map tile (tests)
+        self.log: List[dict] = []                      # keep_log: every device call, in order (tests hold it to the reference's)
         self.drop_bag: List[tuple] = []
-        self.since_kf = torch.eye(4)                   # product of the consecutive edges since the last key-frame
+        self.since_kf = torch.eye(4)                   # product of the consecutive edges since ...
+        self.chain_base: Optional[int] = None          # ... this key-frame
         self.chain_ok = True
         if self.args["key_frame_distance"] == "auto":
             self.dist_auto, self.dist_ratio = True, 1.0
@@ -74,28 +102,44 @@ class Rank0Consumer:
         else:
             self.dist_auto, self.kf_dist0 = False, float(self.args["key_frame_distance"])
             self.cur_kf_dist = self.kf_dist0
-        self.stats = dict(s2m=0, optimisations=0, keyframes=0, dropped=0, re_registrations=0)
+        a = self.args
+        self.last_loop_pose_num = -a["loop_detection_gap"] - 1
+        self.last_optim_pose_num = -a["global_optimization_gap"] - 1
+        self.last_loop_token = -1
+        self.required_optim = False
+        self.stats = dict(s2m=0, optimisations=0, keyframes=0, dropped=0, re_registrations=0, loop_batches=0,
+                          loop_registrations=0, loop_edges=0)
 
-    # -- the pose graph, as much of it as the gating needs ---------------------------------------------------------
+    # -- the pose graph ------------------------------------------------------------------------------------------------
     @property
     def keyframes(self) -> List[int]:
         return [t for t, ty in self.type.items() if ty != "non-keyframe"]
 
+    def _add_vertex(self, tok: int, kind: str) -> None:
+        assert tok not in self.type, f"Scan {tok} already in posegraph map"
+        self.type[tok] = kind
+        if kind == "full":
+            self.key_frame_num += 1
+            self.stats["keyframes"] += 1
+
     def _add_edge(self, src: int, dst: int, edge: dict) -> None:
+        if (src, dst) in self.edges or (dst, src) in self.edges:
+            raise RuntimeError(f"Received an edge that already exists ({src} - {dst})")   # pose_graph.py:198-205
         self.edges[(src, dst)] = edge
         self.adj.setdefault(src, []).append((dst, edge))
         self.adj.setdefault(dst, []).append((src, edge))
 
-    def _neighbors(self, tok: int, kinds) -> List[int]:
-        """PoseGraph.get_neighbor_tokens filtered by edge type: the other ends of the scan's edges, in the order the edges
-        entered the graph (the reference walks its edge dict; an adjacency list per scan gives the same order)"""
-        return [n for n, e in self.adj.get(tok, ()) if e["type"] in kinds]
+    def _neighbors(self, tok: int, kinds=None) -> List[int]:
+        """PoseGraph.get_neighbor_tokens, optionally filtered by edge type: the other ends of the scan's edges, in the
+        order the edges entered the graph (the reference walks its edge dict; an adjacency list per scan gives the same
+        order)"""
+        return [n for n, e in self.adj.get(tok, ()) if kinds is None or e["type"] in kinds]
 
-    def graph_search(self, tok: int, level: int = 5, kinds=("odom", "loop"), max_k: int = 16) -> List[int]:
+    def graph_search(self, tok: int, level: int = 5, kinds=("odom", "loop"), max_k: Optional[int] = 16) -> List[int]:
         """PoseGraph.graph_search (pose_graph.py:513-542)"""
         found: Dict[int, None] = {}
         bfs = [(level, tok)]
-        while bfs and len(found) < max_k:
+        while bfs and (max_k is None or len(found) < max_k):
             rem, t = bfs.pop(0)
             if t in found:
                 continue
@@ -105,11 +149,65 @@ class Rank0Consumer:
             bfs += [(rem - 1, n) for n in self._neighbors(t, kinds)]
         return list(found)
 
+    def shortest_path_length(self, src: int, dst: int, kinds=("odom", "loop"), infinity_length: int = 50) -> int:
+        """PoseGraph.shortest_path_length (pose_graph.py:544-563)"""
+        if src == dst:
+            return 0
+        vis, bfs = set(), [(0, src)]
+        while bfs:
+            d, t = bfs.pop(0)
+            if t == dst:
+                return d
+            if t in vis:
+                continue
+            vis.add(t)
+            if d >= infinity_length:
+                continue
+            bfs += [(d + 1, n) for n in self._neighbors(t, kinds)]
+        return infinity_length
+
+    def map_tokens(self, tok: int, level: int = 5, max_dist: Optional[float] = 20.0) -> List[int]:
+        """The scans of PoseGraph.global_map_query_graph (pose_graph.py:491-496): key-frames of the graph neighbourhood,
+        closer than `max_dist` to the centre scan"""
+        c = self.poses[tok][:3, 3:]
+        toks = [t for t in self.graph_search(tok, level) if self.type[t] != "non-keyframe"]
+        if max_dist is not None:
+            toks = [t for t in toks if torch.norm(self.poses[t][:3, 3:] - c, p=2, dim=0).item() < max_dist]
+        return toks
+
+    def _rec(self, call: dict) -> None:
+        if self.keep_log:
+            self.log.append(call)
+
+    def _tile(self, toks: List[int], centre: torch.Tensor):
+        self._rec(dict(kind="tile", tokens=list(toks)))
+        return self.store.tile(toks, [self.poses[t] for t in toks], centre)
+
+    def _register(self, src: torch.Tensor, dst: torch.Tensor, num_sample, what: str, src_tok, dst_tok):
+        R, T, conf, rmse = self.decoder.registration_forward(src, dst, num_sample=num_sample)
+        SE3 = PoseTool.SE3(R.cpu(), T.cpu())
+        self._rec(dict(kind="reg", what=what, src=src_tok, dst=dst_tok, SE3=SE3.clone(), rmse=float(rmse),
+                             cols=(src.shape[-1], dst.shape[-1])))
+        return SE3, simvec_to_num(conf), float(rmse)
+
+    def _information(self, src: int, dst: int, SE3: torch.Tensor, fallback=None) -> torch.Tensor:
+        """calculate_information_matrix_from_pcd of two scans of the graph (utils.py:60-113); without the clouds -- the
+        sharded path gathers descriptors and edge rows only -- the row's matrix (odometry edges: exactly this matrix when
+        the partner is the predecessor) or, failing that, the identity"""
+        if src in self.pcd and dst in self.pcd:
+            Rt = torch.cat([SE3[:3, :3].reshape(9), SE3[:3, 3].reshape(3)]).to(self.device)
+            G = ops.information_matrix(self.pcd[src], self.pcd[dst], Rt, 1.0).cpu()
+            self._rec(dict(kind="info", src=src, dst=dst, G=G.clone()))
+            return G
+        return fallback.clone() if fallback is not None else torch.eye(6)
+
     def add_loop_edge(self, src: int, dst: int, SE3: torch.Tensor, information=None, confidence: float = 1.0, rmse: float = 0.0):
-        self._add_edge(src, dst, dict(SE3=SE3.clone(), type="loop", information=information, confidence=confidence, rmse=rmse))
+        self._add_edge(src, dst, dict(src=src, dst=dst, SE3=SE3.clone(), type="loop", information=information,
+                                      confidence=confidence, rmse=rmse))
 
     def optimise(self, tokens: Optional[List[int]] = None) -> None:
-        """PoseGraph.optim on the key-frames (all, or `tokens`) and the non-'locz' edges between them."""
+        """PoseGraph.optim (pose_graph.py:565-658) on the key-frames (all, or `tokens`: bench.py's window) and the
+        non-'locz' edges between them; afterwards the non-key-frames follow their key-frames"""
         toks = [t for t in (tokens if tokens is not None else self.keyframes) if self.type.get(t) != "non-keyframe"]
         if len(toks) < 2:
             return
@@ -117,25 +215,61 @@ class Rank0Consumer:
         es = [(a, b, e["SE3"].double().numpy(),
                np.asarray(e["information"] if e["information"] is not None else np.eye(6), dtype=np.float64))
               for (a, b), e in self.edges.items() if e["type"] != "locz" and a in nodes and b in nodes]
-        refined, _ = optimize_pose_graph(nodes, es, base_token=min(toks))
+        base = min(self.type) if tokens is None else min(toks)
+        self._rec(dict(kind="optim", tokens=list(toks), edges=[(a, b, self.edges[(a, b)]["type"]) for a, b, _, _ in es]))
+        self.stats["optimisations"] += 1
+        if self.optimiser is not None:
+            refined = self.optimiser(nodes, es, base)
+        else:
+            refined, _ = optimize_pose_graph(nodes, es, base_token=base)
+        if not refined:
+            return
         for t, P in refined.items():
             self.poses[t] = torch.from_numpy(np.asarray(P, dtype=np.float32))
-        self.stats["optimisations"] += 1
+        # "Adjust non-keyframes" (pose_graph.py:630-656): breadth first from the reference node, a scan that was not
+        # optimised takes the pose of the neighbour it is first reached from times the edge between them
+        todo = {t for t in self.type if t not in refined}
+        bfs, vis = [base], set()
+        while bfs and todo:
+            t = bfs.pop(0)
+            if t in vis:
+                continue
+            vis.add(t)
+            for n in self._neighbors(t):
+                if n in todo and (t, n) in self.edges:
+                    self.poses[n] = self.poses[t] @ self.edges[(t, n)]["SE3"]
+                    todo.discard(n)
+                if n not in vis:
+                    bfs.append(n)
 
-    # -- MappingThread ---------------------------------------------------------------------------------------------------
-    def _valid_check(self, tok: int, edge: dict):
+    # -- OdometryThread ------------------------------------------------------------------------------------------------
+    def _odometry_candidates(self) -> List[int]:
+        """search_candidates (odometry.py:76-101): the key-frames of the last key-frame's graph neighbourhood, nearest to
+        the last known pose first"""
+        if not self.type or self.last_known_keyframe is None or self.last_known_anyframe is None:
+            return []
+        last = self.poses[self.last_known_anyframe]
+        kfs = [t for t in self.graph_search(self.last_known_keyframe) if self.type[t] != "non-keyframe"
+               and (t >> 16) == self.agent_id]
+        d = torch.norm(torch.stack([self.poses[t][:3, 3:] for t in kfs], dim=0) - last[:3, 3:], p=2, dim=1)
+        _, idx = torch.topk(d, dim=0, k=min(len(kfs), self.args["odometer_candidates_num"]), largest=False)
+        return [kfs[i] for i in idx.flatten().tolist()]
+
+    # -- MappingThread -------------------------------------------------------------------------------------------------
+    def _valid_check(self, tok: int, edge: dict) -> str:
         a = self.args
         if edge["confidence"] < a["edge_confidence_drop"] or edge["rmse"] > a["edge_rmse_drop"]:
             self.drop_bag.append((tok, edge))
             if len(self.drop_bag) >= a["max_continuous_drop_scan"]:
                 if a["continuous_drop_scan_strategy"] != "recover":
-                    raise NotImplementedError("continuous_drop_scan_strategy 'break' (mapping.py:65-74) is not mapped")
-                tok, edge = min(self.drop_bag, key=lambda x: x[1]["rmse"])
+                    # 'break' (mapping.py:65-74) adds the scan as a vertex and then falls through to process(), which adds
+                    # it again: the reference's own assertion (pose_graph.py:176) ends that run
+                    raise NotImplementedError("continuous_drop_scan_strategy 'break' does not survive in the reference either")
                 self.drop_bag.clear()
-                return ACPT, tok, edge
-            return DROP, tok, edge
+                return ACPT
+            return DROP
         self.drop_bag.clear()
-        return ACPT, tok, edge
+        return ACPT
 
     def _keyframe_check(self, tok: int, edge: dict) -> str:
         a = self.args
@@ -157,66 +291,195 @@ class Rank0Consumer:
         if not self.args["enable_s2m_adjust"]:
             return edge
         old = edge["src"]
-        toks = [t for t in self.graph_search(old) if self.type[t] != "non-keyframe"]
+        toks = self.map_tokens(old)
         self.tiles.append(list(toks))
-        tile, owner = self.store.tile(toks, [self.poses[t] for t in toks], self.poses[old])
+        tile, owner = self._tile(toks, self.poses[old])
         src = tile[:, (owner != tok).to(self.device)]                    # "drop same descriptors from map" (mapping.py:146)
-        R, T, conf, rmse = self.decoder.registration_forward(src, self.desc[tok], num_sample=self.args["registration_sample_mapping"])
+        SE3, conf, rmse = self._register(src, self.desc[tok], self.args["registration_sample_mapping"], "s2m",
+                                         [t for t in toks if t != tok], tok)
         self.stats["s2m"] += 1
-        return dict(src=old, dst=tok, SE3=PoseTool.SE3(R.cpu(), T.cpu()).inverse(), type="odom", information=edge["information"],
-                    confidence=simvec_to_num(conf), rmse=rmse)
+        return dict(src=old, dst=tok, SE3=SE3.inverse(), type="odom",
+                    information=self._information(old, tok, SE3, edge["information"]), confidence=conf, rmse=rmse)
 
+    # -- LoopThread ----------------------------------------------------------------------------------------------------
+    def _loop_detection(self, tok: int, targets: str) -> List[int]:
+        """loop_closure_detection (loop_closure.py:92-186)"""
+        a = self.args
+        cand = [t for t, ty in self.type.items() if ty == "full" and t in self.desc]
+        if targets == "self":
+            cand = [t for t in cand if (t >> 16) == (tok >> 16)]
+        elif targets == "others":
+            cand = [t for t in cand if (t >> 16) != (tok >> 16)]
+        elif targets != "all":
+            raise RuntimeError(f"add_loop_closure received an unknown arg value: targets = {targets}")
+        if not cand:
+            return []
+        trust = a["loop_detection_trust_range"]
+        zone1 = set(self.graph_search(tok, trust - 1, max_k=None))
+        zone2 = set(self.graph_search(tok, int(trust * 10), max_k=None))
+        new = self.poses[tok]
+        # (loop_detection_gnss_distance: a ScanPack without a GNSS fix sits at the origin, loop_closure.py:120-123 then
+        # keeps every candidate -- nothing on this path carries a fix)
+        if a["loop_detection_pred_distance"] > 0:
+            off = torch.stack([(self.poses[t] - new)[:2, 3:] for t in cand], dim=0)
+            keep = torch.norm(off, p=2, dim=1).squeeze(-1) <= a["loop_detection_pred_distance"]
+            cand = [t for t, m in zip(cand, keep) if m]
+        if not cand:
+            return []
+        valid = []
+        for t in cand:
+            if t in zone1 or t == tok:                                  # trusted zone (too close) or identical
+                continue
+            if (t >> 16) == (tok >> 16) and t in zone2:                 # trusted zone (turning a corner)
+                dR, dT = PoseTool.Rt(torch.linalg.inv(self.poses[t]) @ new)
+                if PoseTool.rotation_angle(dR) * 180 / torch.pi < a["loop_detection_rotation_min"] \
+                        or torch.norm(dT) < a["loop_detection_translation_min"]:
+                    continue
+                if self.last_loop_token != -1:
+                    _, gap = PoseTool.Rt(torch.linalg.inv(self.poses[self.last_loop_token]) @ new)
+                    if torch.norm(gap) < a["loop_detection_transaction_gap"]:
+                        continue
+            valid.append(t)
+        if not valid:
+            return []
+        src = torch.stack([self.desc[t] for t in valid], dim=0)
+        dst = self.desc[tok].unsqueeze(0).expand(len(valid), -1, -1)
+        prob = self.decoder.loop_detection_forward(src, dst).cpu()
+        self.stats["loop_batches"] += 1
+        self._rec(dict(kind="loop", src_tokens=list(valid), dst=tok, prob=prob.clone()))
+        # (torch.topk raises when there are fewer candidates than loop_detection_candidates_num; the shipped configs ask
+        # for one)
+        top, idx = torch.topk(prob, k=min(a["loop_detection_candidates_num"], len(valid)))
+        return [valid[i] for i, p in zip(idx.tolist(), top) if p > a["loop_detection_prob_acpt_threshold"]]
+
+    def _loop_registration(self, tok: int, scans: List[int]) -> List[dict]:
+        """loop_closure_registration (loop_closure.py:188-258)"""
+        out = []
+        for prev in scans:
+            ptoks, ntoks = self.map_tokens(prev), self.map_tokens(tok)
+            self._rec(dict(kind="tile", tokens=list(ptoks)))      # (the reference builds both tiles, then filters
+            self._rec(dict(kind="tile", tokens=list(ntoks)))      # their columns; here the token lists are filtered)
+            overlap = list(set(ptoks) & set(ntoks))
+            if overlap:
+                src_t, dst_t = self.poses[prev][:3, 3:], self.poses[tok][:3, 3:]
+                ot = torch.cat([self.poses[t][:3, 3:] for t in overlap], dim=1)
+                to_prev = torch.norm(ot - src_t, p=2, dim=0) < torch.norm(ot - dst_t, p=2, dim=0)
+                o2prev = {t for t, m in zip(overlap, to_prev) if m}
+                o2new = set(overlap) - o2prev
+                ptoks = [t for t in ptoks if t not in o2new]
+                ntoks = [t for t in ntoks if t not in o2prev]
+            assert not (set(ptoks) & set(ntoks)) and ptoks and ntoks
+            pmap, _ = self.store.tile(ptoks, [self.poses[t] for t in ptoks], self.poses[prev])
+            nmap, _ = self.store.tile(ntoks, [self.poses[t] for t in ntoks], self.poses[tok])
+            SE3, conf, rmse = self._register(pmap, nmap, self.args["registration_sample_loop"], "loop", list(ptoks), list(ntoks))
+            self.stats["loop_registrations"] += 1
+            out.append(dict(src=prev, dst=tok, SE3=SE3.inverse(), type="loop", information=self._information(prev, tok, SE3),
+                            confidence=conf, rmse=rmse))
+        return out
+
+    def _loop_verification(self, edges: List[dict]) -> List[dict]:
+        """loop_closure_verification (loop_closure.py:260-292)"""
+        ok = []
+        for e in edges:
+            if e["confidence"] < self.args["loop_detection_confidence_acpt_threshold"]:
+                continue
+            dist = self.shortest_path_length(e["src"], e["dst"], infinity_length=5000)
+            if dist < 5000:
+                delta = torch.linalg.inv(self.poses[e["src"]] @ e["SE3"]) @ self.poses[e["dst"]]
+                dR, dT = PoseTool.Rt(delta)
+                if torch.norm(dT).item() / (TRANS_STD * sqrt(dist)) > 3 and dist < 100:
+                    continue
+                if PoseTool.rotation_angle(dR) * 180 / torch.pi / (ROT_STD * sqrt(dist)) > 3:
+                    continue
+            ok.append(e)
+        return ok
+
+    def global_optimization(self, forced: bool = False) -> bool:
+        """loop_closure.py:294-307"""
+        a = self.args
+        if not a["enable_loop_closure"]:
+            return False
+        if not forced and (not a["enable_global_optimization"]
+                           or self.key_frame_num - self.last_optim_pose_num < a["global_optimization_gap"]
+                           or not self.required_optim):
+            return False
+        self.optimise()
+        self.last_optim_pose_num, self.required_optim = self.key_frame_num, False
+        return True
+
+    def loop_closure(self, tok: int, targets: Optional[str] = None) -> List[dict]:
+        """LoopThread.process (loop_closure.py:56-90)"""
+        a = self.args
+        if not a["enable_loop_closure"] or self.key_frame_num - self.last_loop_pose_num <= a["loop_detection_gap"]:
+            return []
+        valid = self._loop_verification(self._loop_registration(tok, self._loop_detection(tok, targets or self.loop_targets)))
+        if valid:
+            self.required_optim = True
+            for e in valid:
+                self._add_edge(e["src"], e["dst"], e)
+            self.stats["loop_edges"] += len(valid)
+            self.last_loop_pose_num, self.last_loop_token = self.key_frame_num, tok
+            self.global_optimization(forced=False)
+        return valid
+
+    # -- SlamSystem.step -----------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def push(self, tok: int, desc: torch.Tensor, row: torch.Tensor) -> str:
-        """One scan in sequence order: desc (131,S) on the device, row = its gathered edge row (host): the registration of
-        its predecessor (source) against it.  Returns the reference's exit code ('acpt' / 'drop' / 'dist')."""
+    def push(self, tok: int, desc: torch.Tensor, row: Optional[torch.Tensor] = None, pcd: Optional[torch.Tensor] = None) -> str:
+        """One scan in sequence order: desc (131,S) on the device; row = its gathered edge row (host): the registration of
+        its predecessor (source) against it, or None: the odometry registration runs here; pcd (3,N) metres on the device
+        or None.  Returns the reference's exit code ('acpt' / 'drop' / 'dist')."""
         self.n_frames += 1
-        if self.last_known_keyframe is None:            # first scan of the graph (core.py:383-388)
-            self.poses[tok], self.type[tok], self.desc[tok] = torch.eye(4), "full", desc
+        if pcd is not None:
+            self.pcd[tok] = pcd
+        cands = self._odometry_candidates()
+        if not cands:                                   # first scan of the graph (core.py:383-388)
+            self.poses[tok], self.desc[tok] = torch.eye(4), desc
+            self._add_vertex(tok, "full")
             self.store.put(tok, desc)
-            self.last_known_anyframe = self.last_known_keyframe = tok
-            self.stats["keyframes"] += 1
+            self.last_known_anyframe = self.last_known_keyframe = self.chain_base = tok
             self.codes.append(ACPT)
             return ACPT
-        kf = self.last_known_keyframe
-        step = PoseTool.SE3(row[0:9].view(3, 3), row[9:12].view(3, 1)).inverse()   # edge.SE3 = registration^-1 (odometry.py:119)
-        conf30, rmse = float(row[16]), float(row[12])
-        info = row[ops.RES_HDR:ops.RES_HDR + 36].view(6, 6).clone()
-        if self.chain_ok and not self.exact_odometry:
-            rel = self.since_kf @ step                  # key-frame -> predecessor -> this scan
-        else:                                           # the reference's own edge: this scan against the key-frame
-            R, T, conf, rmse = self.decoder.registration_forward(self.desc[kf], desc, num_sample=self.args["registration_sample_odometer"])
-            rel, conf30 = PoseTool.SE3(R.cpu(), T.cpu()).inverse(), simvec_to_num(conf)
-            self.stats["re_registrations"] += 1
-        edge = dict(src=kf, dst=tok, SE3=rel, type="odom", information=info, confidence=conf30, rmse=rmse)
+        kf = cands[0]
         self.desc[tok] = desc
-        code, tok, edge = self._valid_check(tok, edge)
+        info = row[ops.RES_HDR:ops.RES_HDR + 36].view(6, 6).clone() if row is not None else None
+        if row is not None and self.chain_ok and not self.exact_odometry and kf == self.chain_base:
+            step = PoseTool.SE3(row[0:9].view(3, 3), row[9:12].view(3, 1)).inverse()   # edge.SE3 = registration^-1 (odometry.py:119)
+            rel, conf30, rmse = self.since_kf @ step, float(row[16]), float(row[12])   # key-frame -> predecessor -> this scan
+        else:                                           # the reference's own edge: this scan against the key-frame
+            SE3, conf30, rmse = self._register(self.desc[kf], desc, self.args["registration_sample_odometer"], "odom", kf, tok)
+            rel, info = SE3.inverse(), self._information(kf, tok, SE3, info)
+            self.stats["re_registrations"] += row is not None
+        edge = dict(src=kf, dst=tok, SE3=rel, type="odom", information=info, confidence=conf30, rmse=rmse)
+        code = self._valid_check(tok, edge)
         if code != ACPT:
             self.stats["dropped"] += 1
             self.chain_ok = False                       # the next scan's consecutive edge hangs on a dropped scan
+            self.pcd.pop(tok, None), self.desc.pop(tok, None)
             self.codes.append(code)
             return code
         self.last_known_keyframe = edge["src"]
         code = self._keyframe_check(tok, edge)
         if code != ACPT:
-            self.type[tok] = "non-keyframe"
+            self._add_vertex(tok, "non-keyframe")
             self.last_known_anyframe = tok
             self._add_edge(edge["src"], tok, dict(edge, type="locz"))
-            self.since_kf, self.chain_ok = edge["SE3"].clone(), True
+            self.since_kf, self.chain_base, self.chain_ok = edge["SE3"].clone(), edge["src"], True
+            del self.desc[tok]                          # ScanPack.nonkeyframe(): never registered against again
+            self.pcd.pop(tok, None)
             self.codes.append(code)
             return code
-        self.type[tok] = "full"
+        self._add_vertex(tok, "full")
         self.store.put(tok, self.desc[tok])
         self.last_known_anyframe = self.last_known_keyframe = tok
         self._add_edge(edge["src"], tok, dict(edge))
-        self.stats["keyframes"] += 1
         new = self._scan_to_map(tok, edge)
         if new["rmse"] <= self.args["edge_rmse_drop"] or new["rmse"] <= edge["rmse"]:     # mapping.py:193-201
             self.poses[tok] = self.poses[new["src"]] @ new["SE3"]
-            self.edges[(edge["src"], tok)].update(SE3=new["SE3"], confidence=new["confidence"], rmse=new["rmse"])
-        for t in [t for t in self.desc if t != tok and self.type.get(t) == "non-keyframe"]:
-            del self.desc[t]                            # non-key-frames are never registered against again
-        self.since_kf, self.chain_ok = torch.eye(4), True
+            self.edges[(edge["src"], tok)].update(SE3=new["SE3"], confidence=new["confidence"],
+                                                  information=new["information"], rmse=new["rmse"])
+        self.since_kf, self.chain_base, self.chain_ok = torch.eye(4), tok, True
+        self.loop_closure(tok)
+        self.last_known_anyframe = tok
         if self.optimize_every and self.stats["keyframes"] % self.optimize_every == 0:
             window = self.keyframes[-self.optimize_every:]
             a = window[0]
@@ -226,15 +489,22 @@ class Rank0Consumer:
         self.codes.append(ACPT)
         return ACPT
 
+    def step(self, desc: torch.Tensor, pcd: Optional[torch.Tensor] = None) -> Tuple[int, str]:
+        """SlamSystem.step after the extraction (core.py:382-407) for one agent: token = (agent << 16) + frame number
+        counted from zero (core.py:361, pose_graph.py:39).  -> (token, exit code)"""
+        tok = (self.agent_id << 16) + self.n_frames
+        return tok, self.push(tok, desc, None, pcd)
+
     @torch.no_grad()
-    def consume(self, desc: torch.Tensor, table: torch.Tensor) -> float:
-        """One gathered step: desc (n,131,S), table (n,EDGE_FLOATS) on the device, frames in sequence order.
-        Returns the wall time in ms (device work included: the caller's results are only final after it)."""
+    def consume(self, desc: torch.Tensor, table: torch.Tensor, pcd: Optional[torch.Tensor] = None) -> float:
+        """One gathered step: desc (n,131,S), table (n,EDGE_FLOATS) on the device (pcd (n,3,N) metres, if gathered), frames
+        in sequence order.  Returns the wall time in ms (device work included: the caller's results are only final after
+        it)."""
         torch.cuda.synchronize(self.device)
         t0 = time.perf_counter()
         head = table[:, :ops.RES_HDR + 36].cpu()       # the one download: 56 floats per frame
         base = self.n_frames
         for g in range(desc.shape[0]):
-            self.push(base + g, desc[g], head[g])
+            self.push(base + g, desc[g], head[g], None if pcd is None else pcd[g])
         torch.cuda.synchronize(self.device)
         return (time.perf_counter() - t0) * 1e3

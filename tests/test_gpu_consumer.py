@@ -1,9 +1,6 @@
-"""deeppointmap_amd/consumer.py::Rank0Consumer -- the reference's MappingThread rules on gathered edge rows -- driven by the
-recorded SlamSystem.step run (tests/golden/slam_trace.npz): the same scans in the same order, the reference's own odometry
-edges as the gathered rows, its verified loop edges added when it added them.  The consumer must then make the reference's
-decisions: every scan accepted as a key-frame (the trace's thresholds), every scan-to-map tile made of the same key-frames in
-the same order (PoseGraph.graph_search over the same graph), and -- its tiles and registrations being the device path's -- the
-reference's trajectory."""
+"""deeppointmap_amd/consumer.py::Rank0Consumer -- the reference's odometry / mapping / loop-closure / optimisation rules
+around the device path -- driven by the scans of the recorded SlamSystem.step run (tests/golden/slam_trace.npz) and held to
+every call and every decision of that run, and by hand-made edge rows for the gating rules the run does not reach."""
 import numpy as np
 import pytest
 import torch
@@ -13,50 +10,115 @@ from conftest import T, load_golden, rot_angle
 pytestmark = pytest.mark.gpu
 
 
-def test_consumer_makes_the_reference_s_mapping_decisions_on_the_trace(cfg_full):
+# the thresholds tests/golden/make_trace.py ran the reference with (loosened so that, with procedural weights, key-frames,
+# scan-to-map refinements and loop closures all occur)
+TRACE_SLAM = dict(coor_scale=60, odometer_candidates_num=1, registration_sample_odometer=0.5,
+                  edge_confidence_drop=0.0, edge_rmse_drop=1e9, max_continuous_drop_scan=5, continuous_drop_scan_strategy="recover",
+                  key_frame_distance=0.0, enable_s2m_adjust=True, registration_sample_mapping=0.5,
+                  enable_loop_closure=True, loop_detection_gap=0, loop_detection_transaction_gap=0.0, loop_detection_trust_range=3,
+                  loop_detection_gnss_distance=-1, loop_detection_pred_distance=1e9, loop_detection_rotation_min=0.0,
+                  loop_detection_translation_min=0.0, loop_detection_prob_acpt_threshold=0.0, loop_detection_candidates_num=1,
+                  registration_sample_loop=0.5, loop_detection_confidence_acpt_threshold=0.0,
+                  enable_global_optimization=True, global_optimization_gap=0)
+
+
+@pytest.mark.parametrize("mode", ["rows", "recorded", "own"])
+def test_consumer_runs_the_reference_s_step_on_the_trace(cfg_full, mode):
+    """The consumer alone decides: which key-frame a scan is registered against, whether it is dropped / localised / mapped,
+    which scans form its scan-to-map tile, which key-frames are loop candidates, which of them is registered map against
+    map with which columns, whether the loop edge is believed, when the optimiser runs and on which graph.  Every device
+    call it makes is held to the call the reference made at that place (tests/golden/slam_trace.npz: 145 calls of
+    SlamSystem.step over 15 scans), and the trajectory that comes out to the reference's.
+
+      rows     : the sharded path -- the reference's odometry registrations arrive as gathered edge rows (push);
+      recorded : the reference's flow (step): the odometry registration runs here too, on the recorded descriptors;
+      own      : the same with descriptors from OUR encoder -- nothing but the scans comes from the recording."""
     from deeppointmap_amd import ops
     from deeppointmap_amd.consumer import Rank0Consumer
     from deeppointmap_amd.decoder import Decoder
+    from deeppointmap_amd.encoder import Encoder
+    from deeppointmap_amd.registration import make_descriptors
     from deeppointmap_amd.weights import init_procedural
     g = load_golden("slam_trace.npz")
     kinds = [str(k) for k in g["call_kinds"]]
     desc = {int(t): T(g["desc"][i]) for i, t in enumerate(g["desc_tokens"])}
+    frames = [T(g[f"frame{i}"]) for i in range(11)]
+    n_steps = len(g["order"])
+    frame_of = {int(g[f"s{s}.token"]): int(g[f"s{s}.frame"]) for s in range(n_steps)}
+    first = {}                                           # a revisited frame has the feature columns of its first visit, and
+    for t in sorted(frame_of):                           # the recording names descriptor columns by (first token, column)
+        first.setdefault(frame_of[t], t)
+    alias = {t: first[f] for t, f in frame_of.items()}
     dev = torch.device("cuda:0")
     dec = init_procedural(Decoder(cfg_full)).to(dev)
-    # thresholds of tests/golden/make_trace.py: nothing dropped, key_frame_distance 0 (every accepted scan is a key-frame)
-    cons = Rank0Consumer(dec, dev, slam_args=dict(edge_confidence_drop=0.0, edge_rmse_drop=1e9, key_frame_distance=0.0))
-    loops_seen = set()
-    for s in range(len(g["order"])):
-        tok = int(g[f"s{s}.token"])
+    enc = init_procedural(Encoder(cfg_full)).to(dev) if mode == "own" else None
+    optim_calls = []
+    cons = Rank0Consumer(dec, dev, slam_args=TRACE_SLAM, keep_log=True,
+                         optimiser=lambda nodes, es, base: optim_calls.append((nodes, es, base)))
+    worst = dict(dT=0.0, dR=0.0, loop=0.0, info=0.0)
+    for s in range(n_steps):
+        tok, f = int(g[f"s{s}.token"]), int(g[f"s{s}.frame"])
         k0, k1 = g[f"s{s}.calls"]
-        row = torch.zeros(ops.RES_HDR + 36)
-        regs = [k for k in range(k0, k1) if kinds[k] == "reg"]
-        if regs:
-            k = regs[0]                                  # the odometry registration of this step and its information matrix
-            assert kinds[k + 1] == "info" and int(g[f"c{k + 1}.dst"]) == tok
-            row[0:9], row[9:12] = T(g[f"c{k}.R"]).reshape(9), T(g[f"c{k}.T"]).reshape(3)
-            row[12], row[14], row[16] = float(g[f"c{k}.rmse"]), float(g[f"c{k}.n_conf"]), float(g[f"c{k}.conf30"])
-            row[ops.RES_HDR:] = T(g[f"c{k + 1}.G"]).reshape(36)
-        assert cons.push(tok, desc[tok].to(dev), row) == "acpt"
-        if regs:
-            tiles = [k for k in range(k0, k1) if kinds[k] == "tile"]
-            assert cons.tiles[-1] == [int(t) for t in g[f"c{tiles[0]}.tokens"]], s   # graph_search order, scan by scan
-        for k in range(k0, k1):                          # the loop edges the reference verified in this step
-            if kinds[k] != "optim":
-                continue
-            for a, b, ty, X, info in zip(g[f"c{k}.edge_src"], g[f"c{k}.edge_dst"], g[f"c{k}.edge_type"], g[f"c{k}.edge_T"],
-                                         g[f"c{k}.edge_info"]):
-                if str(ty) == "loop" and (int(a), int(b)) not in loops_seen:
-                    loops_seen.add((int(a), int(b)))
-                    cons.add_loop_edge(int(a), int(b), torch.linalg.inv(T(X)), information=T(info))
-    assert cons.codes == ["acpt"] * len(g["order"]) and cons.stats["s2m"] == len(g["order"]) - 1
+        want = [k for k in range(k0, k1) if kinds[k] != "enc"]
+        if mode == "own":
+            p = frames[f].unsqueeze(0)
+            coor, fea, _ = enc(p, torch.zeros(1, p.shape[2], dtype=torch.bool))
+            d = make_descriptors(coor, fea, 60.0)[0].to(dev)
+        else:
+            d = desc[tok].to(dev)
+        pcd = (frames[f] * 60.0).to(dev).contiguous()
+        n0 = len(cons.log)
+        if mode == "rows":
+            row = torch.zeros(ops.RES_HDR + 36)
+            if want:                                     # the odometry registration of this step and its information matrix
+                k = want[0]
+                assert kinds[k] == "reg" and kinds[k + 1] == "info" and int(g[f"c{k + 1}.dst"]) == tok
+                row[0:9], row[9:12] = T(g[f"c{k}.R"]).reshape(9), T(g[f"c{k}.T"]).reshape(3)
+                row[12], row[14], row[16] = float(g[f"c{k}.rmse"]), float(g[f"c{k}.n_conf"]), float(g[f"c{k}.conf30"])
+                row[ops.RES_HDR:] = T(g[f"c{k + 1}.G"]).reshape(36)
+                want = want[2:]
+            assert cons.push(tok, d, row, pcd) == "acpt"
+        else:
+            assert cons.step(d, pcd) == (tok, "acpt")
+        got = cons.log[n0:]
+        assert [c["kind"] for c in got] == [kinds[k] for k in want], (s, [c["kind"] for c in got], [kinds[k] for k in want])
+        for c, k in zip(got, want):
+            if c["kind"] == "tile":                      # graph_search order and the 20 m cut, scan by scan
+                assert c["tokens"] == [int(t) for t in g[f"c{k}.tokens"]], (s, k)
+            elif c["kind"] == "reg":                     # the same columns on both sides (the overlap deal of a loop closure)
+                assert c["cols"] == (g[f"c{k}.src_tok"].size, g[f"c{k}.dst_tok"].size), (s, k, c["cols"])
+                side = c["src"] if isinstance(c["src"], list) else [c["src"]]
+                assert [alias[t] for t in side] == [int(t) for t in g[f"c{k}.src_tok"][::256]], (s, k)
+                dT = float((c["SE3"][:3, 3] - T(g[f"c{k}.T"]).reshape(3)).norm())
+                dR = rot_angle(c["SE3"][:3, :3], g[f"c{k}.R"])
+                assert dT < 1e-4 and dR < 1e-4 and abs(c["rmse"] - float(g[f"c{k}.rmse"])) < 1e-4, (s, k, dT, dR)
+                worst["dT"], worst["dR"] = max(worst["dT"], dT), max(worst["dR"], dR)
+            elif c["kind"] == "info":
+                assert (c["src"], c["dst"]) == (int(g[f"c{k}.src"]), int(g[f"c{k}.dst"])), (s, k)
+                want_G = g[f"c{k}.G"]
+                worst["info"] = max(worst["info"], float(np.abs(c["G"].numpy() - want_G).max() / np.abs(want_G).max()))
+            elif c["kind"] == "loop":                    # the candidates that survive the trusted zones, in graph order
+                assert [alias[t] for t in c["src_tokens"]] == [int(t) for t in g[f"c{k}.src_tokens"]] and c["dst"] == tok, (s, k)
+                worst["loop"] = max(worst["loop"], float((c["prob"] - T(g[f"c{k}.prob"])).abs().max()))
+            else:                                        # the graph handed to the optimiser (pose_graph.py:565-608)
+                assert c["tokens"] == [int(t) for t in g[f"c{k}.tokens"]]
+                assert c["edges"] == [(int(a), int(b), str(ty)) for a, b, ty in
+                                      zip(g[f"c{k}.edge_src"], g[f"c{k}.edge_dst"], g[f"c{k}.edge_type"])]
+                nodes, es, base = optim_calls[-1]
+                assert base == int(g[f"c{k}.reference"])
+                for (a, b, X, info), X_ref, info_ref in zip(es, g[f"c{k}.edge_T"], g[f"c{k}.edge_info"]):
+                    X_ref = np.linalg.inv(X_ref.astype(np.float64))                 # recorded: inv(edge.SE3)
+                    assert np.abs(X[:3, 3] - X_ref[:3, 3]).max() < 2e-4 and np.abs(X[:3, :3] - X_ref[:3, :3]).max() < 1e-4
+                    assert np.abs(info - info_ref).max() <= 1e-3 * np.abs(info_ref).max()
+    print(f"consumer on the trace ({mode}): worst", worst)
+    assert worst["loop"] < (1e-4 if mode == "own" else 2e-5) and worst["info"] < 1e-3
+    assert cons.codes == ["acpt"] * n_steps and cons.stats["s2m"] == n_steps - 1
+    assert cons.stats["loop_batches"] == kinds.count("loop") == 12 and cons.stats["loop_edges"] == 8 == len(optim_calls)
     assert [cons.type[int(t)] for t in g["final_tokens"]] == [str(x) for x in g["final_type"]]
     final = {int(t): T(x) for t, x in zip(g["final_tokens"], g["final_SE3"])}
     dev_t = max(float((cons.poses[t][:3, 3] - final[t][:3, 3]).norm()) for t in final)
     dev_r = max(rot_angle(cons.poses[t][:3, :3], final[t][:3, :3].numpy()) for t in final)
     assert dev_t < 1e-4 and dev_r < 1e-4, (dev_t, dev_r)
-    # the odometry edges ended up with the scan-to-map values (mapping.py:196-200), the loop edges are the reference's
-    assert sum(e["type"] == "loop" for e in cons.edges.values()) == len(loops_seen) == 8
 
 
 def test_consumer_gating_rules():
@@ -72,7 +134,7 @@ def test_consumer_gating_rules():
     dev = torch.device("cuda:0")
     dec = init_procedural(Decoder(default_args())).to(dev)
     gen = torch.Generator().manual_seed(0)
-    cons = Rank0Consumer(dec, dev, slam_args=dict(edge_confidence_drop=0.5, edge_rmse_drop=1.0, key_frame_distance=3.0,
+    cons = Rank0Consumer(dec, dev, slam_args=dict(edge_confidence_drop=0.5, edge_rmse_drop=1.0, key_frame_distance=3.0, enable_loop_closure=False,
                                                   enable_s2m_adjust=False))
 
     def frame(dx, conf=0.9, rmse=0.2):
