@@ -51,6 +51,24 @@ ACPT, DROP, DIST = "acpt", "drop", "dist"  # EXIT_CODE of the reference (system/
 TRANS_STD, ROT_STD = 0.4, 0.5              # LoopThread.TRANS_STD / ROT_STD (loop_closure.py:16-17)
 
 
+def se3_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a @ b for 4x4 poses, every entry summed in double in index order and rounded once.  The reference multiplies float32
+    tensors through the BLAS of the day, whose last bit depends on the thread and the process it runs in (seen on the test
+    box: the cloud thread of a spawned rank against the main thread of another process, same inputs); a trajectory must not."""
+    A, B = a.double().tolist(), b.double().tolist()
+    return torch.tensor([[A[i][0] * B[0][j] + A[i][1] * B[1][j] + A[i][2] * B[2][j] + A[i][3] * B[3][j] for j in range(4)]
+                         for i in range(4)], dtype=torch.float32)
+
+
+def se3_inv(a: torch.Tensor) -> torch.Tensor:
+    """inverse of a rigid 4x4 pose: [R^T, -R^T t], in double, rounded once (the reference calls the general LU inverse:
+    the same matrix to rounding, and as order-dependent as its products)"""
+    A = a.double().tolist()
+    Rt = [[A[j][i] for j in range(3)] for i in range(3)]
+    t = [-(Rt[i][0] * A[0][3] + Rt[i][1] * A[1][3] + Rt[i][2] * A[2][3]) for i in range(3)]
+    return torch.tensor([Rt[0] + [t[0]], Rt[1] + [t[1]], Rt[2] + [t[2]], [0.0, 0.0, 0.0, 1.0]], dtype=torch.float32)
+
+
 def default_slam_args() -> dict:
     """configs/infer/DeepPointMap_B_Main_SemanticKITTI.yaml:63-97"""
     return dict(coor_scale=60, odometer_candidates_num=1, registration_sample_odometer=0.5,
@@ -77,13 +95,15 @@ class Rank0Consumer:
             self.args["enable_loop_closure"] = False
         self.optimize_every, self.exact_odometry = optimize_every, exact_odometry
         self.agent_id, self.loop_targets, self.optimiser, self.keep_log = agent_id, loop_targets, optimiser, keep_log
-        self.store = MapTileStore(self.device)
+        self.store: Optional[MapTileStore] = None      # key-frame descriptors in HBM (sized by the first one)
         self.type: Dict[int, str] = {}                 # token -> 'full' (key-frame) | 'non-keyframe', in insertion order
         self.poses: Dict[int, torch.Tensor] = {}       # token -> SE3_pred (4,4) CPU
         self.edges: Dict[Tuple[int, int], dict] = {}   # (src, dst) -> SE3, type, information, confidence, rmse
         self.adj: Dict[int, List[Tuple[int, dict]]] = {}   # token -> (neighbour, edge) in edge insertion order
         self.desc: Dict[int, torch.Tensor] = {}        # key-frames and the scan at hand: descriptors on the device
         self.pcd: Dict[int, torch.Tensor] = {}         # full clouds (3,N) in metres on the device, when the caller has them
+        self.coor: Dict[int, int] = {}                 # token -> coordinate system (multi-agent: one per agent until loops merge them)
+        self.coor_sys = agent_id                       # SlamSystem.coor_sys (core.py:44)
         self.last_known_keyframe: Optional[int] = None
         self.last_known_anyframe: Optional[int] = None
         self.key_frame_num = 0
@@ -115,9 +135,10 @@ class Rank0Consumer:
     def keyframes(self) -> List[int]:
         return [t for t, ty in self.type.items() if ty != "non-keyframe"]
 
-    def _add_vertex(self, tok: int, kind: str) -> None:
+    def _add_vertex(self, tok: int, kind: str, coor: Optional[int] = None) -> None:
         assert tok not in self.type, f"Scan {tok} already in posegraph map"
         self.type[tok] = kind
+        self.coor[tok] = self.coor_sys if coor is None else coor
         if kind == "full":
             self.key_frame_num += 1
             self.stats["keyframes"] += 1
@@ -166,6 +187,21 @@ class Rank0Consumer:
             bfs += [(d + 1, n) for n in self._neighbors(t, kinds)]
         return infinity_length
 
+    def repair_coor_sys(self) -> None:
+        """PoseGraph.repair_coor_sys (pose_graph.py:844-864): connected scans share the smallest coordinate-system id of
+        their component"""
+        todo = list(self.type)
+        while todo:
+            seed = min(todo, key=lambda t: self.coor[t])
+            coor, stack = self.coor[seed], [seed]
+            while stack:
+                t = stack.pop()
+                todo.remove(t)
+                for n in self._neighbors(t):
+                    if n in todo and n not in stack:
+                        stack.append(n)
+                self.coor[t] = coor
+
     def map_tokens(self, tok: int, level: int = 5, max_dist: Optional[float] = 20.0) -> List[int]:
         """The scans of PoseGraph.global_map_query_graph (pose_graph.py:491-496): key-frames of the graph neighbourhood,
         closer than `max_dist` to the centre scan"""
@@ -174,6 +210,11 @@ class Rank0Consumer:
         if max_dist is not None:
             toks = [t for t in toks if torch.norm(self.poses[t][:3, 3:] - c, p=2, dim=0).item() < max_dist]
         return toks
+
+    def _store_put(self, tok: int, desc: torch.Tensor) -> None:
+        if self.store is None:
+            self.store = MapTileStore(self.device, channels=desc.shape[0], points=desc.shape[1])
+        self.store.put(tok, desc)
 
     def _rec(self, call: dict) -> None:
         if self.keep_log:
@@ -237,7 +278,7 @@ class Rank0Consumer:
             vis.add(t)
             for n in self._neighbors(t):
                 if n in todo and (t, n) in self.edges:
-                    self.poses[n] = self.poses[t] @ self.edges[(t, n)]["SE3"]
+                    self.poses[n] = se3_mul(self.poses[t], self.edges[(t, n)]["SE3"])
                     todo.discard(n)
                 if n not in vis:
                     bfs.append(n)
@@ -278,7 +319,8 @@ class Rank0Consumer:
             self.dist_ratio = max(min(0.90 * self.dist_ratio + 0.10 * ((1 - rmse_ratio) ** 2) * 2.0, 2.0), 0.0)
             self.cur_kf_dist = max(self.kf_dist0 * self.dist_ratio, 1.0)
         old = edge["src"]
-        self.poses[tok] = self.poses[old] @ edge["SE3"]
+        self.poses[tok] = se3_mul(self.poses[old], edge["SE3"])
+        self._new_coor = self.coor[old]
         self.last_known_keyframe = old
         if self.cur_kf_dist >= 0:
             near = [t for t in self.graph_search(old) if self.type[t] != "non-keyframe"]
@@ -298,7 +340,7 @@ class Rank0Consumer:
         SE3, conf, rmse = self._register(src, self.desc[tok], self.args["registration_sample_mapping"], "s2m",
                                          [t for t in toks if t != tok], tok)
         self.stats["s2m"] += 1
-        return dict(src=old, dst=tok, SE3=SE3.inverse(), type="odom",
+        return dict(src=old, dst=tok, SE3=se3_inv(SE3), type="odom",
                     information=self._information(old, tok, SE3, edge["information"]), confidence=conf, rmse=rmse)
 
     # -- LoopThread ----------------------------------------------------------------------------------------------------
@@ -322,7 +364,8 @@ class Rank0Consumer:
         # keeps every candidate -- nothing on this path carries a fix)
         if a["loop_detection_pred_distance"] > 0:
             off = torch.stack([(self.poses[t] - new)[:2, 3:] for t in cand], dim=0)
-            keep = torch.norm(off, p=2, dim=1).squeeze(-1) <= a["loop_detection_pred_distance"]
+            other = torch.tensor([self.coor[t] != self.coor[tok] for t in cand])    # poses of another system say nothing
+            keep = (torch.norm(off, p=2, dim=1).squeeze(-1) <= a["loop_detection_pred_distance"]) | other
             cand = [t for t, m in zip(cand, keep) if m]
         if not cand:
             return []
@@ -331,12 +374,12 @@ class Rank0Consumer:
             if t in zone1 or t == tok:                                  # trusted zone (too close) or identical
                 continue
             if (t >> 16) == (tok >> 16) and t in zone2:                 # trusted zone (turning a corner)
-                dR, dT = PoseTool.Rt(torch.linalg.inv(self.poses[t]) @ new)
+                dR, dT = PoseTool.Rt(se3_mul(se3_inv(self.poses[t]), new))
                 if PoseTool.rotation_angle(dR) * 180 / torch.pi < a["loop_detection_rotation_min"] \
                         or torch.norm(dT) < a["loop_detection_translation_min"]:
                     continue
                 if self.last_loop_token != -1:
-                    _, gap = PoseTool.Rt(torch.linalg.inv(self.poses[self.last_loop_token]) @ new)
+                    _, gap = PoseTool.Rt(se3_mul(se3_inv(self.poses[self.last_loop_token]), new))
                     if torch.norm(gap) < a["loop_detection_transaction_gap"]:
                         continue
             valid.append(t)
@@ -373,7 +416,7 @@ class Rank0Consumer:
             nmap, _ = self.store.tile(ntoks, [self.poses[t] for t in ntoks], self.poses[tok])
             SE3, conf, rmse = self._register(pmap, nmap, self.args["registration_sample_loop"], "loop", list(ptoks), list(ntoks))
             self.stats["loop_registrations"] += 1
-            out.append(dict(src=prev, dst=tok, SE3=SE3.inverse(), type="loop", information=self._information(prev, tok, SE3),
+            out.append(dict(src=prev, dst=tok, SE3=se3_inv(SE3), type="loop", information=self._information(prev, tok, SE3),
                             confidence=conf, rmse=rmse))
         return out
 
@@ -385,7 +428,7 @@ class Rank0Consumer:
                 continue
             dist = self.shortest_path_length(e["src"], e["dst"], infinity_length=5000)
             if dist < 5000:
-                delta = torch.linalg.inv(self.poses[e["src"]] @ e["SE3"]) @ self.poses[e["dst"]]
+                delta = se3_mul(se3_inv(se3_mul(self.poses[e["src"]], e["SE3"])), self.poses[e["dst"]])
                 dR, dT = PoseTool.Rt(delta)
                 if torch.norm(dT).item() / (TRANS_STD * sqrt(dist)) > 3 and dist < 100:
                     continue
@@ -420,6 +463,8 @@ class Rank0Consumer:
             self.stats["loop_edges"] += len(valid)
             self.last_loop_pose_num, self.last_loop_token = self.key_frame_num, tok
             self.global_optimization(forced=False)
+            if (targets or self.loop_targets) in ("all", "others"):
+                self.repair_coor_sys()
         return valid
 
     # -- SlamSystem.step -----------------------------------------------------------------------------------------------
@@ -435,7 +480,7 @@ class Rank0Consumer:
         if not cands:                                   # first scan of the graph (core.py:383-388)
             self.poses[tok], self.desc[tok] = torch.eye(4), desc
             self._add_vertex(tok, "full")
-            self.store.put(tok, desc)
+            self._store_put(tok, desc)
             self.last_known_anyframe = self.last_known_keyframe = self.chain_base = tok
             self.codes.append(ACPT)
             return ACPT
@@ -443,11 +488,11 @@ class Rank0Consumer:
         self.desc[tok] = desc
         info = row[ops.RES_HDR:ops.RES_HDR + 36].view(6, 6).clone() if row is not None else None
         if row is not None and self.chain_ok and not self.exact_odometry and kf == self.chain_base:
-            step = PoseTool.SE3(row[0:9].view(3, 3), row[9:12].view(3, 1)).inverse()   # edge.SE3 = registration^-1 (odometry.py:119)
-            rel, conf30, rmse = self.since_kf @ step, float(row[16]), float(row[12])   # key-frame -> predecessor -> this scan
+            step = se3_inv(PoseTool.SE3(row[0:9].view(3, 3), row[9:12].view(3, 1)))   # edge.SE3 = registration^-1 (odometry.py:119)
+            rel, conf30, rmse = se3_mul(self.since_kf, step), float(row[16]), float(row[12])   # key-frame -> predecessor -> this scan
         else:                                           # the reference's own edge: this scan against the key-frame
             SE3, conf30, rmse = self._register(self.desc[kf], desc, self.args["registration_sample_odometer"], "odom", kf, tok)
-            rel, info = SE3.inverse(), self._information(kf, tok, SE3, info)
+            rel, info = se3_inv(SE3), self._information(kf, tok, SE3, info)
             self.stats["re_registrations"] += row is not None
         edge = dict(src=kf, dst=tok, SE3=rel, type="odom", information=info, confidence=conf30, rmse=rmse)
         code = self._valid_check(tok, edge)
@@ -460,7 +505,7 @@ class Rank0Consumer:
         self.last_known_keyframe = edge["src"]
         code = self._keyframe_check(tok, edge)
         if code != ACPT:
-            self._add_vertex(tok, "non-keyframe")
+            self._add_vertex(tok, "non-keyframe", self._new_coor)
             self.last_known_anyframe = tok
             self._add_edge(edge["src"], tok, dict(edge, type="locz"))
             self.since_kf, self.chain_base, self.chain_ok = edge["SE3"].clone(), edge["src"], True
@@ -468,13 +513,13 @@ class Rank0Consumer:
             self.pcd.pop(tok, None)
             self.codes.append(code)
             return code
-        self._add_vertex(tok, "full")
-        self.store.put(tok, self.desc[tok])
+        self._add_vertex(tok, "full", self._new_coor)
+        self._store_put(tok, self.desc[tok])
         self.last_known_anyframe = self.last_known_keyframe = tok
         self._add_edge(edge["src"], tok, dict(edge))
         new = self._scan_to_map(tok, edge)
         if new["rmse"] <= self.args["edge_rmse_drop"] or new["rmse"] <= edge["rmse"]:     # mapping.py:193-201
-            self.poses[tok] = self.poses[new["src"]] @ new["SE3"]
+            self.poses[tok] = se3_mul(self.poses[new["src"]], new["SE3"])
             self.edges[(edge["src"], tok)].update(SE3=new["SE3"], confidence=new["confidence"],
                                                   information=new["information"], rmse=new["rmse"])
         self.since_kf, self.chain_base, self.chain_ok = torch.eye(4), tok, True
@@ -484,7 +529,7 @@ class Rank0Consumer:
             window = self.keyframes[-self.optimize_every:]
             a = window[0]
             if (a, tok) not in self.edges and (tok, a) not in self.edges:
-                self.add_loop_edge(a, tok, torch.linalg.inv(self.poses[a]) @ self.poses[tok], torch.eye(6) * 10.0)
+                self.add_loop_edge(a, tok, se3_mul(se3_inv(self.poses[a]), self.poses[tok]), torch.eye(6) * 10.0)
             self.optimise(window)
         self.codes.append(ACPT)
         return ACPT
@@ -494,6 +539,52 @@ class Rank0Consumer:
         counted from zero (core.py:361, pose_graph.py:39).  -> (token, exit code)"""
         tok = (self.agent_id << 16) + self.n_frames
         return tok, self.push(tok, desc, None, pcd)
+
+    # -- multi-agent: what an agent uploads and what the cloud does with it ---------------------------------------------------
+    def upload_message(self, tok: int) -> dict:
+        """The UPLOAD_SCAN message of SlamSystem.step (core.py:409-422) for the key-frame just accepted: the scan, its
+        odometry edge and its other edges (the loop edges this step found)"""
+        scan = dict(token=tok, agent_id=tok >> 16, timestep=tok & 0xFFFF, type=self.type[tok], key_points=self.desc[tok],
+                    full_pcd=self.pcd.get(tok), SE3_pred=self.poses[tok].clone(), coor_sys=self.coor[tok])
+        odom = next((e for (a, b), e in self.edges.items() if b == tok and e["type"] == "odom"), None)
+        others = [e for n, e in self.adj.get(tok, ()) if e is not odom]
+        pack = lambda e: None if e is None else {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in e.items()}
+        return dict(new_scan=scan, odometer_edge=pack(odom), neighbor_edges=[pack(e) for e in others])
+
+    @torch.no_grad()
+    def cloud_step(self, scan: dict, odom_edge: Optional[dict], neighbor_edges: List[dict]) -> List[dict]:
+        """CloudSystem.step (core.py:466-514): the uploaded key-frame joins the cloud's graph at the end of its odometry edge,
+        its other edges follow, then the loop closure against the OTHER agents' key-frames (whose accepted edges merge the
+        coordinate systems).  -> the loop edges it added."""
+        assert scan["type"] == "full"
+        tok = scan["token"]
+        dev = self.device
+        self.n_frames += 1
+        self.desc[tok] = scan["key_points"].to(dev)
+        if scan.get("full_pcd") is not None:
+            self.pcd[tok] = scan["full_pcd"].to(dev)
+        self.poses[tok] = scan["SE3_pred"].cpu().clone()
+        self._add_vertex(tok, "full", scan["coor_sys"])
+        self._store_put(tok, self.desc[tok])
+        if odom_edge is not None:
+            assert tok in (odom_edge["src"], odom_edge["dst"])
+            if tok == odom_edge["src"]:
+                self.poses[tok] = se3_mul(self.poses[odom_edge["dst"]], se3_inv(odom_edge["SE3"]))
+                self.coor[tok] = self.coor[odom_edge["dst"]]
+            else:
+                self.poses[tok] = se3_mul(self.poses[odom_edge["src"]], odom_edge["SE3"])
+                self.coor[tok] = self.coor[odom_edge["src"]]
+            self._add_edge(odom_edge["src"], odom_edge["dst"], dict(odom_edge))
+        for e in neighbor_edges:
+            self._add_edge(e["src"], e["dst"], dict(e))
+        # "for those agents which did not update their pose graph in time" (core.py:487-503): a scan that still carries its
+        # agent's old coordinate system is placed from its neighbours in the cloud's graph
+        base = min((t for t in self.type if (t >> 16) == (tok >> 16)), key=lambda t: t & 0xFFFF)
+        if self.coor[base] != self.coor[tok]:
+            for n in self._neighbors(tok):
+                if (n, tok) in self.edges:
+                    self.poses[tok], self.coor[tok] = se3_mul(self.poses[n], self.edges[(n, tok)]["SE3"]), self.coor[n]
+        return self.loop_closure(tok, "others")
 
     @torch.no_grad()
     def consume(self, desc: torch.Tensor, table: torch.Tensor, pcd: Optional[torch.Tensor] = None) -> float:

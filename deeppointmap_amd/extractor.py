@@ -52,12 +52,24 @@ class MTExtractor:
 
     @staticmethod
     def _collate(scans: List[tuple]):
-        """items are (time_ms, point_cloud (1,C,N), R, T, padding_mask (1,N), original_scan) (core.py:152)"""
-        return torch.cat([s[1] for s in scans], dim=0), torch.cat([s[4] for s in scans], dim=0)
+        """items are (time_ms, point_cloud (1,C,N), R, T, padding_mask (1,N), original_scan) (core.py:152).  The reference
+        concatenates and so needs its dataloader to have padded every scan to one length; scans of different lengths are
+        padded here (zeros, masked) -- the encoder's output does not depend on masked points."""
+        n = max(s[1].shape[2] for s in scans)
+        if all(s[1].shape[2] == n for s in scans):
+            return torch.cat([s[1] for s in scans], dim=0), torch.cat([s[4] for s in scans], dim=0)
+        pts = torch.zeros(len(scans), scans[0][1].shape[1], n, dtype=scans[0][1].dtype, device=scans[0][1].device)
+        pad = torch.ones(len(scans), n, dtype=torch.bool, device=scans[0][4].device)
+        for i, s in enumerate(scans):
+            pts[i, :, :s[1].shape[2]], pad[i, :s[1].shape[2]] = s[1][0], s[4][0]
+        return pts, pad
 
     @torch.no_grad()
-    def run(self, queue_in, queue_out, make_scan: Callable, is_exit: Callable[[object], bool], is_final: Callable[[object], bool]):
-        """Thread body: batches from queue_in -> make_scan(item, descriptors (131,256) CPU) objects on queue_out; exit codes
+    def run(self, queue_in, queue_out, make_scan: Callable, is_exit: Callable[[object], bool], is_final: Callable[[object], bool],
+            to_host: bool = True):
+        """Thread body: batches from queue_in -> make_scan(item, descriptors (131,256)) objects on queue_out (descriptors on
+        the CPU as ScanPack holds them, or -- to_host=False -- left on the device, finished, for a consumer on another stream:
+        it must `record_stream` them); exit codes
         are forwarded where the reference forwards them (ahead of the scans of the batch they were drained with,
         core.py:147-151); returns after the final exit code.  Two batches overlap: the sampling stage of the batch just
         drained runs on a side stream while the previous batch goes through its feature stage."""
@@ -69,7 +81,11 @@ class MTExtractor:
         def finish(batch):
             scans_p, pts_p, pad_p, pre_p, ready_p = batch
             main.wait_event(ready_p)
-            desc = self.encoder(pts_p, pad_p, presampled=pre_p, descriptor_scale=self.coor_scale).cpu()
+            desc = self.encoder(pts_p, pad_p, presampled=pre_p, descriptor_scale=self.coor_scale)
+            if to_host:
+                desc = desc.cpu()
+            else:
+                main.synchronize()
             for item, d in zip(scans_p, desc):
                 queue_out.put(make_scan(item, d))
 

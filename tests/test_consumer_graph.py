@@ -1,0 +1,61 @@
+"""The pose-graph queries of deeppointmap_amd/consumer.py against the reference's PoseGraph on random graphs
+(tests/golden/graph_cases.json, made by tests/golden/make_graph_cases.py: 12 graphs of one or three agents with key-frames,
+non-key-frames and loop edges; 900 queries).  Host logic: no GPU."""
+import json
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ALL = ("loop", "odom", "locz", "prxy")
+
+
+def _graph(case):
+    from deeppointmap_amd.consumer import Rank0Consumer
+    c = Rank0Consumer(decoder=None, device="cpu")
+    for s in case["scans"]:
+        P = torch.eye(4)
+        P[:3, 3] = torch.tensor(s["xyz"])
+        c.poses[s["token"]] = P
+        c._add_vertex(s["token"], s["type"], s["coor"])
+    for a, b, ty in case["edges"]:
+        c._add_edge(a, b, dict(src=a, dst=b, SE3=torch.eye(4), type=ty, information=None, confidence=1.0, rmse=0.0))
+    return c
+
+
+def test_graph_queries_equal_the_reference():
+    cases = json.load(open(os.path.join(HERE, "golden", "graph_cases.json")))
+    n = 0
+    for case in cases:
+        c = _graph(case)
+        for q in case["queries"]:
+            kinds = ALL if q.get("kinds") == "all" else tuple(q.get("kinds") or ())
+            if q["fn"] == "graph_search":
+                got = c.graph_search(q["token"], q["level"], kinds, q["max_k"])
+            elif q["fn"] == "shortest":
+                got = c.shortest_path_length(q["src"], q["dst"], kinds, q["inf"])
+            else:
+                got = c.map_tokens(q["token"], 5, q["max_dist"])
+            assert got == q["out"], q
+            n += 1
+        c.repair_coor_sys()
+        assert {str(t): v for t, v in c.coor.items()} == case["coor_after"]
+    assert n == 900
+
+
+def test_pose_products_are_order_free_and_close_to_blas():
+    from deeppointmap_amd.consumer import se3_inv, se3_mul
+    g = torch.Generator().manual_seed(0)
+    for _ in range(50):
+        q = torch.randn(4, generator=g)
+        w, x, y, z = (q / q.norm()).tolist()
+        A = torch.eye(4)
+        A[:3, :3] = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        A[:3, 3] = 50 * torch.randn(3, generator=g)
+        B = se3_inv(A)
+        ref = A.double() @ torch.linalg.inv(A.double())
+        assert float((se3_mul(A, B).double() - ref).abs().max()) < 2e-5
+        assert float((B.double() - torch.linalg.inv(A.double())).abs().max()) < 1e-5 * 100   # |t| ~ 100, float32 R
+        assert torch.equal(se3_mul(A, torch.eye(4)), A) and torch.equal(se3_mul(torch.eye(4), A), A)

@@ -1,0 +1,69 @@
+"""deeppointmap_amd/system.py: the reference's SlamSystem (system/core.py:36-423) around the device path.  `step` over the
+scans of the recorded run must give the recorded trajectory; the multi-thread mode must give `step`'s trajectory bit for bit
+(it pipelines the encoder against the back end and nothing else)."""
+import pytest
+import torch
+
+from conftest import T, load_golden, rot_angle
+from test_gpu_consumer import TRACE_SLAM
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(cfg_full, **kw):
+    from deeppointmap_amd.config import Cfg
+    from deeppointmap_amd.decoder import Decoder
+    from deeppointmap_amd.encoder import Encoder
+    from deeppointmap_amd.system import SlamSystem
+    from deeppointmap_amd.weights import init_procedural
+    dev = torch.device("cuda:0")
+    args = Cfg(dict(cfg_full))
+    args.device, args.slam_system = "cuda:0", Cfg(TRACE_SLAM)
+    enc, dec = init_procedural(Encoder(cfg_full)).to(dev), init_procedural(Decoder(cfg_full)).to(dev)
+    return SlamSystem(args, enc, dec, system_id=0, **kw)
+
+
+def _scans(g):
+    frames = [T(g[f"frame{i}"]) for i in range(11)]
+    for s in range(len(g["order"])):
+        p = frames[int(g[f"s{s}.frame"])].unsqueeze(0)
+        yield [p, torch.eye(3).unsqueeze(0), torch.zeros(1, 3, 1), torch.zeros(1, p.shape[2], dtype=torch.bool), None]
+
+
+def test_step_gives_the_reference_s_trajectory(cfg_full):
+    from deeppointmap_amd.system import EXIT_CODE
+    g = load_golden("slam_trace.npz")
+    system = _system(cfg_full)
+    system.backend.optimiser = lambda nodes, es, base: None      # the recording skipped open3d (make_trace.py)
+    codes = [system.step(d) for d in _scans(g)]
+    assert codes == [EXIT_CODE.acpt] * len(g["order"]) and [c.value for c in codes] == g["codes"].tolist()
+    toks, poses = system.trajectory()
+    assert toks == [int(t) for t in g["final_tokens"]]
+    final = T(g["final_SE3"])
+    dev_t = float((poses[:, :3, 3] - final[:, :3, 3]).norm(dim=1).max())
+    dev_r = max(rot_angle(poses[i, :3, :3], final[i, :3, :3].numpy()) for i in range(len(toks)))
+    assert dev_t < 1e-4 and dev_r < 1e-4, (dev_t, dev_r)
+    assert system.backend.stats["loop_edges"] == 8 and system.backend.stats["optimisations"] == 8
+
+
+def test_multi_thread_mode_equals_step(cfg_full):
+    """15 scans queued at once: the extractor thread takes them as batches (whatever has queued up), the back-end thread in
+    order.  With the real optimiser, so that poses move under the scans that follow."""
+    g = load_golden("slam_trace.npz")
+    one = _system(cfg_full)
+    for d in _scans(g):
+        one.step(d)
+    mt = _system(cfg_full)
+    mt.MT_Init()
+    for d in _scans(g):
+        mt.MT_Step(d)
+    mt.MT_Done()
+    mt.MT_Wait()
+    assert mt.codes == one.codes and len(mt.codes) == len(g["order"])
+    (t1, p1), (t2, p2) = one.trajectory(), mt.trajectory()
+    assert t1 == t2 and torch.equal(p1, p2)
+    assert mt.backend.stats == one.backend.stats and one.backend.stats["optimisations"] >= 8
+    assert list(mt.backend.edges) == list(one.backend.edges)
+    # the optimiser did move the graph (otherwise this test would not see an order dependence)
+    final = T(g["final_SE3"])
+    assert float((p1[:, :3, 3] - final[:, :3, 3]).norm(dim=1).max()) > 1e-3
