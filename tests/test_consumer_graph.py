@@ -56,6 +56,6 @@ def test_pose_products_are_order_free_and_close_to_blas():
         A[:3, 3] = 50 * torch.randn(3, generator=g)
         B = se3_inv(A)
         ref = A.double() @ torch.linalg.inv(A.double())
-        assert float((se3_mul(A, B).double() - ref).abs().max()) < 2e-5
+        assert float((se3_mul(A, B).double() - ref).abs().max()) < 1e-4
         assert float((B.double() - torch.linalg.inv(A.double())).abs().max()) < 1e-5 * 100   # |t| ~ 100, float32 R
         assert torch.equal(se3_mul(A, torch.eye(4)), A) and torch.equal(se3_mul(torch.eye(4), A), A)
