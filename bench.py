@@ -189,15 +189,29 @@ def main():
         # device in `table` (header | information per frame); no host sync inside a step.
         if args.no_pipeline:
             desc, edges, table = hot.step(pts, pad, pcd_m, materialize=False)
-            last_gathered[0] = gather_step_results(desc.contiguous(), table)
+            gather((desc, table))
             return
         done = hot.submit(pts, pad, pcd_m)
         if done is not None:
+            gather(done)
+
+    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+
+    def gather(done):
+        # the step's one collective runs on a stream of its own: the caller's stream carries the next batch's feature stage,
+        # which must not wait for 8.6 MB per rank to cross xGMI (submit / flush made the caller's stream wait for the results)
+        if comm is None:
+            last_gathered[0] = gather_step_results(done[0].contiguous(), done[1])
+            return
+        comm.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(comm):
+            for t in done:
+                t.record_stream(comm)
             last_gathered[0] = gather_step_results(done[0].contiguous(), done[1])
 
     def drain():  # the batches still in the pipe are finished INSIDE the timed region
         for done in hot.flush():
-            last_gathered[0] = gather_step_results(done[0].contiguous(), done[1])
+            gather(done)
 
     def fence():
         torch.cuda.synchronize()
@@ -318,36 +332,39 @@ def main():
             #     optimisation): the Amdahl term of the sharded path, measured on the last gathered step
             ms = None
             if rank == 0 and last_gathered[0] is not None and last_gathered[0][0] is not None:
-                from deeppointmap_amd.consumer import Rank0Consumer
-                # the reference's step after the extraction on the gathered rows, with the SHIPPED thresholds
-                # (configs/infer/*.yaml: drop rules, 'auto' key-frame distance, loop closure).  Procedural weights give
-                # meaningless registrations -- rmse of metres, poses a random walk on which the partner search and the
-                # key-frame rule see no trajectory -- so the rows carry the synthetic sequence's TRUE relative poses and the
-                # quality figures of a good registration (rmse 0.15 m, confidence 0.9): the gating then meets what it meets in
-                # deployment (0.5 m per frame, a key-frame every ~20 frames, the predecessor chain intact).  Every device call
-                # of the step still runs on the real descriptors: scan-to-map per key-frame (its result is refused by
-                # mapping.py:193 -- rmse above both the threshold and the row's), the loop-detection batch per key-frame
-                # (nothing proposed above 0.7); `optimize_every` stands in for the optimiser runs verified loops would trigger.
-                slam = dict(enable_loop_closure=True)
-                cons = Rank0Consumer(hot.decoder, dev, slam_args=slam, optimize_every=16)
-                gd, gt = last_gathered[0]
-                gt = gt.clone()
-                truth = torch.stack([synthetic.relative_pose(g - 1, g) for g in range(gt.shape[0])]).to(gt)
-                gt[:, 0:9], gt[:, 9:12] = truth[:, :3, :3].reshape(-1, 9), truth[:, :3, 3]
-                gt[:, 12], gt[:, 16] = 0.15, 0.9
-                cons.consume(gd, gt)           # fills the map (first tiles are short), captures the registration shapes
-                cons.consume(gd, gt)
-                before = dict(cons.stats)
-                ms = [cons.consume(gd, gt) for _ in range(2)]
-                extras["rank0_serial_ms"] = round(sum(ms) / len(ms), 2)
-                extras["rank0_consumer"] = {"frames_per_step": int(gd.shape[0]), "key_frame_distance": "auto (shipped config)",
-                                            "key_frames_per_step": (cons.stats["keyframes"] - before["keyframes"]) / 2,
-                                            "scan_to_map_registrations_per_step": (cons.stats["s2m"] - before["s2m"]) / 2,
-                                            "loop_detection_batches_per_step": (cons.stats["loop_batches"] - before["loop_batches"]) / 2,
-                                            "registrations_on_rank0_per_step": (cons.stats["re_registrations"] - before["re_registrations"]) / 2,
-                                            "pose_graph_optimisations": cons.stats["optimisations"],
-                                            "note": "sequential SLAM work that stays on rank 0 (mapping.py:52-201, "
-                                                    "loop_closure.py:56-307); not part of `value`"}
+                try:   # an extra must never cost the line (nor leave the other ranks alone at the fence below)
+                    from deeppointmap_amd.consumer import Rank0Consumer
+                    # the reference's step after the extraction on the gathered rows, with the SHIPPED thresholds
+                    # (configs/infer/*.yaml: drop rules, 'auto' key-frame distance, loop closure).  Procedural weights give
+                    # meaningless registrations -- rmse of metres, poses a random walk on which the partner search and the
+                    # key-frame rule see no trajectory -- so the rows carry the synthetic sequence's TRUE relative poses and the
+                    # quality figures of a good registration (rmse 0.15 m, confidence 0.9): the gating then meets what it meets in
+                    # deployment (0.5 m per frame, a key-frame every ~20 frames, the predecessor chain intact).  Every device call
+                    # of the step still runs on the real descriptors: scan-to-map per key-frame (its result is refused by
+                    # mapping.py:193 -- rmse above both the threshold and the row's), the loop-detection batch per key-frame
+                    # (nothing proposed above 0.7); `optimize_every` stands in for the optimiser runs verified loops would trigger.
+                    slam = dict(enable_loop_closure=True)
+                    cons = Rank0Consumer(hot.decoder, dev, slam_args=slam, optimize_every=16)
+                    gd, gt = last_gathered[0]
+                    gt = gt.clone()
+                    truth = torch.stack([synthetic.relative_pose(g - 1, g) for g in range(gt.shape[0])]).to(gt)
+                    gt[:, 0:9], gt[:, 9:12] = truth[:, :3, :3].reshape(-1, 9), truth[:, :3, 3]
+                    gt[:, 12], gt[:, 16] = 0.15, 0.9
+                    cons.consume(gd, gt)           # fills the map (first tiles are short), captures the registration shapes
+                    cons.consume(gd, gt)
+                    before = dict(cons.stats)
+                    ms = [cons.consume(gd, gt) for _ in range(2)]
+                    extras["rank0_serial_ms"] = round(sum(ms) / len(ms), 2)
+                    extras["rank0_consumer"] = {"frames_per_step": int(gd.shape[0]), "key_frame_distance": "auto (shipped config)",
+                                                "key_frames_per_step": (cons.stats["keyframes"] - before["keyframes"]) / 2,
+                                                "scan_to_map_registrations_per_step": (cons.stats["s2m"] - before["s2m"]) / 2,
+                                                "loop_detection_batches_per_step": (cons.stats["loop_batches"] - before["loop_batches"]) / 2,
+                                                "registrations_on_rank0_per_step": (cons.stats["re_registrations"] - before["re_registrations"]) / 2,
+                                                "pose_graph_optimisations": cons.stats["optimisations"],
+                                                "note": "sequential SLAM work that stays on rank 0 (mapping.py:52-201, "
+                                                        "loop_closure.py:56-307); not part of `value`"}
+                except Exception as e:  # noqa: BLE001
+                    extras["rank0_consumer_error"] = f"{type(e).__name__}: {e}"
             fence()
 
     if args.stages and rank == 0:

@@ -263,15 +263,21 @@ class HotPath:
         else:
             main.wait_event(ready)
             desc = self.extract(points, padding, presampled=pre)
-            if self.chain:  # the hand-over is a collective: every rank reaches it once per batch, in batch order
-                halo_pcd = self._hand_over(desc, pcd_m[0] if pcd_m is not None else None)
-                if halo_pcd is not None:
-                    halo_pcd.record_stream(sb)
             desc_ready = main.record_event()
         desc.record_stream(sb)
-        reg, self._pending["reg"] = self._pending["reg"], (desc, desc_ready, pcd_m, halo_pcd if self.chain else None,
-                                                       self.chain and self._no_predecessor)
-        return self._register_on_b(reg) if reg is not None else None
+        # the registration of the batch before goes onto stream B first ...
+        prev, self._pending["reg"] = self._pending["reg"], None
+        out = self._register_on_b(prev) if prev is not None else None
+        if self.chain:
+            # ... then this batch's hand-over, ALSO on stream B: only the registration needs the predecessor frame, so the
+            # caller's stream -- the next batch's feature stage -- never waits for the neighbour rank's message.  It is a
+            # collective: every rank reaches it once per batch, in batch order.
+            with torch.cuda.stream(sb):
+                sb.wait_event(desc_ready)
+                halo_pcd = self._hand_over(desc, pcd_m[0] if pcd_m is not None else None)
+                desc_ready = sb.record_event()
+        self._pending["reg"] = (desc, desc_ready, pcd_m, halo_pcd if self.chain else None, self.chain and self._no_predecessor)
+        return out
 
     def _register_on_b(self, reg):
         dev = self.encoder.device
