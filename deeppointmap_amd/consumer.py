@@ -100,6 +100,7 @@ class Rank0Consumer:
         self.poses: Dict[int, torch.Tensor] = {}       # token -> SE3_pred (4,4) CPU
         self.edges: Dict[Tuple[int, int], dict] = {}   # (src, dst) -> SE3, type, information, confidence, rmse
         self.adj: Dict[int, List[Tuple[int, dict]]] = {}   # token -> (neighbour, edge) in edge insertion order
+        self._searches: Dict[tuple, List[int]] = {}    # graph_search results since the last new edge
         self.desc: Dict[int, torch.Tensor] = {}        # key-frames and the scan at hand: descriptors on the device
         self.pcd: Dict[int, torch.Tensor] = {}         # full clouds (3,N) in metres on the device, when the caller has them
         self.coor: Dict[int, int] = {}                 # token -> coordinate system (multi-agent: one per agent until loops merge them)
@@ -147,6 +148,7 @@ class Rank0Consumer:
         if (src, dst) in self.edges or (dst, src) in self.edges:
             raise RuntimeError(f"Received an edge that already exists ({src} - {dst})")   # pose_graph.py:198-205
         self.edges[(src, dst)] = edge
+        self._searches.clear()
         self.adj.setdefault(src, []).append((dst, edge))
         self.adj.setdefault(dst, []).append((src, edge))
 
@@ -158,6 +160,10 @@ class Rank0Consumer:
 
     def graph_search(self, tok: int, level: int = 5, kinds=("odom", "loop"), max_k: Optional[int] = 16) -> List[int]:
         """PoseGraph.graph_search (pose_graph.py:513-542)"""
+        key = (tok, level, tuple(kinds), max_k)
+        hit = self._searches.get(key)          # the partner search and the key-frame rule of one scan ask the same question
+        if hit is not None:
+            return list(hit)
         found: Dict[int, None] = {}
         bfs = [(level, tok)]
         while bfs and (max_k is None or len(found) < max_k):
@@ -168,6 +174,9 @@ class Rank0Consumer:
             if rem <= 0:
                 continue
             bfs += [(rem - 1, n) for n in self._neighbors(t, kinds)]
+        if len(self._searches) > 64:
+            self._searches.clear()
+        self._searches[key] = list(found)
         return list(found)
 
     def shortest_path_length(self, src: int, dst: int, kinds=("odom", "loop"), infinity_length: int = 50) -> int:
