@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import copy
 import threading
-from typing import Dict, List, Tuple, Union
+from typing import Dict, Tuple, Union
 
 import torch
 

@@ -11,10 +11,9 @@ exactly what the reference's FPS assumes, utils.py:255).
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import List, Optional
 
 import torch
-import torch.nn as nn
 
 from . import ops
 from .params import ParamTree, encoder_shapes

@@ -11,7 +11,7 @@ and verified by loading them with strict=True into the reference modules
 from __future__ import annotations
 
 from collections import OrderedDict
-from typing import Dict, Tuple
+from typing import Dict
 
 import torch
 import torch.nn as nn

@@ -9,14 +9,13 @@ shard.py.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import Optional
 
 import torch
 
 from . import ops
 from .decoder import Decoder
 from .encoder import Encoder
-from .registration import make_descriptors
 
 EDGE_FLOATS = 56  # per edge: 20-float registration header (R, T, rmse, n_corr, n_inlier, iters, conf30, ...) + 6x6 information
 

@@ -14,7 +14,6 @@ the oracle only (oracle.outlier_filter / lowpass_filter, scipy cKDTree), not by 
 """
 from __future__ import annotations
 
-from typing import Tuple
 
 import torch
 

@@ -13,7 +13,7 @@ The reference has no inference-time collective; this modul
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist

@@ -1,5 +1,4 @@
 """MT extractor contract (reference system/core.py:134-185) and batched scan pre-processing on the HIP path."""
-import os
 import queue
 import sys
 

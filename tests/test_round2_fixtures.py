@@ -1,6 +1,5 @@
 """Round-2 reference fixtures (tests/golden/make_golden_r2.py): tie-heavy small-N neighbour queries, a converged
 registration, and the map-sized registrations of BASELINE configs 3-5.  Inputs come from tests/golden/r2_cases.py."""
-import os
 import sys
 
 import numpy as np
