@@ -39,8 +39,11 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     const int iters = 4096;
-    for (int occ = 1; occ <= 2; ++occ) {
-        const int blocks = 256 * 4 * occ;  // 4 or 8 workgroups of 4 waves per CU
+    int clk = 0;
+    hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
+    printf("device clock %d kHz\n", clk);
+    for (int wg = 1; wg <= 8; wg *= 2) {
+        const int blocks = 256 * wg;  // workgroups of 4 waves per CU = waves per SIMD
         for (int which = 0; which < 2; ++which) {
             float ms = 0;
             for (int rep = 0; rep < 3; ++rep) {
@@ -52,7 +55,7 @@ int main() {
                 hipEventElapsedTime(&ms, e0, e1);
             }
             const double fma = (double)blocks * 256 * 16 * iters;
-            printf("%s %d workgroups/CU: %.3f ms, %.1f TFLOP/s (fp32 FMA = 2 flop)\n", which ? "v_pk_fma_f32" : "v_fma_f32   ", 4 * occ,
+            printf("%s %d workgroups/CU: %.3f ms, %.1f TFLOP/s (fp32 FMA = 2 flop)\n", which ? "v_pk_fma_f32" : "v_fma_f32   ", wg,
                    ms, 2 * fma / ms / 1e9);
         }
     }
