@@ -97,7 +97,11 @@ def preprocessed_frame(i):
     return xyz.float().t().contiguous()  # (3, N)
 
 
-def main():
+def main(variant="all"):
+    """variant "all": every scan a key-frame (slam_trace.npz, with every array needed to replay each call on its own);
+    variant "gated": thresholds under which scans are also DROPPED (the third drop in a row recovered), LOCALISED without
+    becoming key-frames, and scan-to-map results refused (slam_trace_gated.npz: decisions, poses and per-call results only --
+    the scans are those of slam_trace.npz)."""
     cfg = default_args()
     cfg.device = "cpu"
     cfg.use_ros = False
@@ -111,6 +115,8 @@ def main():
         loop_detection_translation_min=0.0, loop_detection_prob_acpt_threshold=0.0, loop_detection_candidates_num=1,
         registration_sample_loop=0.5, loop_detection_confidence_acpt_threshold=0.0,
         enable_global_optimization=True, global_optimization_gap=0))
+    if variant == "gated":
+        cfg.slam_system.update(edge_rmse_drop=1.6, max_continuous_drop_scan=3, key_frame_distance=0.2, loop_detection_trust_range=2)
     enc, dec = RefEncoder(cfg).eval(), RefDecoder(cfg).eval()
     enc.load_state_dict(procedural_state_dict(encoder_shapes(cfg)), strict=True)
     dec.load_state_dict(procedural_state_dict(decoder_shapes(cfg)), strict=True)
@@ -121,7 +127,7 @@ def main():
         m.calculate_information_matrix_from_pcd = lambda p1, p2, SE3, device="cpu": record_info(p1, p2, SE3)
 
     frames = [preprocessed_frame(i) for i in range(11)]
-    order = list(range(11)) + [7, 4, 2, 0]
+    order = list(range(11)) + ([7, 4, 2, 0] if variant == "all" else [9, 10, 7, 4, 2, 0, 3, 8, 5])
     calls, out = [], {}
     kf_desc = {}          # scan token -> descriptors (131, 256)
     col_of = {}           # feature-column bytes -> (token, column)
@@ -267,11 +273,19 @@ def main():
     out["final_SE3"] = torch.stack([s.SE3_pred for s in scans])
     out["final_type"] = np.array([s.type for s in scans])
     path = os.path.join(HERE, "slam_trace.npz")
+    if variant == "gated":
+        import json
+        path = os.path.join(HERE, "slam_trace_gated.npz")
+        big = ("_xyz", "_col", ".xyz", ".desc", ".centering", ".SE3")
+        out = {k: v for k, v in out.items() if not (k.startswith("frame") or k == "desc" or (k.startswith("c") and k.endswith(big)))}
+        for k in [k for k in out if k.endswith("_tok")]:        # one token per 256-column block
+            out[k] = np.asarray(out[k])[::256].copy()
+        out["slam_args"] = json.dumps(dict(cfg.slam_system))
     np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
     kinds = [c[0] for c in calls]
-    print(f"slam_trace.npz: {os.path.getsize(path) / 1024:.0f} KiB, {len(calls)} calls: " +
+    print(f"{os.path.basename(path)}: {os.path.getsize(path) / 1024:.0f} KiB, {len(calls)} calls: " +
           ", ".join(f"{k} x{kinds.count(k)}" for k in ("enc", "reg", "loop", "tile", "info", "optim")))
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "all")

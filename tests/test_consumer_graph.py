@@ -59,3 +59,17 @@ def test_pose_products_are_order_free_and_close_to_blas():
         assert float((se3_mul(A, B).double() - ref).abs().max()) < 1e-4
         assert float((B.double() - torch.linalg.inv(A.double())).abs().max()) < 1e-5 * 100   # |t| ~ 100, float32 R
         assert torch.equal(se3_mul(A, torch.eye(4)), A) and torch.equal(se3_mul(torch.eye(4), A), A)
+
+
+def test_gated_trace_fixture_exercises_every_exit():
+    """tests/golden/slam_trace_gated.npz (make_trace.py gated): the reference's run in which scans are dropped, localised and
+    mapped -- the GPU test replays it through the consumer; here only that the recording holds what it is there for."""
+    import numpy as np
+    g = np.load(os.path.join(HERE, "golden", "slam_trace_gated.npz"))
+    codes = g["codes"].tolist()
+    assert codes.count(0) >= 4 and codes.count(10) >= 8 and codes.count(11) >= 5         # acpt, drop, dist
+    assert any(codes[i:i + 3] == [10, 10, 0] for i in range(len(codes) - 2))             # the third drop in a row recovered
+    types = [str(t) for t in g["final_type"]]
+    assert "non-keyframe" in types and "full" in types and len(types) == len(codes) - codes.count(10)
+    kinds = [str(k) for k in g["call_kinds"]]
+    assert kinds.count("optim") == 2 and kinds.count("loop") == 2 and kinds.count("tile") == 7

@@ -121,6 +121,68 @@ def test_consumer_runs_the_reference_s_step_on_the_trace(cfg_full, mode):
     assert dev_t < 1e-4 and dev_r < 1e-4, (dev_t, dev_r)
 
 
+def test_consumer_drops_localises_and_recovers_like_the_reference(cfg_full):
+    """The second recorded run (tests/golden/slam_trace_gated.npz: 20 steps under thresholds that DROP scans -- the third drop
+    in a row recovered --, LOCALISE scans without making them key-frames and refuse scan-to-map results): exit code by exit
+    code, call by call, with descriptors from OUR encoder.  Tokens skip the dropped scans, non-key-frames hang on their
+    key-frames by 'locz' edges, the odometry partner is searched from the last key-frame around the last known pose."""
+    import json
+    from deeppointmap_amd.consumer import Rank0Consumer
+    from deeppointmap_amd.decoder import Decoder
+    from deeppointmap_amd.encoder import Encoder
+    from deeppointmap_amd.registration import make_descriptors
+    from deeppointmap_amd.weights import init_procedural
+    g, scans = load_golden("slam_trace_gated.npz"), load_golden("slam_trace.npz")
+    kinds = [str(k) for k in g["call_kinds"]]
+    frames = [T(scans[f"frame{i}"]) for i in range(11)]
+    n_steps = len(g["order"])
+    dev = torch.device("cuda:0")
+    enc, dec = init_procedural(Encoder(cfg_full)).to(dev), init_procedural(Decoder(cfg_full)).to(dev)
+    cons = Rank0Consumer(dec, dev, slam_args=json.loads(str(g["slam_args"])), keep_log=True, optimiser=lambda nodes, es, base: None)
+    name = {0: "acpt", 10: "drop", 11: "dist"}
+    first = {}
+    worst = 0.0
+    for s in range(n_steps):
+        tok, f = int(g[f"s{s}.token"]), int(g[f"s{s}.frame"])
+        first.setdefault(f, tok)
+        k0, k1 = g[f"s{s}.calls"]
+        want = [k for k in range(k0, k1) if kinds[k] != "enc"]
+        p = frames[f].unsqueeze(0)
+        coor, fea, _ = enc(p, torch.zeros(1, p.shape[2], dtype=torch.bool))
+        n0 = len(cons.log)
+        got_tok, code = cons.step(make_descriptors(coor, fea, 60.0)[0].to(dev), (frames[f] * 60.0).to(dev).contiguous())
+        assert (got_tok, code) == (tok, name[int(g["codes"][s])]), (s, got_tok, code)
+        got = cons.log[n0:]
+        assert [c["kind"] for c in got] == [kinds[k] for k in want], (s, [c["kind"] for c in got], [kinds[k] for k in want])
+        for c, k in zip(got, want):
+            if c["kind"] == "tile":
+                assert c["tokens"] == [int(t) for t in g[f"c{k}.tokens"]], (s, k)
+            elif c["kind"] == "reg":
+                dT = float((c["SE3"][:3, 3] - T(g[f"c{k}.T"]).reshape(3)).norm())
+                dR = rot_angle(c["SE3"][:3, :3], g[f"c{k}.R"])
+                assert dT < 1e-4 and dR < 1e-4 and abs(c["rmse"] - float(g[f"c{k}.rmse"])) < 1e-4, (s, k, dT, dR)
+                worst = max(worst, dT)
+            elif c["kind"] == "info":
+                assert (c["src"], c["dst"]) == (int(g[f"c{k}.src"]), int(g[f"c{k}.dst"])), (s, k)
+            elif c["kind"] == "loop":
+                assert c["dst"] == tok and len(c["src_tokens"]) == g[f"c{k}.src_tokens"].size, (s, k)
+                assert float((c["prob"] - T(g[f"c{k}.prob"])).abs().max()) < 1e-4
+            else:
+                assert c["tokens"] == [int(t) for t in g[f"c{k}.tokens"]]
+                assert c["edges"] == [(int(a), int(b), str(ty)) for a, b, ty in
+                                      zip(g[f"c{k}.edge_src"], g[f"c{k}.edge_dst"], g[f"c{k}.edge_type"])]
+    codes = [name[int(c)] for c in g["codes"]]
+    assert cons.codes == codes and {"acpt", "drop", "dist"} <= set(codes)
+    assert cons.stats["dropped"] == codes.count("drop") and cons.stats["keyframes"] == codes.count("acpt")
+    assert list(cons.type) == [int(t) for t in g["final_tokens"]]
+    assert [cons.type[int(t)] for t in g["final_tokens"]] == [str(x) for x in g["final_type"]]
+    final = {int(t): T(x) for t, x in zip(g["final_tokens"], g["final_SE3"])}
+    dev_t = max(float((cons.poses[t][:3, 3] - final[t][:3, 3]).norm()) for t in final)
+    dev_r = max(rot_angle(cons.poses[t][:3, :3], final[t][:3, :3].numpy()) for t in final)
+    print(f"gated run: worst registration {worst:.2e} m, trajectory {dev_t:.2e} m / {dev_r:.2e} rad")
+    assert dev_t < 1e-4 and dev_r < 1e-4, (dev_t, dev_r)
+
+
 def test_consumer_gating_rules():
     """valid_check and keyframe_check on hand-made edge rows: a scan that moved less than key_frame_distance is localised
     but not mapped, edges below the confidence / above the rmse threshold are dropped, the fifth drop in a row recovers the
