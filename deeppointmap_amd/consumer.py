@@ -198,17 +198,23 @@ class Rank0Consumer:
 
     def repair_coor_sys(self) -> None:
         """PoseGraph.repair_coor_sys (pose_graph.py:844-864): connected scans share the smallest coordinate-system id of
-        their component"""
-        todo = list(self.type)
-        while todo:
-            seed = min(todo, key=lambda t: self.coor[t])
-            coor, stack = self.coor[seed], [seed]
+        their component.  (The reference takes the unvisited scan with the smallest id as the seed of every flood fill and
+        removes visited scans from a list: quadratic in the scans; one pass over the components gives the same labels.)"""
+        seen = set()
+        for seed in self.type:
+            if seed in seen:
+                continue
+            comp, stack = [], [seed]
+            seen.add(seed)
             while stack:
                 t = stack.pop()
-                todo.remove(t)
-                for n in self._neighbors(t):
-                    if n in todo and n not in stack:
+                comp.append(t)
+                for n, _ in self.adj.get(t, ()):
+                    if n not in seen:
+                        seen.add(n)
                         stack.append(n)
+            coor = min(self.coor[t] for t in comp)
+            for t in comp:
                 self.coor[t] = coor
 
     def map_tokens(self, tok: int, level: int = 5, max_dist: Optional[float] = 20.0) -> List[int]:
