@@ -23,15 +23,19 @@ when everything lives in one process).
 """
 from __future__ import annotations
 
+import os
 import threading
+import time
 from enum import Enum, unique
 from queue import Queue
-from typing import List, Optional
+from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 
 from .consumer import ACPT, Rank0Consumer
 from .extractor import MTExtractor
+from .posegraph_optim import write_g2o
 
 
 @unique
@@ -41,6 +45,60 @@ class EXIT_CODE(Enum):      # system/modules/utils.py:21-27
     dist = 11
     engy = 12
     exit = 21
+
+
+class ResultLogger:
+    """The part of the reference's ResultLogger (system/modules/recoder.py:24-110) that pipeline/infer.py reads and that is
+    text: stage timings (`record_perf` / `log_time` / `get_time_list`), the trajectory files (`save_trajectory`,
+    recoder.py:76-97: every scan's and every key-frame's SE3_pred as twelve numbers per line, KITTI style, plus the step
+    numbers) and the pose graph as g2o (`save_posegraph` -> PoseGraph.to_g2o_file, pose_graph.py:821-842).  The plots and the
+    point-cloud map (`draw_trajectory`, `save_map`) are not provided: the calls are accepted and do nothing."""
+
+    def __init__(self, backend: Rank0Consumer, log_dir: Optional[str]):
+        self.backend, self.log_dir = backend, log_dir
+        self.time_recorder: Dict[str, List[float]] = {}
+
+    def record_perf(self, name: str, time_s: float) -> None:
+        self.time_recorder.setdefault(name, []).append(time_s)
+
+    def log_time(self, window: Optional[int] = None) -> dict:
+        ret = {}
+        for name, tl in self.time_recorder.items():
+            t = [x for x in tl if x > 0.0] if window is None else (tl[-window:] if window < len(tl) else tl)
+            ret[name] = (sum(t) / len(t), np.std(t))
+        return ret
+
+    def get_time_list(self, log_name: str) -> List[float]:
+        return self.time_recorder[log_name].copy()
+
+    def _path(self, name: str) -> str:
+        if self.log_dir is None:
+            raise ValueError("this SlamSystem was built without a logger_dir")
+        os.makedirs(self.log_dir, exist_ok=True)
+        return os.path.join(self.log_dir, name)
+
+    def save_trajectory(self, file_name: str = "traj_kitti") -> None:
+        b = self.backend
+        scans = sorted(b.type, key=lambda t: t & 0xFFFF)          # by timestep, graph order among equals (stable)
+        for kind, toks in (("all", scans), ("key", [t for t in scans if b.type[t] == "full"])):
+            with open(self._path(f"{file_name}.{kind}frames.txt"), "w+") as f:
+                for t in toks:
+                    f.write(" ".join(f"{i:.10f}" for i in b.poses[t][:3, :].flatten().tolist()) + "\n")
+            with open(self._path(f"{file_name}.{kind}steps.txt"), "w+") as f:
+                for t in toks:
+                    f.write(f"{int(t & 0xFFFF)}\n")
+
+    def save_posegraph(self, file_name: str = "posegraph") -> None:
+        b = self.backend
+        edges = [(a, c, e["SE3"].double().numpy(), np.asarray(e["information"] if e["information"] is not None else np.eye(6)))
+                 for (a, c), e in b.edges.items()]
+        write_g2o(self._path(file_name + ".pg.g2o"), {t: b.poses[t].numpy() for t in b.type}, edges)
+
+    def draw_trajectory(self, *a, **k) -> None:
+        pass
+
+    def save_map(self, *a, **k) -> None:
+        pass
 
 
 class SlamSystem:
@@ -58,6 +116,7 @@ class SlamSystem:
         self.extraction_thread = MTExtractor(dpm_encoder, coor_scale=self.coor_scale)
         # odometry_thread + mapping_thread + loop_thread + posegraph_map of the reference
         self.backend = Rank0Consumer(dpm_decoder, self.device, slam_args=slam, agent_id=system_id, keep_log=keep_log)
+        self.result_logger = ResultLogger(self.backend, logger_dir if logger_dir is not None else getattr(args, "infer_tgt", None))
         self.comm_module = comm_module
         if comm_module is not None:
             self.comm_id = system_id
@@ -71,7 +130,9 @@ class SlamSystem:
         return (point_cloud[:3].to(self.device, dtype=torch.float32) * self.coor_scale).contiguous()
 
     def _backend_step(self, desc: torch.Tensor, point_cloud: torch.Tensor) -> EXIT_CODE:
+        t0 = time.perf_counter()
         tok, code = self.backend.step(desc, self._full_pcd(point_cloud))
+        self.result_logger.record_perf("backend", time.perf_counter() - t0)      # odometer + mapping + loop_closure
         if code == ACPT and self.comm_module is not None:     # drop / dist leave step() before the upload (core.py:399-400)
             self.comm_module.send_message(caller=self.comm_id, callee=0, command="UPLOAD_SCAN",
                                           message=self.backend.upload_message(tok))
@@ -84,7 +145,9 @@ class SlamSystem:
         """sensor_data = [point_cloud (1,C,N) normalised, R, T, padding_mask (1,N), original_scan] (core.py:365)"""
         point_cloud, padding_mask = sensor_data[0], sensor_data[3]
         with torch.cuda.device(self.device):
+            t0 = time.perf_counter()
             desc = self.extraction_thread.process(point_cloud=point_cloud, padding_mask=padding_mask)
+            self.result_logger.record_perf("extract", time.perf_counter() - t0)   # enqueue time: the kernels run on
             return self._backend_step(desc[0], point_cloud[0])
 
     def trajectory(self):

@@ -14,12 +14,10 @@ def _graph(case):
     from deeppointmap_amd.consumer import Rank0Consumer
     c = Rank0Consumer(decoder=None, device="cpu")
     for s in case["scans"]:
-        P = torch.eye(4)
-        P[:3, 3] = torch.tensor(s["xyz"])
-        c.poses[s["token"]] = P
+        c.poses[s["token"]] = torch.tensor(s["SE3"])
         c._add_vertex(s["token"], s["type"], s["coor"])
-    for a, b, ty in case["edges"]:
-        c._add_edge(a, b, dict(src=a, dst=b, SE3=torch.eye(4), type=ty, information=None, confidence=1.0, rmse=0.0))
+    for a, b, ty, E, info in case["edges"]:
+        c._add_edge(a, b, dict(src=a, dst=b, SE3=torch.tensor(E), type=ty, information=torch.tensor(info), confidence=1.0, rmse=0.0))
     return c
 
 
@@ -73,3 +71,21 @@ def test_gated_trace_fixture_exercises_every_exit():
     assert "non-keyframe" in types and "full" in types and len(types) == len(codes) - codes.count(10)
     kinds = [str(k) for k in g["call_kinds"]]
     assert kinds.count("optim") == 2 and kinds.count("loop") == 2 and kinds.count("tile") == 7
+
+
+def test_text_writers_equal_the_reference_s(tmp_path):
+    """system.ResultLogger.save_trajectory / save_posegraph against the files the reference's ResultLogger wrote for the same
+    graphs (recoder.py:76-97, pose_graph.py:821-842): byte for byte"""
+    from deeppointmap_amd.system import ResultLogger
+    cases = json.load(open(os.path.join(HERE, "golden", "graph_cases.json")))
+    n = 0
+    for i, case in enumerate(cases):
+        if not case["files"]:
+            continue
+        rl = ResultLogger(_graph(case), str(tmp_path / str(i)))
+        rl.save_trajectory("traj")
+        rl.save_posegraph("graph")
+        for name, text in case["files"].items():
+            assert open(tmp_path / str(i) / name).read() == text, (i, name)
+            n += 1
+    assert n == 20

@@ -30,10 +30,10 @@ def _scans(g):
         yield [p, torch.eye(3).unsqueeze(0), torch.zeros(1, 3, 1), torch.zeros(1, p.shape[2], dtype=torch.bool), None]
 
 
-def test_step_gives_the_reference_s_trajectory(cfg_full):
+def test_step_gives_the_reference_s_trajectory(cfg_full, tmp_path):
     from deeppointmap_amd.system import EXIT_CODE
     g = load_golden("slam_trace.npz")
-    system = _system(cfg_full)
+    system = _system(cfg_full, logger_dir=str(tmp_path))
     system.backend.optimiser = lambda nodes, es, base: None      # the recording skipped open3d (make_trace.py)
     codes = [system.step(d) for d in _scans(g)]
     assert codes == [EXIT_CODE.acpt] * len(g["order"]) and [c.value for c in codes] == g["codes"].tolist()
@@ -44,6 +44,15 @@ def test_step_gives_the_reference_s_trajectory(cfg_full):
     dev_r = max(rot_angle(poses[i, :3, :3], final[i, :3, :3].numpy()) for i in range(len(toks)))
     assert dev_t < 1e-4 and dev_r < 1e-4, (dev_t, dev_r)
     assert system.backend.stats["loop_edges"] == 8 and system.backend.stats["optimisations"] == 8
+    # what pipeline/infer.py does with the system afterwards (infer.py:115-119)
+    rl = system.result_logger
+    assert set(rl.log_time(window=50)) == {"extract", "backend"} and len(rl.get_time_list("backend")) == len(codes)
+    rl.save_trajectory("trajectory"), rl.save_posegraph("trajectory"), rl.draw_trajectory("trajectory", draft=False), rl.save_map("trajectory")
+    rows = [[float(v) for v in line.split()] for line in open(tmp_path / "trajectory.allframes.txt")]
+    assert len(rows) == len(toks) and all(len(r) == 12 for r in rows)
+    assert float((torch.tensor(rows).view(-1, 3, 4) - final[:, :3, :]).abs().max()) < 1e-4
+    assert open(tmp_path / "trajectory.keysteps.txt").read().split() == [str(t) for t in toks]
+    assert sum(line.startswith("EDGE_SE3:QUAT") for line in open(tmp_path / "trajectory.pg.g2o")) == len(system.backend.edges)
 
 
 def test_multi_thread_mode_equals_step(cfg_full):
