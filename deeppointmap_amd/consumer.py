@@ -63,7 +63,7 @@ def se3_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def se3_inv(a: torch.Tensor) -> torch.Tensor:
     """inverse of a rigid 4x4 pose: [R^T, -R^T t], in double, rounded once (the reference calls the general LU inverse:
     the same matrix to rounding, and as order-dependent as its products)"""
-    A = a.double().tolist()
+    A = a.double().tolist() if isinstance(a, torch.Tensor) else a      # (nested lists: rows of float32 values as floats)
     Rt = [[A[j][i] for j in range(3)] for i in range(3)]
     t = [-(Rt[i][0] * A[0][3] + Rt[i][1] * A[1][3] + Rt[i][2] * A[2][3]) for i in range(3)]
     return torch.tensor([Rt[0] + [t[0]], Rt[1] + [t[1]], Rt[2] + [t[2]], [0.0, 0.0, 0.0, 1.0]], dtype=torch.float32)
@@ -100,7 +100,8 @@ class Rank0Consumer:
         self.poses: Dict[int, torch.Tensor] = {}       # token -> SE3_pred (4,4) CPU
         self.edges: Dict[Tuple[int, int], dict] = {}   # (src, dst) -> SE3, type, information, confidence, rmse
         self.adj: Dict[int, List[Tuple[int, dict]]] = {}   # token -> (neighbour, edge) in edge insertion order
-        self._searches: Dict[tuple, List[int]] = {}    # graph_search results since the last new edge
+        self._searches: Dict[tuple, List[int]] = {}    # graph_search results since the last new edge of their kinds
+        self._near: Dict[int, tuple] = {}              # key-frame neighbourhood of a scan + its positions (see _neighbourhood)
         self.desc: Dict[int, torch.Tensor] = {}        # key-frames and the scan at hand: descriptors on the device
         self.pcd: Dict[int, torch.Tensor] = {}         # full clouds (3,N) in metres on the device, when the caller has them
         self.coor: Dict[int, int] = {}                 # token -> coordinate system (multi-agent: one per agent until loops merge them)
@@ -148,7 +149,11 @@ class Rank0Consumer:
         if (src, dst) in self.edges or (dst, src) in self.edges:
             raise RuntimeError(f"Received an edge that already exists ({src} - {dst})")   # pose_graph.py:198-205
         self.edges[(src, dst)] = edge
-        self._searches.clear()
+        ty = edge["type"]           # a search only walks edges of its kinds: a 'locz' edge (every non-key-frame adds one) leaves
+        for k in [k for k in self._searches if ty in k[2]]:      # the odometry / loop neighbourhoods of the key-frames alone
+            del self._searches[k]
+        if ty != "locz":
+            self._near.clear()
         self.adj.setdefault(src, []).append((dst, edge))
         self.adj.setdefault(dst, []).append((src, edge))
 
@@ -282,6 +287,7 @@ class Rank0Consumer:
             return
         for t, P in refined.items():
             self.poses[t] = torch.from_numpy(np.asarray(P, dtype=np.float32))
+        self._moved()
         # "Adjust non-keyframes" (pose_graph.py:630-656): breadth first from the reference node, a scan that was not
         # optimised takes the pose of the neighbour it is first reached from times the edge between them
         todo = {t for t in self.type if t not in refined}
@@ -298,6 +304,21 @@ class Rank0Consumer:
                 if n not in vis:
                     bfs.append(n)
 
+    def _neighbourhood(self, tok: int):
+        """The key-frames of `graph_search(tok)` and their positions, stacked as the partner search (n,3,1) and the key-frame
+        rule (n,3) stack them.  Both ask for the same key-frame scan after scan until the next key-frame arrives, so the
+        answer is kept while no odometry / loop edge is added and no key-frame pose changes (`_moved`)."""
+        hit = self._near.get(tok)
+        if hit is None:
+            near = [t for t in self.graph_search(tok) if self.type[t] != "non-keyframe"]
+            hit = self._near[tok] = (near, torch.stack([self.poses[t][:3, 3:] for t in near], dim=0),
+                                     torch.stack([self.poses[t][:3, 3] for t in near]))
+        return hit
+
+    def _moved(self) -> None:
+        """a key-frame's pose changed (scan-to-map refinement, optimiser, an upload placed on the cloud's graph)"""
+        self._near.clear()
+
     # -- OdometryThread ------------------------------------------------------------------------------------------------
     def _odometry_candidates(self) -> List[int]:
         """search_candidates (odometry.py:76-101): the key-frames of the last key-frame's graph neighbourhood, nearest to
@@ -305,9 +326,13 @@ class Rank0Consumer:
         if not self.type or self.last_known_keyframe is None or self.last_known_anyframe is None:
             return []
         last = self.poses[self.last_known_anyframe]
-        kfs = [t for t in self.graph_search(self.last_known_keyframe) if self.type[t] != "non-keyframe"
-               and (t >> 16) == self.agent_id]
-        d = torch.norm(torch.stack([self.poses[t][:3, 3:] for t in kfs], dim=0) - last[:3, 3:], p=2, dim=1)
+        near, stack31, _ = self._neighbourhood(self.last_known_keyframe)
+        if all((t >> 16) == self.agent_id for t in near):
+            kfs = near
+        else:
+            kfs = [t for t in near if (t >> 16) == self.agent_id]
+            stack31 = torch.stack([self.poses[t][:3, 3:] for t in kfs], dim=0)
+        d = torch.norm(stack31 - last[:3, 3:], p=2, dim=1)
         _, idx = torch.topk(d, dim=0, k=min(len(kfs), self.args["odometer_candidates_num"]), largest=False)
         return [kfs[i] for i in idx.flatten().tolist()]
 
@@ -338,8 +363,7 @@ class Rank0Consumer:
         self._new_coor = self.coor[old]
         self.last_known_keyframe = old
         if self.cur_kf_dist >= 0:
-            near = [t for t in self.graph_search(old) if self.type[t] != "non-keyframe"]
-            d = torch.stack([self.poses[t][:3, 3] for t in near]) - self.poses[tok][:3, 3].unsqueeze(0)
+            d = self._neighbourhood(old)[2] - self.poses[tok][:3, 3].unsqueeze(0)
             if float(torch.norm(d, p=2, dim=1).min()) < self.cur_kf_dist:
                 return DIST
         return ACPT
@@ -503,8 +527,9 @@ class Rank0Consumer:
         self.desc[tok] = desc
         info = row[ops.RES_HDR:ops.RES_HDR + 36].view(6, 6).clone() if row is not None else None
         if row is not None and self.chain_ok and not self.exact_odometry and kf == self.chain_base:
-            step = se3_inv(PoseTool.SE3(row[0:9].view(3, 3), row[9:12].view(3, 1)))   # edge.SE3 = registration^-1 (odometry.py:119)
-            rel, conf30, rmse = se3_mul(self.since_kf, step), float(row[16]), float(row[12])   # key-frame -> predecessor -> this scan
+            v = row[:17].tolist()                       # R row-major, T, rmse, -, -, -, confidence (ops.RES_HDR layout)
+            step = se3_inv([v[0:3] + [v[9]], v[3:6] + [v[10]], v[6:9] + [v[11]], [0.0, 0.0, 0.0, 1.0]])   # edge.SE3 = registration^-1 (odometry.py:119)
+            rel, conf30, rmse = se3_mul(self.since_kf, step), v[16], v[12]                 # key-frame -> predecessor -> this scan
         else:                                           # the reference's own edge: this scan against the key-frame
             SE3, conf30, rmse = self._register(self.desc[kf], desc, self.args["registration_sample_odometer"], "odom", kf, tok)
             rel, info = se3_inv(SE3), self._information(kf, tok, SE3, info)
@@ -535,6 +560,7 @@ class Rank0Consumer:
         new = self._scan_to_map(tok, edge)
         if new["rmse"] <= self.args["edge_rmse_drop"] or new["rmse"] <= edge["rmse"]:     # mapping.py:193-201
             self.poses[tok] = se3_mul(self.poses[new["src"]], new["SE3"])
+            self._moved()
             self.edges[(edge["src"], tok)].update(SE3=new["SE3"], confidence=new["confidence"],
                                                   information=new["information"], rmse=new["rmse"])
         self.since_kf, self.chain_base, self.chain_ok = torch.eye(4), tok, True
@@ -599,6 +625,7 @@ class Rank0Consumer:
             for n in self._neighbors(tok):
                 if (n, tok) in self.edges:
                     self.poses[tok], self.coor[tok] = se3_mul(self.poses[n], self.edges[(n, tok)]["SE3"]), self.coor[n]
+        self._moved()
         return self.loop_closure(tok, "others")
 
     @torch.no_grad()
