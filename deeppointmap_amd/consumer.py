@@ -111,7 +111,7 @@ class Rank0Consumer:
         self.key_frame_num = 0
         self.n_frames = 0
         self.codes: List[str] = []
-        self.tiles: List[List[int]] = []               # token order of every scan-to-map tile (tests)
+        self.tiles: List[List[int]] = []               # keep_log: token order of every scan-to-map tile (tests)
         self.log: List[dict] = []                      # keep_log: every device call, in order (tests hold it to the reference's)
         self.drop_bag: List[tuple] = []
         self.since_kf = torch.eye(4)                   # product of the consecutive edges since ...
@@ -373,7 +373,8 @@ class Rank0Consumer:
             return edge
         old = edge["src"]
         toks = self.map_tokens(old)
-        self.tiles.append(list(toks))
+        if self.keep_log:
+            self.tiles.append(list(toks))
         tile, owner = self._tile(toks, self.poses[old])
         src = tile[:, (owner != tok).to(self.device)]                    # "drop same descriptors from map" (mapping.py:146)
         SE3, conf, rmse = self._register(src, self.desc[tok], self.args["registration_sample_mapping"], "s2m",
