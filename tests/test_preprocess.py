@@ -54,6 +54,27 @@ def test_hip_preprocess_vs_reference_transforms():
         preprocess_scan(xyz, max_cells=4096)
 
 
+@pytest.mark.gpu
+def test_hip_distance_crop_on_the_radius():
+    """DistanceSample keeps min <= torch.norm(xyz, dim=1) <= max (transforms.py:394-395).  360 000 points within six ulps of the
+    60 m radius: the device crop must keep exactly the points the reference's own expression keeps -- torch's CPU norm is a
+    float fma chain over x, y, z, and a sum-of-squares in another order is off by an ulp for one point in ten."""
+    from deeppointmap_amd.preprocess import preprocess_scan
+    from oracle import dpm_oracle as O
+    g = torch.Generator().manual_seed(3)
+    for trial in range(6):
+        n = 60000
+        d = torch.randn(n, 3, generator=g)
+        d = d / d.norm(dim=1, keepdim=True)
+        x = d * (60.0 + torch.randint(-6, 7, (n, 1), generator=g).float() * 3.8e-6) + (torch.rand(n, 3, generator=g) - 0.5) * 1e-5
+        dis = torch.norm(x, p=2, dim=1)
+        assert 0.2 < float(((1.0 <= dis) & (dis <= 60.0)).float().mean()) < 0.8          # the radius cuts through the cloud
+        wp, wi = O.preprocess_scan(x, 0.4, 1.0, 60.0)
+        assert bool(((1.0 <= dis[wi.long()]) & (dis[wi.long()] <= 60.0)).all())            # (the oracle is that expression)
+        pts, pad, idx = preprocess_scan(x, 0.4, 1.0, 60.0, return_index=True)
+        assert pts.shape[2] == wp.shape[0] and np.array_equal(idx.cpu().numpy(), wi.numpy().astype(np.int32)), trial
+
+
 # ------------------------------------------------------------------------------------------------
 # OutlierFilter / LowPassFilter (transforms.py:230-289): pytorch3d / open3d based in the reference, so the checker
 # is the oracle's restatement (scipy cKDTree + numpy eigh); parity with the reference itself is unpinned.
