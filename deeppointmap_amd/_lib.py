@@ -23,6 +23,7 @@ SIGNATURES = {
     "dpm_error_string": (c_char_p, [I]),
     "dpm_prepare_points": (I, [P, P, I, I, I, P, P, P]),
     "dpm_to_channel_first": (I, [P, I, I, I, P, P]),
+    "dpm_to_channel_first_ld": (I, [P, I, I, I, P, I, P]),
     "dpm_emit_descriptors": (I, [P, P, P, I, I, I, D, P, P, P, P, P]),
     "dpm_nested_levels": (I, [P, P, I, I, I, P, P, P, P, P]),
     "dpm_gather_frames": (I, [P, LL, I, I, I, P, I, P, P]),
@@ -56,6 +57,7 @@ SIGNATURES = {
     "dpm_attention": (I, [P, I, LL, P, I, LL, P, I, LL, P, I, LL, I, I, I, I, I, P]),
     "dpm_attention_shifted": (I, [P, I, LL, P, I, LL, P, I, LL, P, I, LL, I, I, I, I, I, I, P]),
     "dpm_attention_masked": (I, [P, I, LL, P, I, LL, P, I, LL, P, I, LL, I, I, I, I, I, I, P, P]),
+    "dpm_attention_indexed": (I, [P, I, LL, P, I, LL, P, I, LL, P, I, LL, I, I, I, I, I, I, P, P]),
     "dpm_attention_split_workspace_bytes": (c_size_t, [I, I, I, I, I]),
     "dpm_attention_split": (I, [P, I, LL, P, I, LL, P, I, LL, P, I, LL, I, I, I, I, I, I, I, P, P]),
     "dpm_l2_normalize": (I, [P, I, I, P, P]),

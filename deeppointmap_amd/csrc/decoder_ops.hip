@@ -16,12 +16,14 @@ namespace {
 __global__ __launch_bounds__(256) void posemb_kernel(const float *__restrict__ xyz, int ld,
                                                      const float *__restrict__ dim_t, int F, int E, int R,
                                                      float scale, float *__restrict__ out) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)R * E) return;
-    const int r = (int)(e / E), c = (int)(e - (long long)r * E);
+    // R * E < 2^32 (checked by the launcher): 32-bit index arithmetic -- the two 64-bit divisions per element were
+    // most of this kernel
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (unsigned)R * (unsigned)E) return;
+    const unsigned r = e / (unsigned)E, c = e - r * (unsigned)E;
     float v = 0.f;
-    if (c < 3 * F) {
-        const int a = c / F, i = c - a * F;
+    if (c < 3u * (unsigned)F) {
+        const unsigned a = c / (unsigned)F, i = c - a * (unsigned)F;
         const float ang = (xyz[(size_t)r * ld + a] * scale) / dim_t[i];
         v = (i & 1) ? cosf(ang) : sinf(ang);
     }
@@ -94,7 +96,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
                                                         int N, float scale, int kv_shift,
                                                         const uint8_t *__restrict__ key_mask = nullptr, int nsplit = 1,
                                                         float *__restrict__ part_o = nullptr,
-                                                        float *__restrict__ part_ml = nullptr) {
+                                                        float *__restrict__ part_ml = nullptr,
+                                                        const int32_t *__restrict__ seq = nullptr) {
     constexpr int TK = 64;                 // keys per tile
     __shared__ __attribute__((aligned(16))) float Ks[TK][HD + 2];  // A operand of S^T: A[i=key][k=d] = Ks[key][d]
     // A operand of O^T: A[i=d][k=key] = Vs[key][d].  Row stride 36: 16-byte aligned rows, and the four lane groups of
@@ -110,14 +113,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     // key range of this block: whole tiles, the same count for every range but the last
     const int chunk = SPLIT ? ((N + TK * nsplit - 1) / (TK * nsplit)) * TK : N;
     const int n_begin = split * chunk, n_end = SPLIT ? min(N, n_begin + chunk) : N;
-    const float *Qb = Q + (size_t)b * sq + h * HD;
     // batch element b reads the keys / values of element (b + kv_shift) mod batch: with the source and target tokens
     // of B pairs stacked as 2B sequences and kv_shift = B, ONE launch is both directions of a cross attention
     int bk = b + kv_shift;
     if (bk >= (int)gridDim.z) bk -= (int)gridDim.z;
+    // seq: the batch elements are DRAWN from a smaller set of stored sequences (consecutive-frame pairs use every frame
+    // twice): element b's queries are stored sequence seq[b], its keys / values stored sequence seq[bk]; the output and the
+    // key mask stay per batch element
+    const int bq = seq ? seq[b] : b;
+    const float *Qb = Q + (size_t)bq * sq + h * HD;
+    const uint8_t *km = MASK ? key_mask + (size_t)bk * N : nullptr;
+    if (seq) bk = seq[bk];
     const float *Kb = Kp + (size_t)bk * sk + h * HD;
     const float *Vb = V + (size_t)bk * sv + h * HD;
-    const uint8_t *km = MASK ? key_mask + (size_t)bk * N : nullptr;
 
     // Q^T fragments (B operand: B[k=lane>>4][j=lane&15] = Q[query lane&15][d = 4 ks + (lane>>4)]), pre-scaled
     float qa[QT][HD / 4];
@@ -336,6 +344,7 @@ __global__ __launch_bounds__(256) void attention_generic_kernel(const float *__r
 // ------------------------------------------------------------------------------------------
 // F.normalize(x, p=2, dim=-1): x / max(||x||, 1e-12); one wave per row
 // ------------------------------------------------------------------------------------------
+template <bool VEC>
 __global__ __launch_bounds__(256) void l2norm_kernel(const float *__restrict__ X, int R, int C,
                                                      float *__restrict__ out) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -344,6 +353,13 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float *__restrict__ X
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s = fmaf(x[c], x[c], s);
     const float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    if (VEC) {  // C % 4 == 0, 16-byte aligned rows: the quotients leave as 16-byte stores (same sums as above: same bits)
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + c);
+            *reinterpret_cast<float4 *>(out + (size_t)r * C + c) = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
+        }
+        return;
+    }
     for (int c = lane; c < C; c += 64) out[(size_t)r * C + c] = x[c] / nrm;
 }
 
@@ -437,19 +453,39 @@ __global__ __launch_bounds__(256) void col_slab_finish_kernel(int N, int splits,
     cmax[(size_t)batch * N + c] = mx, csum[(size_t)batch * N + c] = sum;
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void dual_softmax_kernel(float *__restrict__ S, long long rows, int M, int N, float itau,
                                                            const float *__restrict__ rmax,
                                                            const float *__restrict__ rsum,
                                                            const float *__restrict__ cmax,
                                                            const float *__restrict__ csum) {
-    // One block = 256 consecutive columns of ONE row (M = rows of one batch element, `rows` = batch * M): the row and
-    // its batch element come from two scalar divisions per block, not from two 64-bit divisions per element.
-    const unsigned cblocks = (unsigned)(N + 255) >> 8;
-    const unsigned r = blockIdx.x / cblocks, c = (blockIdx.x - r * cblocks) * 256u + threadIdx.x;
+    // One block = 256 consecutive columns of ONE row (M = rows of one batch element, `rows` = batch * M): the
+    // row and its batch element come from two scalar divisions per block, not from two 64-bit divisions per element.
+    // VEC (N % 4 == 0): four columns per thread, 16-byte accesses; per element the same expression, the same bits.
+    unsigned r, c;
+    if (VEC) {  // flat over the rows' float4 groups (rows * N / 4 < 2^31, checked by the launcher): one 32-bit division
+        const unsigned q = (unsigned)N >> 2, e4 = blockIdx.x * 256u + threadIdx.x;
+        r = e4 / q, c = (e4 - r * q) * 4u;
+    } else {
+        const unsigned cblocks = ((unsigned)N + 255u) >> 8;
+        r = blockIdx.x / cblocks, c = (blockIdx.x - r * cblocks) * 256u + threadIdx.x;
+    }
     if (r >= rows || c >= (unsigned)N) return;
     const size_t e = (size_t)r * N + c, cb = (size_t)(r / (unsigned)M) * N + c;
+    const float rm = rmax[r], rs = rsum[r];
+    if (VEC) {
+        const float4 x = *reinterpret_cast<const float4 *>(S + e);
+        const float4 cm = *reinterpret_cast<const float4 *>(cmax + cb), cs = *reinterpret_cast<const float4 *>(csum + cb);
+        float4 o;
+        o.x = (expf(x.x * itau - rm) / rs) * (expf(x.x * itau - cm.x) / cs.x);
+        o.y = (expf(x.y * itau - rm) / rs) * (expf(x.y * itau - cm.y) / cs.y);
+        o.z = (expf(x.z * itau - rm) / rs) * (expf(x.z * itau - cm.z) / cs.z);
+        o.w = (expf(x.w * itau - rm) / rs) * (expf(x.w * itau - cm.w) / cs.w);
+        *reinterpret_cast<float4 *>(S + e) = o;
+        return;
+    }
     const float x = S[e] * itau;
-    S[e] = (expf(x - rmax[r]) / rsum[r]) * (expf(x - cmax[cb]) / csum[cb]);
+    S[e] = (expf(x - rm) / rs) * (expf(x - cmax[cb]) / csum[cb]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1197,17 +1233,18 @@ extern "C" int dpm_map_tile(const float *key_points, const int32_t *select, cons
 
 extern "C" int dpm_posemb(const float *xyz, int ld, const float *dim_t, int F, int E, int R, float *out,
                           dpm_stream_t stream) {
-    DPM_CHECK_ARG(xyz && dim_t && out && ld >= 3 && F >= 1 && E >= 3 * F && R >= 1);
+    DPM_CHECK_ARG(xyz && dim_t && out && ld >= 3 && F >= 1 && E >= 3 * F && R >= 1 && (long long)R * E < (1ll << 32));
     hipLaunchKernelGGL(posemb_kernel, dim3(dpm_cdiv((long long)R * E, 256)), dim3(256), 0, (hipStream_t)stream, xyz, ld,
                        dim_t, F, E, R, 3.14159265358979323846f, out);
     return dpm_launch_status();
 }
 
-extern "C" int dpm_attention_masked(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
-                                    const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B,
-                                    int M, int N, int heads, int head_dim, int kv_shift, const uint8_t *key_mask,
-                                    dpm_stream_t stream) {
+static int attention_launch(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                            const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B,
+                            int M, int N, int heads, int head_dim, int kv_shift, const uint8_t *key_mask,
+                            const int32_t *seq, dpm_stream_t stream) {
     DPM_CHECK_ARG(Q && K && V && out && B >= 1 && M >= 1 && N >= 1 && heads >= 1 && kv_shift >= 0 && kv_shift < B);
+    if (seq && (head_dim != HD || key_mask)) return DPM_EUNSUPPORTED;
     if (head_dim != HD) {  // other decoder widths: the generic kernel
         const float sc = (float)(1.0 / sqrt((double)head_dim));
         const dim3 grid(dpm_cdiv(M, 4), heads, B);
@@ -1235,7 +1272,8 @@ extern "C" int dpm_attention_masked(const float *Q, int ldq, long long sq, const
     const bool wide = M % 128 == 0 && (long long)(M / 128) * heads * B >= 1024;
 #define DPM_ATT(V, QT)                                                                                                  \
     hipLaunchKernelGGL((attention_kernel<V, QT>), dim3(dpm_cdiv(M, 64 * QT), heads, B), dim3(256), 0, (hipStream_t)stream, \
-                       Q, ldq, sq, K, ldk, sk, V_, ldv, sv, out, ldo, so, M, N, scale, kv_shift)
+                       Q, ldq, sq, K, ldk, sk, V_, ldv, sv, out, ldo, so, M, N, scale, kv_shift, nullptr, 1, nullptr,     \
+                       nullptr, seq)
     const float *V_ = V;
     if (key_mask) {
         if (vec)
@@ -1252,6 +1290,28 @@ extern "C" int dpm_attention_masked(const float *Q, int ldq, long long sq, const
     else DPM_ATT(false, 1);
 #undef DPM_ATT
     return dpm_launch_status();
+}
+
+extern "C" int dpm_attention_masked(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                                    const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B,
+                                    int M, int N, int heads, int head_dim, int kv_shift, const uint8_t *key_mask,
+                                    dpm_stream_t stream) {
+    return attention_launch(Q, ldq, sq, K, ldk, sk, V, ldv, sv, out, ldo, so, B, M, N, heads, head_dim, kv_shift, key_mask,
+                            nullptr, stream);
+}
+
+// dpm_attention_shifted over batch elements DRAWN from a smaller set of stored sequences: element b's queries are stored
+// sequence seq_index[b] (Q + seq_index[b] * sq), its keys / values stored sequence seq_index[(b + kv_shift) mod B]; the
+// output is per batch element.  The consecutive-frame registrations of a batch use every frame as a source and as a
+// target, and the first cross-attention block's projections depend on the frame alone: they are computed once per frame
+// and attended through this entry point (head_dim 32, no key mask).
+extern "C" int dpm_attention_indexed(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                                     const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B,
+                                     int M, int N, int heads, int head_dim, int kv_shift, const int32_t *seq_index,
+                                     dpm_stream_t stream) {
+    DPM_CHECK_ARG(seq_index);
+    return attention_launch(Q, ldq, sq, K, ldk, sk, V, ldv, sv, out, ldo, so, B, M, N, heads, head_dim, kv_shift, nullptr,
+                            seq_index, stream);
 }
 
 // Key-split form (few queries, many keys; see attention_kernel<SPLIT>): same arguments as dpm_attention_shifted plus the
@@ -1304,7 +1364,10 @@ extern "C" int dpm_attention(const float *Q, int ldq, long long sq, const float 
 
 extern "C" int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stream) {
     DPM_CHECK_ARG(x && out && R >= 1 && C >= 1);
-    hipLaunchKernelGGL(l2norm_kernel, dim3(dpm_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, R, C, out);
+    if (C % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(l2norm_kernel<true>, dim3(dpm_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, R, C, out);
+    else
+        hipLaunchKernelGGL(l2norm_kernel<false>, dim3(dpm_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, R, C, out);
     return dpm_launch_status();
 }
 
@@ -1345,8 +1408,13 @@ extern "C" int dpm_dual_softmax_topk(float *S, int batch, int M, int N, double t
         hipLaunchKernelGGL(col_slab_finish_kernel, dim3(dpm_cdiv(N, 256), batch), dim3(256), 0, st, N, splits, pmax, psum, cmax,
                            csum);
     }
-    hipLaunchKernelGGL(dual_softmax_kernel, dim3((unsigned)(BM * dpm_cdiv(N, 256))), dim3(256), 0, st, S, (long long)BM, M, N,
-                       itau, rmax, rsum, cmax, csum);
+    if (N % 4 == 0 && ((uintptr_t)S & 15) == 0 && ((uintptr_t)cmax & 15) == 0 && ((uintptr_t)csum & 15) == 0 &&
+        (long long)BM * (N / 4) < (1ll << 31))
+        hipLaunchKernelGGL(dual_softmax_kernel<true>, dim3((unsigned)dpm_cdiv((long long)BM * (N / 4), 256)), dim3(256), 0, st, S,
+                           (long long)BM, M, N, itau, rmax, rsum, cmax, csum);
+    else
+        hipLaunchKernelGGL(dual_softmax_kernel<false>, dim3((unsigned)(BM * dpm_cdiv(N, 256))), dim3(256), 0, st, S, (long long)BM,
+                           M, N, itau, rmax, rsum, cmax, csum);
     const long long n = (long long)M * N;
     if (n < TOPK_BIG) {
         hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(TK_THREADS), 0, st, S, n, k, out_val, out_idx);

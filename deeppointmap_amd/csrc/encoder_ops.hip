@@ -58,17 +58,17 @@ __global__ __launch_bounds__(1024) void count_valid_kernel(const uint8_t *__rest
 }
 
 __global__ __launch_bounds__(256) void to_channel_first_kernel(const float *__restrict__ x, int R, int C,
-                                                               float *__restrict__ out) {
+                                                               float *__restrict__ out, int ldo) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const float *xi = x + (size_t)b * R * C;
-    float *oi = out + (size_t)b * R * C;
+    float *oi = out + (size_t)b * C * ldo;   // output rows ldo >= R floats apart
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int k = ty; k < 32; k += 8)
         if (r0 + k < R && c0 + tx < C) tile[k][tx] = xi[(size_t)(r0 + k) * C + c0 + tx];
     __syncthreads();
     for (int k = ty; k < 32; k += 8)
-        if (c0 + k < C && r0 + tx < R) oi[(size_t)(c0 + k) * R + r0 + tx] = tile[tx][k];
+        if (c0 + k < C && r0 + tx < R) oi[(size_t)(c0 + k) * ldo + r0 + tx] = tile[tx][k];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -482,11 +482,15 @@ extern "C" int dpm_gather_frames(const float *src, long long frame_stride, int r
     return dpm_launch_status();
 }
 
-extern "C" int dpm_to_channel_first(const float *x, int B, int R, int C, float *out, dpm_stream_t stream) {
-    DPM_CHECK_ARG(x && out && B >= 1 && R >= 1 && C >= 1);
+extern "C" int dpm_to_channel_first_ld(const float *x, int B, int R, int C, float *out, int ldo, dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && out && B >= 1 && R >= 1 && C >= 1 && ldo >= R);
     hipLaunchKernelGGL(to_channel_first_kernel, dim3(dpm_cdiv(C, 32), dpm_cdiv(R, 32), B), dim3(256), 0,
-                       (hipStream_t)stream, x, R, C, out);
+                       (hipStream_t)stream, x, R, C, out, ldo);
     return dpm_launch_status();
+}
+
+extern "C" int dpm_to_channel_first(const float *x, int B, int R, int C, float *out, dpm_stream_t stream) {
+    return dpm_to_channel_first_ld(x, B, R, C, out, R, stream);
 }
 
 extern "C" int dpm_group_mlp_max_generic(const float *xyz, const float *fea, const float *centers, const int32_t *idx,

@@ -17,6 +17,7 @@ the three SLAM threads of the reference can share one instance (system/core.py:5
 from __future__ import annotations
 
 import copy
+import os
 import threading
 from typing import Dict, Tuple, Union
 
@@ -39,6 +40,8 @@ class Decoder(ParamTree):
         self.tau = args.loss.tau
         self._dim_t: Dict[str, torch.Tensor] = {}
         self.stack_sides = True   # M != N: one launch per row-wise layer over both sides (False: the per-side loop)
+        # pair lists over shared frames: per-frame work once per frame (False / DPM_DEDUP_FRAMES=0: per pair side, A/B runs)
+        self.dedup_frames = os.environ.get("DPM_DEDUP_FRAMES", "1") != "0"
         # One-pair registrations (the reference's own call: odometry.py:108-110, mapping.py:153-155, loop_closure.py:239-242)
         # are ~50 small launches whose enqueue takes longer than their execution.  A shape (M, N, k) that keeps coming back is
         # captured once as a HIP graph over static input / output buffers and replayed from then on: same kernels, same
@@ -95,12 +98,15 @@ class Decoder(ParamTree):
                                     self.p(ln + ".bias"), pre=residual, post=post)
 
     def _stage(self, desc: torch.Tensor, dev) -> Tuple[torch.Tensor, torch.Tensor, int, int]:
-        """(B,131,M) any device -> token-major rows (B*M,131) on the GPU."""
+        """(B,131,M) any device -> token-major rows (B*M,131) on the GPU.  The rows are 132 floats apart: the 128 feature
+        columns of every token start 16-byte aligned, which the projection GEMM's vector loads need (with rows of 131
+        floats it took the scalar-load kernel: 34.6 against 13 us per 64-pair batch)."""
         d = desc.to(device=dev, dtype=torch.float32).contiguous()
         B, C, M = d.shape
         if C != self.in_channel + 3:
             raise ValueError(f"descriptor must have {self.in_channel + 3} rows, got {C}")
-        return ops.to_channel_first(d).view(B * M, C), B, M
+        t = ops.to_channel_first(d, row_multiple=4)           # (B,M,C) view of a (B,M,ld) buffer
+        return t.as_strided((B * M, C), (t.stride(1), 1), t.storage_offset()), B, M
 
     def _self_attn(self, pre: str, xp, B, M, norm: str = None, post=None, mask=None):
         """x + MHA(x, x, x) (norm None) or LN_norm(x + MHA(x, x, x)) + post, the out-projection carrying the norm;
@@ -227,12 +233,16 @@ class Decoder(ParamTree):
             order = sidx if didx is None else torch.cat([sidx, didx])  # (2B,) int32: sources then targets
             pos = ops.gather_frames(pos_u, order, M, E).view(2 * R, E)
             z1_first = ops.gather_frames(z1u, order, M, E).view(2 * R, E)
+            # the first cross-attention block's q | k | v projection sees the frame alone as well: once per frame, the
+            # attention kernel picks a pair's sequences through `order` (row-wise kernel: the same rows bit for bit)
+            ca0 = pre + ".cross_attn"
+            qkv_u = ops.linear(z1u, self.p(ca0 + ".in_proj_weight"), self.p(ca0 + ".in_proj_bias")) if self.dedup_frames else None
             zp = None
         else:
             z_in = torch.cat([ts, td], dim=0)                       # (2R, 131): [src tokens ; dst tokens]
             pos = ops.posemb(z_in[:, C:C + 3], self._dimt(dev), E)
             zp = ops.linear(z_in[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=pos)
-            z1_first = None
+            z1_first = qkv_u = None
         for l in range(self.attention_layers):
             pre = f"descriptor_attention.{l}"
             last = l == self.attention_layers - 1
@@ -241,10 +251,14 @@ class Decoder(ParamTree):
             else:
                 z1 = self._self_attn(pre + ".self_attn", zp, 2 * B, M, norm=pre + ".norm1", post=pos, mask=mask)
             ca = pre + ".cross_attn"
-            qkv = ops.linear(z1, self.p(ca + ".in_proj_weight"), self.p(ca + ".in_proj_bias"))  # q | k | v of every token
             # both directions in one launch: sequence b (source of pair b, or target of pair b - B) reads the keys and
             # values of sequence (b + B) mod 2B, its partner
-            a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], 2 * B, M, M, HEADS, kv_shift=B, key_mask=mask)
+            if l == 0 and z1_first is not None and qkv_u is not None:
+                a = ops.attention(qkv_u[:, :E], qkv_u[:, E:2 * E], qkv_u[:, 2 * E:], 2 * B, M, M, HEADS, kv_shift=B,
+                                  seq_index=order)
+            else:
+                qkv = ops.linear(z1, self.p(ca + ".in_proj_weight"), self.p(ca + ".in_proj_bias"))  # q | k | v of every token
+                a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], 2 * B, M, M, HEADS, kv_shift=B, key_mask=mask)
             z2 = self._lin_ln(ca + ".out_proj", pre + ".norm2", a, z1)
             zp = self._lin_ln(pre + ".mlp.2", pre + ".norm3", self._lin(pre + ".mlp.0", z2, ops.ACT_RELU), z2,
                               None if last else pos)
@@ -279,7 +293,7 @@ class Decoder(ParamTree):
             tu, U, M = self._stage(src_descriptor, dev)
             N, B, C = M, sidx.numel(), self.in_channel
             x, y = self._attention_layers_joint(None, None, B, M, frames=(tu, order, None))
-            xyz_sd = ops.gather_frames(tu, order, M, 3, ld=C + 3, offset=C).view(2 * B * M, 3)
+            xyz_sd = ops.gather_frames(tu, order, M, 3, ld=tu.stride(0), offset=C).view(2 * B * M, 3)
             xyz_s, xyz_d = xyz_sd[:B * M], xyz_sd[B * M:]
         else:
             x, xyz_s, y, xyz_d, B, M, N = self._descriptor_attention_forward(src_descriptor, dst_descriptor, *masks)

@@ -93,7 +93,11 @@ def gather_frames(src: torch.Tensor, index: torch.Tensor, rows: int, cols: int, 
                   offset: int = 0) -> torch.Tensor:
     """out (n, rows, cols) = rows [0, rows) x columns [offset, offset + cols) of the frames index[p] of `src`
     (frames `frame_stride` floats apart, rows `ld` floats apart; defaults: packed)."""
-    _chk(src, torch.float32, "src"), _chk(index, torch.int32, "index")
+    _chk(index, torch.int32, "index")
+    if ld is None:
+        _chk(src, torch.float32, "src")
+    elif not src.is_cuda or src.dtype != torch.float32 or src.stride(-1) != 1:   # an explicit row stride: a row view
+        raise ValueError("src: expected an fp32 GPU tensor with unit column stride")
     ld = cols if ld is None else ld
     frame_stride = rows * ld if frame_stride is None else frame_stride
     n = index.numel()
@@ -104,12 +108,15 @@ def gather_frames(src: torch.Tensor, index: torch.Tensor, rows: int, cols: int, 
     return out
 
 
-def to_channel_first(x: torch.Tensor) -> torch.Tensor:
+def to_channel_first(x: torch.Tensor, row_multiple: int = 1) -> torch.Tensor:
+    """(B,R,C) -> (B,C,R).  row_multiple > 1: the output rows are padded to a multiple of that many floats and the result
+    is the (B,C,R) view of the padded buffer (row stride > R)."""
     _chk(x, torch.float32, "x")
     B, R, C = x.shape
-    out = torch.empty(B, C, R, device=x.device, dtype=torch.float32)
-    _lib.check(_lib.load().dpm_to_channel_first(_ptr(x), B, R, C, _ptr(out), _stream(x)), "dpm_to_channel_first")
-    return out
+    ldo = -(-R // row_multiple) * row_multiple
+    out = torch.empty(B, C, ldo, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().dpm_to_channel_first_ld(_ptr(x), B, R, C, _ptr(out), ldo, _stream(x)), "dpm_to_channel_first")
+    return out[:, :, :R] if ldo != R else out
 
 
 def fps(xyz: torch.Tensor, lengths: torch.Tensor, K: int, algo: int = 0, start: Optional[torch.Tensor] = None):
@@ -500,11 +507,14 @@ def attention_key_splits(B: int, M: int, N: int, heads: int, head_dim: int) -> i
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, M: int, N: int, heads: int = 8,
-              out: Optional[torch.Tensor] = None, kv_shift: int = 0, key_mask: Optional[torch.Tensor] = None):
+              out: Optional[torch.Tensor] = None, kv_shift: int = 0, key_mask: Optional[torch.Tensor] = None,
+              seq_index: Optional[torch.Tensor] = None):
     """q (B*M,E) / k,v (B*N,E) row views (column slices of wider buffers allowed) -> (B*M,E)
     (written into `out`, a contiguous (B*M,E) tensor or row range of one, when given).
     kv_shift: sequence b attends the keys / values of sequence (b + kv_shift) mod B.
-    key_mask (B,N) uint8, non-zero = padding key (nn.MultiheadAttention's key_padding_mask), indexed like the keys."""
+    key_mask (B,N) uint8, non-zero = padding key (nn.MultiheadAttention's key_padding_mask), indexed like the keys.
+    seq_index (B,) int32: q / k / v hold U stored sequences ((U*M,E) / (U*N,E)) and batch element b is stored sequence
+    seq_index[b] (its keys / values: stored sequence seq_index[(b + kv_shift) mod B]); the output stays (B*M,E)."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _rows2d(t, n)
     E = q.shape[1]
@@ -516,6 +526,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, M: int,
         _chk(key_mask, torch.uint8, "key_mask")
         if tuple(key_mask.shape) != (B, N):
             raise ValueError(f"key_mask must be ({B}, {N}), got {tuple(key_mask.shape)}")
+    if seq_index is not None:
+        _chk(seq_index, torch.int32, "seq_index")
+        if seq_index.numel() != B or key_mask is not None:
+            raise ValueError("seq_index must hold B entries and excludes key_mask")
+        _lib.check(_lib.load().dpm_attention_indexed(_ptr(q), q.stride(0), M * q.stride(0), _ptr(k), k.stride(0),
+                                                     N * k.stride(0), _ptr(v), v.stride(0), N * v.stride(0), _ptr(out), E,
+                                                     M * E, B, M, N, heads, E // heads, int(kv_shift), _ptr(seq_index),
+                                                     _stream(q)), "dpm_attention_indexed")
+        return out
     nsplit = attention_key_splits(B, M, N, heads, E // heads) if key_mask is None else 1
     if nsplit > 1:
         lib = _lib.load()

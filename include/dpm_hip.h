@@ -49,6 +49,10 @@ int dpm_prepare_points(const float *points_cf, const uint8_t *padding, int B, in
 
 /* (B,R,C) point-major -> (B,C,R) channel-first (the layout Encoder.forward returns). */
 int dpm_to_channel_first(const float *x, int B, int R, int C, float *out, dpm_stream_t stream);
+/* The same with the output rows ldo >= R floats apart (batch elements C * ldo apart).  The decoder stages the reference's
+ * channel-first descriptors (B,131,M) (odometry.py:47-49) as token rows of 132 floats, so that the 128 feature columns of
+ * a row start 16-byte aligned for the projection GEMM (descriptor_attention.py:24-30). */
+int dpm_to_channel_first_ld(const float *x, int B, int R, int C, float *out, int ldo, dpm_stream_t stream);
 
 /* The encoder's return triple [coor (B,3,S), feat (B,C,S), padding (B,S; 1 = padded)] (network/encoder/encoder.py:51-69)
  * from the point-major level (xyz (B,S,3), fea (B,S,C), lengths), and -- desc != NULL -- the unified descriptor
@@ -271,6 +275,17 @@ int dpm_attention_shifted(const float *Q, int ldq, long long sq, const float *K,
 int dpm_attention_masked(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
                          const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
                          int N, int heads, int head_dim, int kv_shift, const uint8_t *key_mask, dpm_stream_t stream);
+
+/* dpm_attention_shifted over batch elements DRAWN from a smaller set of stored sequences: element b's queries are stored
+ * sequence seq_index[b] (Q + seq_index[b] * sq), its keys / values stored sequence seq_index[(b + kv_shift) mod B]
+ * (K / V + ... * sk / sv); out is per batch element.  The consecutive-frame registrations of a batch (odometry.py:103-127)
+ * use every frame as a source and as a target, and the q | k | v projection of the first cross-attention block
+ * (descriptor_attention.py:41-44) depends on the frame alone: it is computed once per frame and attended through this
+ * entry point -- row-wise kernels give the same rows whatever the row count, so the result equals the per-pair form bit
+ * for bit.  head_dim 32 only; seq_index (B) int32 on the device. */
+int dpm_attention_indexed(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
+                          const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
+                          int N, int heads, int head_dim, int kv_shift, const int32_t *seq_index, dpm_stream_t stream);
 
 /* Key-split form of dpm_attention_shifted for FEW queries against MANY keys (scan-to-map registration: 256 scan tokens
  * attending a 4096-token map tile, mapping.py:153-155 -> descriptor_attention.py:41-44): the keys are cut into `nsplit`

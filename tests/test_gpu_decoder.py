@@ -317,6 +317,29 @@ def test_pairs_entry_equals_batched_entry(dec):
         assert n_in > 0 and torch.equal(r1[b, 20:20 + n_in], r2[b, 20:20 + n_in])
 
 
+def test_pairs_entry_projects_each_frame_once(dec):
+    """64 consecutive-frame pairs over 65 frames (the bench's shape: 32-query waves in the attention kernel): the first
+    cross-attention block's q | k | v projection runs once per FRAME and the attention kernel picks each pair's sequences
+    through the index list (dpm_attention_indexed); bit-equal to projecting every pair side (dedup_frames = False)."""
+    gen = torch.Generator().manual_seed(11)
+    frames = torch.randn(65, 131, 256, generator=gen)
+    frames[:, 128:] = torch.rand(65, 3, 256, generator=gen) * 2 - 1
+    frames = frames.to(DEV)
+    src = torch.arange(0, 64, dtype=torch.int32, device=DEV)
+    dst = src + 1
+    assert dec.dedup_frames
+    try:
+        r1 = dec.registration_forward_pairs(frames, src, dst, 0.5)
+        dec.dedup_frames = False
+        r2 = dec.registration_forward_pairs(frames, src, dst, 0.5)
+    finally:
+        dec.dedup_frames = True
+    assert torch.equal(r1[:, :16].contiguous().view(torch.int32), r2[:, :16].contiguous().view(torch.int32))  # NaN-safe
+    for b in range(64):
+        n_in = int(r1[b, 14])
+        assert torch.equal(r1[b, 20:20 + n_in], r2[b, 20:20 + n_in])
+
+
 def test_batched_information_matrix_equals_single(ops):
     """3 pairs (plain block mapping) and 8 pairs (XCD-aware mapping, one of them with the source pushed half
     out of the target's bounding box) against the single-pair entry point."""
