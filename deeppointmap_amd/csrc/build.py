@@ -37,9 +37,12 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, flags=(), out=None):
+    """flags / out: an experimental build with extra compiler flags into a library of its own (objects under build/<name>/;
+    `DPM_LIB=<out>` selects it at run time: A/B measurements of one tree in one GPU session)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build") if out is None else os.path.join(HERE, "build", os.path.basename(out) + ".d")
+    OUT = globals()["OUT"] if out is None else out
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "dpm_hip.h"))
@@ -48,7 +51,7 @@ def build(force=False, verbose=False):
         s = os.path.join(HERE, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *COMMON, *extra, "-c", s, "-o", o])
+            jobs.append([hipcc, *COMMON, *extra, *flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -83,5 +86,9 @@ def build_abi_smoke(verbose=False):
 
 
 if __name__ == "__main__":
+    if "--out" in sys.argv:   # python build.py --out <lib.so> [extra compiler flags ...]
+        i = sys.argv.index("--out")
+        print(build(verbose=True, flags=tuple(a for a in sys.argv[i + 2:]), out=os.path.abspath(sys.argv[i + 1])))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_abi_smoke(verbose=True))

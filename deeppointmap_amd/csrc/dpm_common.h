@@ -31,6 +31,16 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Issue priority of the kernels that are bound by vector-ALU issue (neighbour searches, gather + LayerNorm kernels, the
+// NN-1 search): inside the stream pipeline they share every SIMD with matrix-pipe kernels and the sampling chains.
+// -DDPM_VALU_PRIO=n builds a library whose VALU-bound kernels run at wave priority n (A/B measurements; 0 = default).
+#ifndef DPM_VALU_PRIO
+#define DPM_VALU_PRIO 0
+#endif
+__device__ __forceinline__ void valu_bound_priority() {
+    if (DPM_VALU_PRIO) __builtin_amdgcn_s_setprio(DPM_VALU_PRIO);
+}
+
 // XCD-aware workgroup order.  Workgroups are dealt round-robin to the 8 XCDs by linear id and every XCD has its own
 // 4 MB L2; with the plain order all XCDs walk through all frames at once and every L2 holds a slice of everything.
 // This maps the hardware id to a logical id such that XCD x processes the contiguous chunk [x*n/8, (x+1)*n/8) in

@@ -456,6 +456,7 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
     const float *__restrict__ Wr, int ldwr, const float *__restrict__ gamma, const float *__restrict__ beta, int N,
     int S, int K, long long total, int cpw, float inv_r, float *__restrict__ out_all) {
     constexpr int G = COUT / (4 * V), RPW = 64 / G;  // lanes per row, rows per wave pass
+    valu_bound_priority();
     // the wave index through readfirstlane: the centre loop, its frame pointers and the centre itself become scalar
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), gl = lane % G, gr = lane / G;
     // per-lane constants for its 4*V channels: relative-coordinate weights, LayerNorm affine, (AFFINE) the point map

@@ -120,92 +120,84 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float inv_cs, int g
     return min(max((int)floorf((v - lo) * inv_cs), 0), g - 1);
 }
 
-// Counting sort of pcd2 into the grid, entirely in LDS: the cells are split into SLABS contiguous index ranges
-// and one 1024-thread workgroup owns one slab of one pair.  It streams the pair's points twice (count, then
-// place), keeps its cells' counters / cursors in LDS and derives its global base offset from the number of
-// points that fall into earlier slabs, so slabs need no communication and there is no global atomic at all
-// (the three-kernel count / scan / scatter version spent 0.35 ms per launch in device-scope atomics).
-constexpr int SLABS = 8;
-constexpr int SLAB_CELLS = GMAX * GMAX / SLABS;  // 32768 32-bit counters = 128 KB of LDS
+// Counting sort of pcd2 into the grid as FOUR short chip-wide kernels with a few KB of LDS each (round 3).  The one-kernel
+// form it replaces kept a scan's 57 600 cell counters in the LDS of ONE 1024-thread workgroup (131 KB): 64 compute units
+// were closed to every other workgroup of the pipeline for the 0.23 ms (0.47 ms under load) it took, and the pipelined
+// step was 0.2 ms shorter without it (ablation).  Now:
+//   rows:    a workgroup takes a chunk of GB_CHUNK points, counts them per grid ROW (<= 512 counters in LDS) and leaves
+//            the histogram in the workspace;
+//   offsets: one workgroup per scan turns the histograms into start offsets per (chunk, row) and per row;
+//   scatter: the chunks again -- a point goes to its row's range in a temporary array (points of one chunk and row are
+//            consecutive there);
+//   cells:   one WAVE per grid row: counting sort of the row's points by cell (<= 512 counters in LDS per wave) into the
+//            final array, plus the row's cell start offsets.
+// The order of the points inside a cell depends on scheduling (LDS atomics); nothing downstream depends on it: the search
+// takes the minimum of (distance, original index) keys and sums integers.
+constexpr int GB_CHUNK = 4096;  // points per workgroup of the row passes (16 per thread)
 
-// Counters come in two widths.  For scans of up to 65 536 points a counter -- and the cursor of a non-empty cell -- fits 16
-// bits once point 0 is kept out of the histogram (it is added back in the scan and placed first in its cell by the thread
-// that scans that cell): two counters per word, added to with one 32-bit LDS atomic on the right half, 65 536 cells per
-// slab (a 120 m x 120 m scan on half-metre cells is ONE slab; every further slab streams all points again).  Larger scans
-// use 32-bit counters.  A cursor that reaches 65 536 carries into its neighbour's half: that is the cell holding the scan's
-// last point, and every cell behind it is empty and never used as a cursor.
-__device__ __forceinline__ void cnt_inc(int *cnt, int c, bool pack) {
-    if (pack) atomicAdd((unsigned *)&cnt[c >> 1], 1u << ((c & 1) * 16));
-    else atomicAdd(&cnt[c], 1);
+__device__ __forceinline__ float4 *pair_tmp(const PairArgs &a, int p) {
+    return (float4 *)(pair_partial(a, p) + 10 * (size_t)((a.N1 + 255) / 256));
 }
-__device__ __forceinline__ int cnt_take(int *cnt, int c, bool pack) {  // post-increment of a cursor
-    if (pack) {
-        const unsigned sh = (c & 1) * 16;
-        return (int)((atomicAdd((unsigned *)&cnt[c >> 1], 1u << sh) >> sh) & 0xffffu);
-    }
-    return atomicAdd(&cnt[c], 1);
-}
-__device__ __forceinline__ int cnt_get(const int *cnt, int c, bool pack) {
-    return pack ? (int)((const unsigned short *)cnt)[c] : cnt[c];
-}
-__device__ __forceinline__ void cnt_set(int *cnt, int c, int v, bool pack) {
-    if (pack) ((unsigned short *)cnt)[c] = (unsigned short)v;
-    else cnt[c] = v;
+__device__ __forceinline__ int *pair_rowhist(const PairArgs &a, int p) { return (int *)(pair_tmp(a, p) + a.N2); }  // [chunks][GMAX]
+__device__ __forceinline__ int *pair_rowstart(const PairArgs &a, int p) {                                           // [GMAX + 1]
+    return pair_rowhist(a, p) + (size_t)((a.N2 + GB_CHUNK - 1) / GB_CHUNK) * GMAX;
 }
 
-__global__ __launch_bounds__(1024) void grid_build_kernel(PairArgs A) {
-    int pair, slab;
-    pair_block(slab, pair);
+// PLACE = false: row histogram of the chunk; PLACE = true: the chunk's points into their rows' ranges of `tmp`
+template <bool PLACE>
+__global__ __launch_bounds__(256) void grid_rows_kernel(PairArgs A) {
+    int pair, chunk;
+    pair_block(chunk, pair);
     const float *p2 = pair_p2(A, pair);
     const int N2 = A.N2;
     const GridHdr *hdr = pair_hdr(A, pair);
-    int *start = pair_count(A, pair);
-    float4 *sorted = pair_sorted(A, pair);
-    __shared__ int cnt[SLAB_CELLS];
-    __shared__ int wsum[16];
-    __shared__ int s_before;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int ncell = hdr->ncell, gx = hdr->gx, gy = hdr->gy;
-    const float lox = hdr->lox, loy = hdr->loy, inv_cs = hdr->inv_cs;
-    const bool pack = N2 <= 65536;
-    const int cell0 = cell_coord(p2[N2], loy, inv_cs, gy) * gx + cell_coord(p2[0], lox, inv_cs, gx);  // point 0's cell
-    const int cap = pack ? 2 * SLAB_CELLS : SLAB_CELLS;
-    // as few slabs as the LDS allows: every slab streams all points, so extra slabs only cost; the surplus workgroups
-    // leave at once
-    const int used = (ncell + cap - 1) / cap;
-    if (slab >= used) return;
-    const int per = (((ncell + used - 1) / used) + 1) & ~1;  // even: a packed word belongs to one slab
-    const int c0 = min(slab * per, ncell), c1 = min(c0 + per, ncell), nc = c1 - c0;
-    for (int c = t; c < (pack ? (nc + 1) / 2 : nc); c += 1024) cnt[c] = 0;
-    if (t == 0) s_before = 0;
+    const int gy = hdr->gy;
+    const float loy = hdr->loy, inv_cs = hdr->inv_cs;
+    __shared__ int cnt[GMAX];
+    int *hist = pair_rowhist(A, pair) + (size_t)chunk * GMAX;
+    const int t = threadIdx.x;
+    for (int r = t; r < gy; r += 256) cnt[r] = PLACE ? hist[r] : 0;
     __syncthreads();
-    int before = 0;
-    constexpr int UB = 8;  // points per thread per batch: all loads of a batch are in flight before any is used
-    for (int i0 = t; i0 < N2; i0 += 1024 * UB) {
-        float xs[UB], ys[UB];
+    constexpr int PPT = GB_CHUNK / 256;
+    const int i0 = chunk * GB_CHUNK + t;
+    float xs[PPT], ys[PPT], zs[PPT];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int i = min(i0 + u * 1024, N2 - 1);
-            xs[u] = p2[i], ys[u] = p2[(size_t)N2 + i];
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            if (i0 + u * 1024 >= N2) break;
-            const int cell = cell_coord(ys[u], loy, inv_cs, gy) * gx + cell_coord(xs[u], lox, inv_cs, gx);
-            if (cell < c0) ++before;
-            else if (cell < c1 && !(pack && i0 + u * 1024 == 0)) cnt_inc(cnt, cell - c0, pack);
-        }
+    for (int u = 0; u < PPT; ++u) {  // all loads of the chunk in flight before the first is used
+        const int i = min(i0 + u * 256, N2 - 1);
+        ys[u] = p2[(size_t)N2 + i];
+        if (PLACE) xs[u] = p2[i], zs[u] = p2[2 * (size_t)N2 + i];
     }
+    float4 *tmp = pair_tmp(A, pair);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
-    if (lane == 0 && before) atomicAdd(&s_before, before);
+    for (int u = 0; u < PPT; ++u) {
+        const int i = i0 + u * 256;
+        if (i >= N2) break;
+        const int row = cell_coord(ys[u], loy, inv_cs, gy);
+        const int pos = atomicAdd(&cnt[row], 1);
+        if (PLACE) tmp[pos] = make_float4(xs[u], ys[u], zs[u], __int_as_float(i));
+    }
+    if (PLACE) return;
     __syncthreads();
-    // exclusive scan of the slab's counters (base = points of earlier slabs) -> cell start offsets; a thread's run of cells
-    // starts on an even cell, so the halves of a packed word have one writer
-    const int chunk = (((nc + 1023) / 1024) + 1) & ~1;
-    const int a = min(t * chunk, nc), b = min(a + chunk, nc);
-    int sum = 0;
-    for (int c = a; c < b; ++c) sum += cnt_get(cnt, c, pack) + (pack && c0 + c == cell0);
+    for (int r = t; r < gy; r += 256) hist[r] = cnt[r];
+}
+
+// histograms [chunk][row] -> start offset of every (chunk, row) run in `tmp` (in place) and of every row (rowstart)
+__global__ __launch_bounds__(256) void grid_offsets_kernel(PairArgs A) {
+    const int pair = blockIdx.x;
+    const GridHdr *hdr = pair_hdr(A, pair);
+    const int gy = hdr->gy, chunks = (A.N2 + GB_CHUNK - 1) / GB_CHUNK;
+    int *hist = pair_rowhist(A, pair), *rowstart = pair_rowstart(A, pair);
+    __shared__ int wsum[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // thread t owns rows 2t and 2t + 1 (gy <= GMAX = 512)
+    int tot[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = 2 * t + k;
+        if (r < gy)
+            for (int c = 0; c < chunks; ++c) tot[k] += hist[(size_t)c * GMAX + r];
+    }
+    const int sum = tot[0] + tot[1];
     int inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -214,34 +206,66 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(PairArgs A) {
     }
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    int run = s_before + inc - sum;
+    int run = inc - sum;
     for (int k = 0; k < w; ++k) run += wsum[k];
-    for (int c = a; c < b; ++c) {
-        const bool first = pack && c0 + c == cell0;
-        const int v = cnt_get(cnt, c, pack) + first;
-        if (first) sorted[run] = make_float4(p2[0], p2[N2], p2[2 * (size_t)N2], __int_as_float(0));
-        cnt_set(cnt, c, run + first, pack), start[c0 + c] = run;
-        run += v;
-    }
-    if (slab == used - 1 && t == 0) start[ncell] = N2;
-    __syncthreads();
-    for (int i0 = t; i0 < N2; i0 += 1024 * UB) {
-        float xs[UB], ys[UB], zs[UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int i = min(i0 + u * 1024, N2 - 1);
-            xs[u] = p2[i], ys[u] = p2[(size_t)N2 + i], zs[u] = p2[2 * (size_t)N2 + i];
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int i = i0 + u * 1024;
-            if (i >= N2) break;
-            const int cell = cell_coord(ys[u], loy, inv_cs, gy) * gx + cell_coord(xs[u], lox, inv_cs, gx);
-            if (cell >= c0 && cell < c1 && !(pack && i == 0)) {
-                const int pos = cnt_take(cnt, cell - c0, pack);
-                sorted[pos] = make_float4(xs[u], ys[u], zs[u], __int_as_float(i));
+    for (int k = 0; k < 2; ++k) {
+        const int r = 2 * t + k;
+        if (r < gy) {
+            rowstart[r] = run;
+            int at = run;
+            for (int c = 0; c < chunks; ++c) {
+                const int n = hist[(size_t)c * GMAX + r];
+                hist[(size_t)c * GMAX + r] = at, at += n;
             }
+            run = at;
         }
+    }
+    if (t == 0) rowstart[gy] = A.N2;
+}
+
+// one wave per grid row: the row's points (a contiguous range of `tmp`) counting-sorted by cell into `sorted`
+__global__ __launch_bounds__(256) void grid_cells_kernel(PairArgs A) {
+    int pair, blk;
+    pair_block(blk, pair);
+    const GridHdr *hdr = pair_hdr(A, pair);
+    const int gx = hdr->gx, gy = hdr->gy;
+    const float lox = hdr->lox, inv_cs = hdr->inv_cs;
+    __shared__ int cnt[4][GMAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, row = blk * 4 + w;
+    if (row >= gy) return;  // whole waves; no workgroup barrier below
+    const int *rowstart = pair_rowstart(A, pair);
+    int *start = pair_count(A, pair);
+    const float4 *tmp = pair_tmp(A, pair);
+    float4 *sorted = pair_sorted(A, pair);
+    const int lo = rowstart[row], hi = rowstart[row + 1];
+    int *c = cnt[w];
+    for (int k = lane; k < gx; k += 64) c[k] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int p = lo + lane; p < hi; p += 64) atomicAdd(&c[cell_coord(tmp[p].x, lox, inv_cs, gx)], 1);
+    __builtin_amdgcn_wave_barrier();
+    // exclusive scan over the row's gx counters: lane l owns cells [l * per, (l + 1) * per)
+    const int per = (gx + 63) / 64, a = min(lane * per, gx), b = min(a + per, gx);
+    int sum = 0;
+    for (int k = a; k < b; ++k) sum += c[k];
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    int run = lo + inc - sum;
+    for (int k = a; k < b; ++k) {
+        const int n = c[k];
+        c[k] = run, run += n;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < gx; k += 64) start[(size_t)row * gx + k] = c[k];  // cursors still at the cell starts
+    if (row == gy - 1 && lane == 0) start[(size_t)gy * gx] = A.N2;
+    __builtin_amdgcn_wave_barrier();
+    for (int p = lo + lane; p < hi; p += 64) {
+        const float4 v = tmp[p];
+        sorted[atomicAdd(&c[cell_coord(v.x, lox, inv_cs, gx)], 1)] = v;
     }
 }
 
@@ -271,6 +295,7 @@ __device__ __forceinline__ float quad_min(float v) {
 //  * the moments are summed as 64-bit integers (see the end of the kernel), so the result does not depend on the order the
 //    queries are walked in.
 __global__ __launch_bounds__(256) void nn1_match_kernel(PairArgs A, float r2, int ordered) {
+    valu_bound_priority();
     int pair, blk;
     pair_block(blk, pair);
     const float *p1 = pair_p1(A, pair);
@@ -454,7 +479,8 @@ __global__ __launch_bounds__(64) void infomat_finalize_kernel(PairArgs A) {
 
 static size_t ws_slice_bytes(int N1, int N2) {
     size_t b = 256 + sizeof(int) * (size_t)(GMAX * GMAX + 1) + 12 + sizeof(float4) * (size_t)N2 +
-               10 * sizeof(long long) * (size_t)dpm_cdiv(N1, 256);
+               10 * sizeof(long long) * (size_t)dpm_cdiv(N1, 256) +
+               sizeof(float4) * (size_t)N2 + sizeof(int) * ((size_t)dpm_cdiv(N2, GB_CHUNK) * GMAX + GMAX + 4);  // row-sorted copy, row histograms, row starts
     return (b + 255) & ~(size_t)255;
 }
 
@@ -465,7 +491,12 @@ extern "C" size_t dpm_infomat_workspace_bytes(int n_pairs, int N1, int N2) {
 static int launch_grid(PairArgs A, int n_pairs, double radius, hipStream_t st) {
     const char *fine = getenv("DPM_NN1_FINE");  // 0: cells of one radius and 3x3 blocks (the round-2 layout; A/B measurements)
     hipLaunchKernelGGL(grid_setup_kernel, dim3(n_pairs), dim3(1024), 0, st, A, (float)radius, fine ? atoi(fine) : 1);
-    hipLaunchKernelGGL(grid_build_kernel, dim3(SLABS, n_pairs), dim3(1024), 0, st, A);
+    if (getenv("DPM_ABLATE_GRID")) return dpm_launch_status();  // timing experiments only (with DPM_ABLATE_NN1: nothing reads the grid)
+    const int chunks = dpm_cdiv(A.N2, GB_CHUNK);
+    hipLaunchKernelGGL(grid_rows_kernel<false>, dim3(chunks, n_pairs), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(grid_offsets_kernel, dim3(n_pairs), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(grid_rows_kernel<true>, dim3(chunks, n_pairs), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(grid_cells_kernel, dim3(GMAX / 4, n_pairs), dim3(256), 0, st, A);
     return dpm_launch_status();
 }
 

@@ -757,6 +757,7 @@ __global__ __launch_bounds__(WPB * 64) void knn_grid_fast_kernel(const int32_t *
                                                                  int *__restrict__ todo_count, int32_t *__restrict__ todo_rows,
                                                                  int todo_cap) {
     constexpr int CPB = WPB * 64 / QL;  // centres per block
+    valu_bound_priority();
     const unsigned bid = xcd_chunked_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int b = bid / gridDim.x;
     const int ql = threadIdx.x & (QL - 1);
