@@ -241,7 +241,10 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                                                         int32_t *__restrict__ new_len, int slots,
                                                         const int32_t *__restrict__ start = nullptr) {
     constexpr int NW = FB / 64;
-    constexpr int OB = 2048;  // picks buffered in LDS between flushes to global memory
+#ifndef DPM_FPS_OB
+#define DPM_FPS_OB 2048
+#endif
+    constexpr int OB = DPM_FPS_OB;  // picks buffered in LDS between flushes to global memory
     // per-wave bests, double-buffered by round parity: [parity][value, index bits, x, y, z][wave] in ONE block, so
     // a wave's five fields are one address plus immediate offsets
     __shared__ float s_ex[2][5][NW];

@@ -1488,8 +1488,11 @@ void launch_grid_build(const float *points, const int32_t *lengths, int B, int N
     // cell edge > sqrt(r^2 + 2e-5 max(1, max |p|^2)): the expanded-form distance can undershoot the true one by ~1.5e-6 on
     // unit-ball coordinates and proportionally more on larger ones (the kernel knows the frame's extent)
     const float cs_min = (float)(sqrt(radius * radius + 2e-5) * 1.002);
-    hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, st, points, lengths, N, cs_min, (float)(radius * radius),
-                       w.hdr, w.start, w.sorted, w.tie_count);
+    // DPM_PRICE_KNN_BUILD=n: the (idempotent) build n more times -- what the kernel costs the pipelined step is the step's growth
+    const char *pr = getenv("DPM_PRICE_KNN_BUILD");
+    for (int rep = 0; rep <= (pr && N >= 16384 ? atoi(pr) : 0); ++rep)
+        hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, st, points, lengths, N, cs_min, (float)(radius * radius),
+                           w.hdr, w.start, w.sorted, w.tie_count);
 }
 // DPM_KNN_FAST=0: every row through the one-wave-per-centre search (the round-2 path; A/B measurements)
 bool knn_fast_enabled() {
