@@ -48,7 +48,7 @@ def pmc_traffic_bytes(frames_per_launch: int):
         if j.get("frames_per_launch") != frames_per_launch:
             return None
         tot = 0
-        for k in ("fps_bucket_kernel", "fps_tree_sort_kernel"):
+        for k in ("fps_bucket_kernel", "fps_str_sort_kernels"):
             tot += (2 * j[k]["FETCH_SIZE_KB"] + j[k]["WRITE_SIZE_KB"]) * 1024
         return int(tot)
     except Exception:
@@ -398,11 +398,11 @@ def main():
                        "parallelism": f"frame-sharded x{world}, one RCCL gather of descriptors+edges per step",
                        "pipeline": "none" if args.no_pipeline else "HIP-stream pipeline: geometry (staging+FPS chain) of batches i, i-1 on two alternating streams | features of batch i-2 | registration+information matrices of batch i-3",
                        "weights": "procedural (deeppointmap_amd/weights.py)"},
-            "roofline": {"kernel": "fps_tree_sort_kernel<buckets>+fps_bucket_kernel (stage-0 farthest point sampling, Sort-Tile-Recursive packing)",
+            "roofline": {"kernel": "str_chunk/str_xoffsets/str_ysort kernels + fps_bucket_kernel (stage-0 farthest point sampling: Sort-Tile-Recursive packing, then the sampling rounds)",
                          "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK / 1e9), 6), "traffic": pmc_traffic_bytes(F),
-                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                           "kernel pair at this batch size, committed; not re-measured in this run)",
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of these "
+                                           "kernels at this batch size, committed; not re-measured in this run)",
                          "avg_launch_ms": round(fps_ms, 4), "algorithmic_bytes_per_launch": alg,
                          "whole_path_frac": round(value / world * B_ALG_FRAME / HBM_PEAK, 6),
                          "us_per_round": round(fps_ms * 1e3 / (cfg.encoder.npoint[0] - 1), 3),

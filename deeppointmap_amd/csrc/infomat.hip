@@ -53,18 +53,31 @@ __device__ __forceinline__ long long *pair_partial(const PairArgs &a, int p) {
     return (long long *)(pair_sorted(a, p) + a.N2);
 }
 
-__global__ __launch_bounds__(1024) void grid_setup_kernel(PairArgs A, float radius, int fine) {
-    const int pair = blockIdx.x;
+// Bounds of the target scan in chunks of GB_CHUNK points (a 1024-thread workgroup per scan walked it alone: 41 us, and 71 us
+// between the other stages' workgroups, where sixteen waves wait for half a compute unit to fall free), then the header.
+constexpr int GB_CHUNK = 4096;  // points per workgroup of the chunk passes (16 per thread)
+
+__device__ __forceinline__ float *pair_bounds(const PairArgs &a, int p);  // [chunks][8], defined with the build's scratch below
+
+__global__ __launch_bounds__(256) void grid_bounds_kernel(PairArgs A) {
+    const int chunk = blockIdx.x, pair = blockIdx.y, chunks = gridDim.x;
     const float *p2 = pair_p2(A, pair);
     const int N2 = A.N2;
-    GridHdr *hdr = pair_hdr(A, pair);
-    __shared__ float red[5][16];
+    __shared__ float red[5][4];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     float lox = __builtin_inff(), loy = lox, hix = -lox, hiy = -lox, amax = 0.f;
-    for (int i = t; i < N2; i += 1024) {
-        const float x = p2[i], y = p2[(size_t)N2 + i], z = p2[2 * (size_t)N2 + i];
-        lox = fminf(lox, x), hix = fmaxf(hix, x), loy = fminf(loy, y), hiy = fmaxf(hiy, y);
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)));
+    constexpr int PPT = GB_CHUNK / 256;
+    const int i0 = chunk * GB_CHUNK + t;
+    float xs[PPT], ys[PPT], zs[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {  // clamped duplicates change neither a minimum nor a maximum
+        const int i = min(i0 + u * 256, N2 - 1);
+        xs[u] = p2[i], ys[u] = p2[(size_t)N2 + i], zs[u] = p2[2 * (size_t)N2 + i];
+    }
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        lox = fminf(lox, xs[u]), hix = fmaxf(hix, xs[u]), loy = fminf(loy, ys[u]), hiy = fmaxf(hiy, ys[u]);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(xs[u]), fabsf(ys[u])), fabsf(zs[u])));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -75,10 +88,27 @@ __global__ __launch_bounds__(1024) void grid_setup_kernel(PairArgs A, float radi
     if (lane == 0) red[0][w] = lox, red[1][w] = loy, red[2][w] = hix, red[3][w] = hiy, red[4][w] = amax;
     __syncthreads();
     if (t == 0) {
-        for (int k = 1; k < 16; ++k) {
+        for (int k = 1; k < 4; ++k) {
             lox = fminf(lox, red[0][k]), loy = fminf(loy, red[1][k]);
             hix = fmaxf(hix, red[2][k]), hiy = fmaxf(hiy, red[3][k]);
             amax = fmaxf(amax, red[4][k]);
+        }
+        float *o = pair_bounds(A, pair) + (size_t)chunk * 8;
+        o[0] = lox, o[1] = loy, o[2] = hix, o[3] = hiy, o[4] = amax;
+        (void)chunks;
+    }
+}
+
+__global__ __launch_bounds__(64) void grid_setup_kernel(PairArgs A, float radius, int fine, int chunks) {
+    const int pair = blockIdx.x;
+    GridHdr *hdr = pair_hdr(A, pair);
+    if (threadIdx.x == 0) {
+        float lox = __builtin_inff(), loy = lox, hix = -lox, hiy = -lox, amax = 0.f;
+        const float *o = pair_bounds(A, pair);
+        for (int k = 0; k < chunks; ++k, o += 8) {
+            lox = fminf(lox, o[0]), loy = fminf(loy, o[1]);
+            hix = fmaxf(hix, o[2]), hiy = fmaxf(hiy, o[3]);
+            amax = fmaxf(amax, o[4]);
         }
         const float ext = fmaxf(fmaxf(hix - lox, hiy - loy), 1e-6f);
         // cell edge = half the radius (5x5 cells cover it: a scan's nearest neighbour is a fraction of the radius away, and
@@ -133,14 +163,15 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float inv_cs, int g
 //            final array, plus the row's cell start offsets.
 // The order of the points inside a cell depends on scheduling (LDS atomics); nothing downstream depends on it: the search
 // takes the minimum of (distance, original index) keys and sums integers.
-constexpr int GB_CHUNK = 4096;  // points per workgroup of the row passes (16 per thread)
-
 __device__ __forceinline__ float4 *pair_tmp(const PairArgs &a, int p) {
     return (float4 *)(pair_partial(a, p) + 10 * (size_t)((a.N1 + 255) / 256));
 }
 __device__ __forceinline__ int *pair_rowhist(const PairArgs &a, int p) { return (int *)(pair_tmp(a, p) + a.N2); }  // [chunks][GMAX]
 __device__ __forceinline__ int *pair_rowstart(const PairArgs &a, int p) {                                           // [GMAX + 1]
     return pair_rowhist(a, p) + (size_t)((a.N2 + GB_CHUNK - 1) / GB_CHUNK) * GMAX;
+}
+__device__ __forceinline__ float *pair_bounds(const PairArgs &a, int p) {                                        // [chunks][8]
+    return (float *)(pair_rowstart(a, p) + GMAX + 4);
 }
 
 // PLACE = false: row histogram of the chunk; PLACE = true: the chunk's points into their rows' ranges of `tmp`
@@ -480,7 +511,7 @@ __global__ __launch_bounds__(64) void infomat_finalize_kernel(PairArgs A) {
 static size_t ws_slice_bytes(int N1, int N2) {
     size_t b = 256 + sizeof(int) * (size_t)(GMAX * GMAX + 1) + 12 + sizeof(float4) * (size_t)N2 +
                10 * sizeof(long long) * (size_t)dpm_cdiv(N1, 256) +
-               sizeof(float4) * (size_t)N2 + sizeof(int) * ((size_t)dpm_cdiv(N2, GB_CHUNK) * GMAX + GMAX + 4);  // row-sorted copy, row histograms, row starts
+               sizeof(float4) * (size_t)N2 + sizeof(int) * ((size_t)dpm_cdiv(N2, GB_CHUNK) * (GMAX + 8) + GMAX + 4);  // row-sorted copy, row histograms, row starts, chunk bounds
     return (b + 255) & ~(size_t)255;
 }
 
@@ -490,9 +521,10 @@ extern "C" size_t dpm_infomat_workspace_bytes(int n_pairs, int N1, int N2) {
 
 static int launch_grid(PairArgs A, int n_pairs, double radius, hipStream_t st) {
     const char *fine = getenv("DPM_NN1_FINE");  // 0: cells of one radius and 3x3 blocks (the round-2 layout; A/B measurements)
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(n_pairs), dim3(1024), 0, st, A, (float)radius, fine ? atoi(fine) : 1);
-    if (getenv("DPM_ABLATE_GRID")) return dpm_launch_status();  // timing experiments only (with DPM_ABLATE_NN1: nothing reads the grid)
     const int chunks = dpm_cdiv(A.N2, GB_CHUNK);
+    hipLaunchKernelGGL(grid_bounds_kernel, dim3(chunks, n_pairs), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(n_pairs), dim3(64), 0, st, A, (float)radius, fine ? atoi(fine) : 1, chunks);
+    if (getenv("DPM_ABLATE_GRID")) return dpm_launch_status();  // timing experiments only (with DPM_ABLATE_NN1: nothing reads the grid)
     hipLaunchKernelGGL(grid_rows_kernel<false>, dim3(chunks, n_pairs), dim3(256), 0, st, A);
     hipLaunchKernelGGL(grid_offsets_kernel, dim3(n_pairs), dim3(256), 0, st, A);
     hipLaunchKernelGGL(grid_rows_kernel<true>, dim3(chunks, n_pairs), dim3(256), 0, st, A);
