@@ -236,7 +236,10 @@ __global__ __launch_bounds__(SB) void fps_tree_sort_kernel(const float *__restri
 // (the frame sorted by x bin, as above), then one workgroup per SLAB for the y sort into leaves.  Which points share a
 // leaf depends on the arbitrary order inside an x bin, as it did before; no sampling result depends on it.
 // ------------------------------------------------------------------------------------------
-constexpr int SC_CHUNK = 8192, SC_T = 256;
+#ifndef DPM_SC_CHUNK
+#define DPM_SC_CHUNK 8192
+#endif
+constexpr int SC_CHUNK = DPM_SC_CHUNK, SC_T = 256;
 
 struct StrAux {       // per frame, behind the sort's scratch array
     float *part;      // [chunks][4]: lox, loy, hix, hiy of the chunk

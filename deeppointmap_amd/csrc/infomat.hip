@@ -272,8 +272,17 @@ __global__ __launch_bounds__(256) void grid_cells_kernel(PairArgs A) {
     const int lo = rowstart[row], hi = rowstart[row + 1];
     int *c = cnt[w];
     for (int k = lane; k < gx; k += 64) c[k] = 0;
+    // the row's first RB * 64 points are fetched together and stay in registers for both passes (a typical row holds a few
+    // hundred points: one round trip instead of a dozen dependent ones); longer rows loop over the rest
+    constexpr int RB = 8;
+    float4 v[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) v[u] = tmp[min(lo + lane + u * 64, max(hi, 1) - 1)];  // clamped: an empty row reads a neighbour's point and drops it
     __builtin_amdgcn_wave_barrier();
-    for (int p = lo + lane; p < hi; p += 64) atomicAdd(&c[cell_coord(tmp[p].x, lox, inv_cs, gx)], 1);
+#pragma unroll
+    for (int u = 0; u < RB; ++u)
+        if (lo + lane + u * 64 < hi) atomicAdd(&c[cell_coord(v[u].x, lox, inv_cs, gx)], 1);
+    for (int p = lo + lane + RB * 64; p < hi; p += 64) atomicAdd(&c[cell_coord(tmp[p].x, lox, inv_cs, gx)], 1);
     __builtin_amdgcn_wave_barrier();
     // exclusive scan over the row's gx counters: lane l owns cells [l * per, (l + 1) * per)
     const int per = (gx + 63) / 64, a = min(lane * per, gx), b = min(a + per, gx);
@@ -294,9 +303,12 @@ __global__ __launch_bounds__(256) void grid_cells_kernel(PairArgs A) {
     for (int k = lane; k < gx; k += 64) start[(size_t)row * gx + k] = c[k];  // cursors still at the cell starts
     if (row == gy - 1 && lane == 0) start[(size_t)gy * gx] = A.N2;
     __builtin_amdgcn_wave_barrier();
-    for (int p = lo + lane; p < hi; p += 64) {
-        const float4 v = tmp[p];
-        sorted[atomicAdd(&c[cell_coord(v.x, lox, inv_cs, gx)], 1)] = v;
+#pragma unroll
+    for (int u = 0; u < RB; ++u)
+        if (lo + lane + u * 64 < hi) sorted[atomicAdd(&c[cell_coord(v[u].x, lox, inv_cs, gx)], 1)] = v[u];
+    for (int p = lo + lane + RB * 64; p < hi; p += 64) {
+        const float4 q = tmp[p];
+        sorted[atomicAdd(&c[cell_coord(q.x, lox, inv_cs, gx)], 1)] = q;
     }
 }
 
