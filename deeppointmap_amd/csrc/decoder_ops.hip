@@ -89,7 +89,15 @@ __device__ __forceinline__ float rows4_sum(float v) {
 // range's UNNORMALISED output rows (relative to its own running max) into part_o (nsplit, B, M, heads*HD) and
 // (max, sum) into part_ml (nsplit, B, heads, M, 2); attention_merge_kernel rescales and adds the ranges.
 template <bool VEC, int QT, bool MASK = false, bool SPLIT = false>
-__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
+#ifndef DPM_ATT_WAVES
+#define DPM_ATT_WAVES 0
+#endif
+#if DPM_ATT_WAVES
+#define DPM_ATT_OCC __attribute__((amdgpu_waves_per_eu(DPM_ATT_WAVES, DPM_ATT_WAVES)))
+#else
+#define DPM_ATT_OCC
+#endif
+__global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
                                                         const float *__restrict__ Kp, int ldk, long long sk,
                                                         const float *__restrict__ V, int ldv, long long sv,
                                                         float *__restrict__ O, int ldo, long long so, int M,
