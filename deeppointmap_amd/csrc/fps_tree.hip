@@ -1,27 +1,15 @@
-// Farthest point sampling, TREE algorithm (N up to 65536): one WAVE per frame, no workgroup barrier in the round loop.
-// Replaces Sampler.fps / pytorch3d.sample_farthest_points (reference network/encoder/utils.py:210-285) with the
-// bit-exact contract of fps.hip: d = (dx*dx + dy*dy) + dz*dz without fused multiply-add, closest = min(d, closest),
-// next pick = FIRST index attaining the maximum.
+// Sort-Tile-Recursive packing of a frame for the bucket kernel of fps.hip (farthest point sampling, N up to 65 536;
+// replaces Sampler.fps / pytorch3d.sample_farthest_points, reference network/encoder/utils.py:210-285, together with it).
 //
 // Geometry.  The valid points of a frame are packed Sort-Tile-Recursive style: a counting sort by x (4096 bins)
 // cut BY POSITION into <= 32 slabs of whole leaves, then every slab counting-sorted by y (512 bins) and cut by
 // position into leaves of 64 points (= one wave-wide float4 load).  Leaves are addressed node-major: a node is a
-// 4 x 4 block of (slab, tile) leaves, 64 nodes of 16 leaves.  Compared with Z-ordered grid cells cut into runs,
+// 4 x 4 block of (slab, tile) leaves, 64 nodes of 16 leaves -- bucket b of the sampling kernel is owned by wave b % 16, so
+// the 16 neighbours of a block land on 16 different waves.  Compared with Z-ordered grid cells cut into runs,
 // leaves are compact rectangles adapted to the point density: 6.5 instead of 10.8 leaves survive the pruning test
 // of a round on the benchmark scans (the order inside a bin is arbitrary; no result depends on it).
-//
-// A round, for the one wave that owns the frame:
-//   select : lane n holds node n's box and max(closest) in registers -> DPP wave max -> the winning node's 16 leaf
-//            maxima (LDS) -> the leaf's recorded best point (LDS: x, y, z, position).  Ties anywhere fall into an
-//            exact slow path that compares ORIGINAL indices (the first-index rule).
-//   apply  : box test of the 64 nodes (same fp32 expression as the point distance; every operation is monotone, so
-//            box distance <= point distance and the pruning is exact), then the 16 leaf boxes of up to four surviving
-//            nodes at once (lane group g tests node g's children), then ALL surviving leaves are requested from
-//            memory before the first is evaluated (one round trip per round): distance, conditional store of the
-//            new closest value, DPP arg-max, leaf record back to LDS, node maxima patched into their owner lanes.
-// ~350 wave-instructions per pick instead of ~1900 (16 waves x 117) for the barrier-synchronised bucket kernel at
-// about the same latency per round, so the sampling chain of a whole batch costs the chip's other kernels a sixth of
-// the issue slots; `NW` > 1 is reserved for a latency-mode variant.
+// Rounds 1-2 also carried a one-wave-per-frame TREE sampling kernel over this packing (removed in round 3: exact, slower)
+// and, until the end of round 3, the packing as ONE 1024-thread workgroup per frame (git history: "FPS packing: ...").
 #include "fps_util.h"
 
 #pragma clang fp contract(off)
@@ -33,33 +21,6 @@ constexpr int LEAF = 64;      // points per leaf
 constexpr int XB = 4096;      // x bins of the first counting sort
 constexpr int YB = 512;       // y bins per slab of the second
 constexpr int MAXSLAB = 32;
-constexpr int SB = 1024;      // threads of the sort workgroup
-
-// per-frame workspace (bytes)
-constexpr size_t WS_PTS = (size_t)TL * LEAF * sizeof(float4);   // (x, y, z, closest); closest = -1 in unused slots
-constexpr size_t WS_ORIG = (size_t)TL * LEAF * sizeof(int32_t); // original index of every slot
-constexpr size_t WS_META = (size_t)TL * (6 + 1 + 4) * sizeof(float);  // leaf boxes (SoA) | leaf max | leaf best (float4)
-__host__ __device__ inline size_t ws_frame_bytes(int N) { return WS_PTS + WS_ORIG + WS_META + (size_t)N * sizeof(float4); }
-
-struct FrameWs {
-    float4 *pts;
-    int32_t *orig;
-    float *box;    // [6][TL]
-    float *lmax;   // [TL]
-    float4 *best;  // [TL]
-    float4 *tmp;   // [N] scratch of the sort
-};
-__device__ __forceinline__ FrameWs frame_ws(char *ws, int b, int N) {
-    char *p = ws + (size_t)b * ws_frame_bytes(N);
-    FrameWs f;
-    f.pts = (float4 *)p;
-    f.orig = (int32_t *)(p + WS_PTS);
-    f.box = (float *)(p + WS_PTS + WS_ORIG);
-    f.lmax = f.box + 6 * TL;
-    f.best = (float4 *)(f.lmax + TL);
-    f.tmp = (float4 *)(p + WS_PTS + WS_ORIG + WS_META);
-    return f;
-}
 
 // slab / tile geometry of a frame with `len` valid points
 __device__ __forceinline__ void str_shape(int len, int &nsx, int &lps) {
@@ -71,167 +32,11 @@ __device__ __forceinline__ void str_shape(int len, int &nsx, int &lps) {
 }
 
 // ------------------------------------------------------------------------------------------
-// sort: Sort-Tile-Recursive packing of one frame per workgroup
-// ------------------------------------------------------------------------------------------
-// BUCKETS = true writes the layout of fps.hip's bucket kernel instead (algo 5): points (x, y, z, original index) +
-// a separate `closest` array (+inf; -1 in unused slots, whose index field is INT_MAX), TL * LEAF slots per frame.
-template <bool BUCKETS>
-__global__ __launch_bounds__(SB) void fps_tree_sort_kernel(const float *__restrict__ xyz_all,
-                                                           const int32_t *__restrict__ lengths, int N, char *ws,
-                                                           float4 *__restrict__ bpts_all, float *__restrict__ bclosest_all,
-                                                           float4 *__restrict__ btmp_all) {
-    __shared__ int s_hist[MAXSLAB * YB];  // 64 KB; the x pass uses the first XB counters
-    __shared__ float s_red[4][SB / 64];
-    __shared__ int s_wsum[SB / 64];
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const float *xyz = xyz_all + (size_t)b * N * 3;
-    FrameWs f;
-    float *bclosest = nullptr;
-    if (BUCKETS) {
-        f.pts = bpts_all + (size_t)b * TL * LEAF, f.tmp = btmp_all + (size_t)b * N, bclosest = bclosest_all + (size_t)b * TL * LEAF;
-        f.orig = nullptr, f.box = f.lmax = nullptr, f.best = nullptr;
-    } else {
-        f = frame_ws(ws, b, N);
-    }
-    const int len = min(max(lengths[b], 0), N);
-    if (len == 0 && !BUCKETS) return;
-    for (int i = t; i < TL * LEAF; i += SB) {
-        f.pts[i] = make_float4(0.f, 0.f, 0.f, BUCKETS ? __int_as_float(0x7fffffff) : -1.f);
-        if (BUCKETS) bclosest[i] = -1.f;
-    }
-    if (len == 0) return;
-
-    float lox = __builtin_inff(), loy = __builtin_inff(), hix = -__builtin_inff(), hiy = -__builtin_inff();
-    // every pass fetches UB elements per thread before it uses the first (unconditional loads from clamped positions):
-    // 64 dependent round trips per thread and pass otherwise -- five passes of them made this kernel a latency chain
-    constexpr int UB = 8;
-    auto for_points = [&](auto &&fn) {   // fn(original index, x, y, z)
-        for (int i0 = t; i0 < len; i0 += SB * UB) {
-            float xs[UB], ys[UB], zs[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int i = min(i0 + u * SB, len - 1);
-                xs[u] = xyz[3 * i], ys[u] = xyz[3 * i + 1], zs[u] = xyz[3 * i + 2];
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u)
-                if (i0 + u * SB < len) fn(i0 + u * SB, xs[u], ys[u], zs[u]);
-        }
-    };
-    auto for_sorted = [&](auto &&fn) {   // fn(position, element of the x-sorted array)
-        for (int p0 = t; p0 < len; p0 += SB * UB) {
-            float4 e[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) e[u] = f.tmp[min(p0 + u * SB, len - 1)];
-#pragma unroll
-            for (int u = 0; u < UB; ++u)
-                if (p0 + u * SB < len) fn(p0 + u * SB, e[u]);
-        }
-    };
-    for_points([&](int, float x, float y, float) {
-        lox = fminf(lox, x), hix = fmaxf(hix, x), loy = fminf(loy, y), hiy = fmaxf(hiy, y);
-    });
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        lox = fminf(lox, __shfl_xor(lox, off, 64));
-        loy = fminf(loy, __shfl_xor(loy, off, 64));
-        hix = fmaxf(hix, __shfl_xor(hix, off, 64));
-        hiy = fmaxf(hiy, __shfl_xor(hiy, off, 64));
-    }
-    if (lane == 0) s_red[0][w] = lox, s_red[1][w] = loy, s_red[2][w] = hix, s_red[3][w] = hiy;
-    for (int c = t; c < XB; c += SB) s_hist[c] = 0;
-    __syncthreads();
-    for (int k = 0; k < SB / 64; ++k) {
-        lox = fminf(lox, s_red[0][k]), loy = fminf(loy, s_red[1][k]);
-        hix = fmaxf(hix, s_red[2][k]), hiy = fmaxf(hiy, s_red[3][k]);
-    }
-    const float sxc = (hix > lox) ? (float)XB / (hix - lox) : 0.f;
-    const float syc = (hiy > loy) ? (float)YB / (hiy - loy) : 0.f;
-    auto xbin = [&](float x) { return min(max((int)((x - lox) * sxc), 0), XB - 1); };
-    auto ybin = [&](float y) { return min(max((int)((y - loy) * syc), 0), YB - 1); };
-
-    // ---- pass 1: counting sort by x bin into tmp (x, y, z, original index)
-    for_points([&](int, float x, float, float) { atomicAdd(&s_hist[xbin(x)], 1); });
-    __syncthreads();
-    {
-        const int c0 = s_hist[4 * t], c1 = s_hist[4 * t + 1], c2 = s_hist[4 * t + 2], c3 = s_hist[4 * t + 3];
-        const int tsum = c0 + c1 + c2 + c3;
-        int inc = tsum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += o;
-        }
-        if (lane == 63) s_wsum[w] = inc;
-        __syncthreads();
-        int base = 0;
-        for (int k = 0; k < w; ++k) base += s_wsum[k];
-        const int excl = base + inc - tsum;
-        s_hist[4 * t] = excl;
-        s_hist[4 * t + 1] = excl + c0;
-        s_hist[4 * t + 2] = excl + c0 + c1;
-        s_hist[4 * t + 3] = excl + c0 + c1 + c2;
-    }
-    __syncthreads();
-    for_points([&](int i, float x, float y, float z) {
-        const int pos = atomicAdd(&s_hist[xbin(x)], 1);
-        f.tmp[pos] = make_float4(x, y, z, __int_as_float(i));
-    });
-    __threadfence_block();
-    __syncthreads();
-
-    // ---- pass 2: every slab (a run of lps * 64 consecutive positions) counting-sorted by y bin; a leaf is a run of
-    //      64 positions inside its slab
-    int nsx, lps;
-    str_shape(len, nsx, lps);
-    const int slab_pts = lps * LEAF;
-    for (int c = t; c < nsx * YB; c += SB) s_hist[c] = 0;
-    __syncthreads();
-    for_sorted([&](int pos, const float4 e) { atomicAdd(&s_hist[(pos / slab_pts) * YB + ybin(e.y)], 1); });
-    __syncthreads();
-    {
-        // 32 threads per slab, 16 bins each; exclusive scan inside the slab
-        const int slab = t >> 5, sub = t & 31;
-        int c[16], tsum = 0;
-        if (slab < nsx) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) c[k] = s_hist[slab * YB + sub * 16 + k], tsum += c[k];
-        }
-        int inc = tsum;
-#pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const int o = __shfl_up(inc, off, 32);
-            if (sub >= off) inc += o;
-        }
-        if (slab < nsx) {
-            int run = inc - tsum;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) s_hist[slab * YB + sub * 16 + k] = run, run += c[k];
-        }
-    }
-    __syncthreads();
-    const float s0x = xyz[0], s0y = xyz[1], s0z = xyz[2];  // the first pick is index 0 (utils.py:249-250)
-    for_sorted([&](int pos, const float4 p) {
-        const int slab = pos / slab_pts;
-        const int j = atomicAdd(&s_hist[slab * YB + ybin(p.y)], 1);
-        const int tile = j >> 6;
-        const int leaf = (((slab >> 2) * 8 + (tile >> 2)) << 4) + ((slab & 3) << 2) + (tile & 3);
-        const int q = leaf * LEAF + (j & 63);
-        if (BUCKETS) {
-            f.pts[q] = p;  // (x, y, z, original index)
-            bclosest[q] = __builtin_inff();
-        } else {
-            // closest distance after the first pick: min(+inf, d) = d
-            f.pts[q] = make_float4(p.x, p.y, p.z, sqdist(s0x, s0y, s0z, p.x, p.y, p.z));
-            f.orig[q] = __float_as_int(p.w);
-        }
-    });
-}
-
-// ------------------------------------------------------------------------------------------
-// The same packing (BUCKETS layout) as FIVE short chip-wide kernels (round 3).  The one-workgroup-per-frame kernel above
-// holds 64 compute units with 1024 threads and 64 KB of LDS each for 0.26 ms (0.34 ms under load) per batch; run twice per
-// batch it lengthened the pipelined step by 0.19 ms -- it costs the other stages almost its whole duration.  Here a frame's
+// The packing as FIVE short chip-wide kernels.  As one 1024-thread workgroup per frame (rounds 2-3) it held 64 compute
+// units with 64 KB of LDS each for 0.26 ms (0.34 ms under load) per batch; run twice per batch it lengthened the pipelined
+// step by 0.19 ms -- such a kernel costs the other stages almost its whole duration.  Output layout (the bucket kernel's):
+// points (x, y, z, original index) + a separate `closest` array (+inf; -1 in unused slots, whose index field is INT_MAX),
+// TL * LEAF slots per frame.  Here a frame's
 // points are cut into chunks of SC_CHUNK: bounds per chunk, x histogram per chunk, offsets per frame, scatter per chunk
 // (the frame sorted by x bin, as above), then one workgroup per SLAB for the y sort into leaves.  Which points share a
 // leaf depends on the arbitrary order inside an x bin, as it did before; no sampling result depends on it.
@@ -442,15 +247,10 @@ size_t dpm_fps_str_bucket_workspace_bytes(int B, int N) {
 int dpm_fps_str_bucket_sort(const float *xyz, const int32_t *lengths, int B, int N, float4 *pts, float *closest, float4 *tmp,
                             hipStream_t st) {
     if (N > TL * LEAF) return DPM_EUNSUPPORTED;
-    const char *one = getenv("DPM_FPS_SORT_ONE_WG");  // 1: the one-workgroup-per-frame kernel (A/B measurements)
     const char *pr = getenv("DPM_PRICE_FPS_SORT");   // the (idempotent) sort n more times: its price inside the pipelined step
     char *aux = (char *)(((uintptr_t)(tmp + (size_t)B * N) + 255) & ~(uintptr_t)255);
     const int chunks = (N + SC_CHUNK - 1) / SC_CHUNK;
     for (int rep = 0; rep <= (pr ? atoi(pr) : 0); ++rep) {
-        if (one && atoi(one)) {
-            hipLaunchKernelGGL(fps_tree_sort_kernel<true>, dim3(B), dim3(SB), 0, st, xyz, lengths, N, (char *)nullptr, pts, closest, tmp);
-            continue;
-        }
         hipLaunchKernelGGL(str_chunk_kernel<0>, dim3(chunks, B), dim3(SC_T), 0, st, xyz, lengths, N, pts, closest, tmp, aux);
         hipLaunchKernelGGL(str_chunk_kernel<1>, dim3(chunks, B), dim3(SC_T), 0, st, xyz, lengths, N, pts, closest, tmp, aux);
         hipLaunchKernelGGL(str_xoffsets_kernel, dim3(B), dim3(1024), 0, st, lengths, N, aux);
