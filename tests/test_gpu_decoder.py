@@ -57,6 +57,16 @@ def test_attention_core_vs_torch(ops):
     two = torch.cat([ops.attention(qkv[:R, :256], qkv[R:, 256:512], qkv[R:, 512:], B // 2, M, M, 8),
                      ops.attention(qkv[R:, :256], qkv[:R, 256:512], qkv[:R, 512:], B // 2, M, M, 8)])
     assert torch.equal(one, two)
+    # seq_index: the batch elements are drawn from a smaller set of stored sequences (dpm_attention_indexed) -- equal to the
+    # shifted form over the gathered rows, bit for bit, in both wave layouts (16 and 32 queries per wave)
+    for U, M, B in ((5, 128, 8), (33, 256, 64)):
+        store = torch.randn(U * M, 768, generator=gen).to(DEV)
+        seq = torch.randint(0, U, (B,), generator=gen, dtype=torch.int32).to(DEV)
+        rows = (seq.long()[:, None] * M + torch.arange(M, device=DEV)[None, :]).reshape(-1)
+        gathered = store[rows].contiguous()
+        want = ops.attention(gathered[:, :256], gathered[:, 256:512], gathered[:, 512:], B, M, M, 8, kv_shift=B // 2)
+        got = ops.attention(store[:, :256], store[:, 256:512], store[:, 512:], B, M, M, 8, kv_shift=B // 2, seq_index=seq)
+        assert torch.equal(got, want), (U, M, B)
 
 
 def test_attention_key_split_vs_torch(ops):
