@@ -146,19 +146,28 @@ __global__ __launch_bounds__(SC_T) void str_chunk_kernel(const float *__restrict
     }
 }
 
-// x histograms [chunk][bin] -> start offset of every (chunk, bin) run in the x-sorted array, in place
-__global__ __launch_bounds__(1024) void str_xoffsets_kernel(const int32_t *__restrict__ lengths, int N, char *__restrict__ aux) {
+// x histograms [chunk][bin] -> start offset of every (chunk, bin) run in the x-sorted array, in place.  256 threads of 16
+// bins each: a 16-wave workgroup waits for half a compute unit to fall free inside the pipeline (5 us alone, 38 us there).
+__global__ __launch_bounds__(256) void str_xoffsets_kernel(const int32_t *__restrict__ lengths, int N, char *__restrict__ aux) {
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int len = min(max(lengths[b], 0), N), chunks = (len + SC_CHUNK - 1) / SC_CHUNK;
     if (chunks == 0) return;
     const StrAux A = str_aux(aux, b, N);
-    __shared__ int s_wsum[16];
-    int tot[4] = {0, 0, 0, 0};  // thread t owns bins 4t .. 4t + 3 (XB = 4 * 1024)
+    __shared__ int s_wsum[4];
+    constexpr int PER = XB / 256;  // bins per thread (16), as int4 groups
+    int tot[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) tot[k] = 0;
     for (int c = 0; c < chunks; ++c) {
-        const int4 h = *reinterpret_cast<const int4 *>(A.xhist + (size_t)c * XB + 4 * t);
-        tot[0] += h.x, tot[1] += h.y, tot[2] += h.z, tot[3] += h.w;
+#pragma unroll
+        for (int g = 0; g < PER / 4; ++g) {
+            const int4 h = *reinterpret_cast<const int4 *>(A.xhist + (size_t)c * XB + PER * t + 4 * g);
+            tot[4 * g] += h.x, tot[4 * g + 1] += h.y, tot[4 * g + 2] += h.z, tot[4 * g + 3] += h.w;
+        }
     }
-    const int tsum = tot[0] + tot[1] + tot[2] + tot[3];
+    int tsum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) tsum += tot[k];
     int inc = tsum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -169,12 +178,17 @@ __global__ __launch_bounds__(1024) void str_xoffsets_kernel(const int32_t *__res
     __syncthreads();
     int base = inc - tsum;
     for (int k = 0; k < w; ++k) base += s_wsum[k];
-    int at[4] = {base, base + tot[0], base + tot[0] + tot[1], base + tot[0] + tot[1] + tot[2]};
+    int at[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) at[k] = base, base += tot[k];
     for (int c = 0; c < chunks; ++c) {
-        int4 *hp = reinterpret_cast<int4 *>(A.xhist + (size_t)c * XB + 4 * t);
-        const int4 h = *hp;
-        *hp = make_int4(at[0], at[1], at[2], at[3]);
-        at[0] += h.x, at[1] += h.y, at[2] += h.z, at[3] += h.w;
+#pragma unroll
+        for (int g = 0; g < PER / 4; ++g) {
+            int4 *hp = reinterpret_cast<int4 *>(A.xhist + (size_t)c * XB + PER * t + 4 * g);
+            const int4 h = *hp;
+            *hp = make_int4(at[4 * g], at[4 * g + 1], at[4 * g + 2], at[4 * g + 3]);
+            at[4 * g] += h.x, at[4 * g + 1] += h.y, at[4 * g + 2] += h.z, at[4 * g + 3] += h.w;
+        }
     }
 }
 
@@ -253,7 +267,7 @@ int dpm_fps_str_bucket_sort(const float *xyz, const int32_t *lengths, int B, int
     for (int rep = 0; rep <= (pr ? atoi(pr) : 0); ++rep) {
         hipLaunchKernelGGL(str_chunk_kernel<0>, dim3(chunks, B), dim3(SC_T), 0, st, xyz, lengths, N, pts, closest, tmp, aux);
         hipLaunchKernelGGL(str_chunk_kernel<1>, dim3(chunks, B), dim3(SC_T), 0, st, xyz, lengths, N, pts, closest, tmp, aux);
-        hipLaunchKernelGGL(str_xoffsets_kernel, dim3(B), dim3(1024), 0, st, lengths, N, aux);
+        hipLaunchKernelGGL(str_xoffsets_kernel, dim3(B), dim3(256), 0, st, lengths, N, aux);
         hipLaunchKernelGGL(str_chunk_kernel<2>, dim3(chunks, B), dim3(SC_T), 0, st, xyz, lengths, N, pts, closest, tmp, aux);
         hipLaunchKernelGGL(str_ysort_kernel, dim3(MAXSLAB, B), dim3(SC_T), 0, st, lengths, N, pts, closest, tmp, aux);
     }
