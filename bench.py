@@ -95,7 +95,24 @@ def main():
     ap.add_argument("--geometry-knn", type=int, default=None, help="1: neighbour queries run in the geometry stage, 0: in the feature stage")
     ap.add_argument("--feature-streams", type=int, default=None, help="feature-stage streams (pipeline tuning)")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time breakdown to stderr")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend for --gpus > 1; gloo (ranks folded onto the visible GPUs) exists only to dry-run "
+                         "the N>1 code path on a single-GPU box and is recorded in config.parallelism")
+    ap.add_argument("--allow-knobs", action="store_true",
+                    help="run although DPM_* variables are set / an experimental library is loaded (A/B measurements); they are "
+                         "recorded under config.knobs and the line is not a headline number")
     args = ap.parse_args()
+
+    # Tamper evidence: the headline number comes from the shipped library and the shipped host settings or not at all.
+    # DPM_LIB swaps the library, the other DPM_* names are what an experimental build (-DDPM_EXPERIMENT) or
+    # deeppointmap_amd.knobs.apply_env() would read -- some of them skip work.
+    from deeppointmap_amd import knobs
+    env_knobs = knobs.env_knobs()
+    if env_knobs and not args.allow_knobs:
+        raise SystemExit("bench.py: refusing to run with measurement knobs in the environment (" + ", ".join(env_knobs) +
+                         "); unset them, or pass --allow-knobs to run an A/B measurement that records them in the JSON line")
+    if args.allow_knobs:
+        knobs.apply_env()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,9 +123,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    # one rank per GPU; DPM_BENCH_BACKEND=gloo (+ ranks folded onto the visible GPUs) exists only to dry-run the
-    # N>1 code path on a single-GPU box
-    backend = os.environ.get("DPM_BENCH_BACKEND", "nccl")
+    # one rank per GPU; --backend gloo (+ ranks folded onto the visible GPUs) exists only to dry-run the N>1 code path on a
+    # single-GPU box
+    backend = args.backend
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -120,7 +137,9 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    from deeppointmap_amd import ops, synthetic
+    from deeppointmap_amd import _lib, ops, synthetic
+    if _lib.experimental() and not args.allow_knobs:
+        raise SystemExit(f"bench.py: {_lib.LIB_PATH} is an experimental build (-DDPM_EXPERIMENT); refusing without --allow-knobs")
     from deeppointmap_amd.config import default_args
     from deeppointmap_amd.decoder import Decoder
     from deeppointmap_amd.encoder import Encoder
@@ -363,8 +382,15 @@ def main():
                                                 "loop_detection_batches_per_step": (cons.stats["loop_batches"] - before["loop_batches"]) / 2,
                                                 "registrations_on_rank0_per_step": (cons.stats["re_registrations"] - before["re_registrations"]) / 2,
                                                 "pose_graph_optimisations": cons.stats["optimisations"],
+                                                "synthetic_rows": True,
                                                 "note": "sequential SLAM work that stays on rank 0 (mapping.py:52-201, "
-                                                        "loop_closure.py:56-307); not part of `value`"}
+                                                        "loop_closure.py:56-307); not part of `value`.  The gathered edge rows "
+                                                        "are OVERWRITTEN with the synthetic sequence's true relative poses and a fixed "
+                                                        "rmse 0.15 / confidence 0.9 (procedural weights give meaningless "
+                                                        "registrations); under these rows every scan-to-map result is refused and no "
+                                                        "loop is proposed, so the figure prices the device calls and the gating of a "
+                                                        "loop-free drive, not a measured SLAM run; the same rows are consumed on every "
+                                                        "call (row 0 = the edge from the previous call's last frame)"}
                 except Exception as e:  # noqa: BLE001
                     extras["rank0_consumer_error"] = f"{type(e).__name__}: {e}"
             fence()
@@ -397,7 +423,8 @@ def main():
             "config": {"workload": f"synthetic {F}x{N}-pt scans per GPU: Encoder.forward + consecutive-frame "
                                    "registration_forward (256x256) + information matrix per frame",
                        "frames_per_gpu_per_step": F, "points_per_frame": N,
-                       "parallelism": f"frame-sharded x{world}, one RCCL gather of descriptors+edges per step",
+                       "parallelism": f"frame-sharded x{world}, one RCCL gather of descriptors+edges per step" +
+                                      ("" if backend == "nccl" or world == 1 else f" (DRY RUN over {backend}, ranks folded onto the visible GPUs)"),
                        "pipeline": "none" if args.no_pipeline else "HIP-stream pipeline: geometry (staging+FPS chain) of batches i, i-1 on two alternating streams | features of batch i-2 | registration+information matrices of batch i-3",
                        "weights": "procedural (deeppointmap_amd/weights.py)"},
             "roofline": {"kernel": "str_chunk/str_xoffsets/str_ysort kernels + fps_bucket_kernel (stage-0 farthest point sampling: Sort-Tile-Recursive packing, then the sampling rounds)",
@@ -420,6 +447,10 @@ def main():
             line["roofline"]["alone"] = {"launch_ms": round(alone["fps_ms"], 4),
                                          "us_per_round": round(alone["fps_ms"] * 1e3 / (cfg.encoder.npoint[0] - 1), 3),
                                          "frac": round(alg / (alone["fps_ms"] * 1e-3) / HBM_PEAK, 6)}
+        if args.allow_knobs:   # an A/B measurement, not a headline number: say what was different
+            line["config"]["knobs"] = dict(env_knobs, experimental_library=_lib.experimental(), library=_lib.LIB_PATH,
+                                           host={"FPS_ALGO": knobs.FPS_ALGO, "FUSED_LN": knobs.FUSED_LN,
+                                                 "DEDUP_FRAMES": knobs.DEDUP_FRAMES})
         line.update(extras)
         if "rank0_serial_ms" in extras:
             line["value_with_rank0_consumer"] = round(world * F / (dt / args.steps + extras["rank0_serial_ms"] * 1e-3), 1)

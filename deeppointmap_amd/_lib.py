@@ -13,7 +13,10 @@ import torch  # noqa: F401  -- must precede the CDLL below: libdpm_hip.so has to
 from ctypes import c_char_p, c_double, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DPM_LIB") or os.path.join(_HERE, "libdpm_hip.so")  # DPM_LIB: an experimental build (scripts/)
+# DPM_LIB (read once, at import): another build of the library for A/B measurements (csrc/build.py --out).  bench.py refuses
+# to run with it unless --allow-knobs is given; no entry point of the shipped library reads the environment.
+LIB_PATH = os.environ.get("DPM_LIB") or os.path.join(_HERE, "libdpm_hip.so")
+VERSION_EXPERIMENT = 0x40000000   # include/dpm_hip.h: DPM_VERSION_EXPERIMENT
 
 P, I, D, LL = c_void_p, c_int, c_double, c_longlong
 
@@ -102,8 +105,17 @@ def load() -> ctypes.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
+        if lib.dpm_version() & VERSION_EXPERIMENT:
+            import sys
+            print(f"deeppointmap_amd: {LIB_PATH} is an EXPERIMENTAL build (-DDPM_EXPERIMENT): its kernels read DPM_* "
+                  "measurement switches from the environment, some of which skip work -- not for results", file=sys.stderr)
         _lib = lib
     return _lib
+
+
+def experimental() -> bool:
+    """True when the loaded library was built with -DDPM_EXPERIMENT (measurement switches compiled in)."""
+    return bool(load().dpm_version() & VERSION_EXPERIMENT)
 
 
 def check(status: int, what: str) -> None:

@@ -191,6 +191,28 @@ class RankCommunicateModule:
                 else:
                     dist.send(t.cpu(), dst=self._global(callee), group=self.data)
 
+    def loopback(self, t: torch.Tensor) -> torch.Tensor:
+        """One tensor out through the data channel and back into this member: the send of `_send` and the receive of
+        `_receive_from` (owned receive buffer on `self.device`, the process's one RCCL lock, the stream synchronised before
+        the tensor is handed on) posted as ONE group, which is the only form in which a rank may talk to itself over RCCL.
+        It is how a single-GPU box executes the channel at all (tests/test_gpu_rccl.py); members never need it."""
+        t = t.detach().contiguous()
+        me = self._global(self.rank, self.data)
+        if self.data_is_nccl:
+            src = t if t.is_cuda else t.to(self.device)
+            got = torch.empty(src.shape, dtype=src.dtype, device=self.device)
+            with self._nccl_lock:
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, me, group=self.data),
+                                                   dist.P2POp(dist.irecv, got, me, group=self.data)]):
+                    req.wait()
+                torch.cuda.current_stream(self.device).synchronize()
+            return got if t.is_cuda else got.cpu()
+        got = torch.empty(t.shape, dtype=t.dtype)
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, t.cpu(), me, group=self.data),
+                                           dist.P2POp(dist.irecv, got, me, group=self.data)]):
+            req.wait()
+        return got.to(self.device) if t.is_cuda and self.device.type == "cuda" else got
+
     def _receive_from(self, peer: int) -> None:
         try:
             while True:

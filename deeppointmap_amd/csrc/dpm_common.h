@@ -19,6 +19,20 @@ static inline int dpm_launch_status() {
 
 static inline unsigned dpm_cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
+// Measurement switches (ablations that skip work, A/B layouts, "run it n more times" pricing).  The shipped library has
+// NONE: dpm_knob() folds to its default and no entry point reads the environment.  Only a library built with
+// -DDPM_EXPERIMENT (`csrc/build.py --out <lib> -DDPM_EXPERIMENT`, selected by scripts through DPM_LIB, which bench.py
+// refuses without --allow-knobs) looks the name up, and dpm_version() of such a build carries DPM_VERSION_EXPERIMENT.
+#ifdef DPM_EXPERIMENT
+#include <stdlib.h>
+static inline int dpm_knob(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+static inline constexpr int dpm_knob(const char *, int dflt) { return dflt; }
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -261,10 +261,10 @@ size_t dpm_fps_str_bucket_workspace_bytes(int B, int N) {
 int dpm_fps_str_bucket_sort(const float *xyz, const int32_t *lengths, int B, int N, float4 *pts, float *closest, float4 *tmp,
                             hipStream_t st) {
     if (N > TL * LEAF) return DPM_EUNSUPPORTED;
-    const char *pr = getenv("DPM_PRICE_FPS_SORT");   // the (idempotent) sort n more times: its price inside the pipelined step
+    const int extra = dpm_knob("DPM_PRICE_FPS_SORT", 0);   // -DDPM_EXPERIMENT builds only: the (idempotent) sort n more times = its price inside the pipelined step
     char *aux = (char *)(((uintptr_t)(tmp + (size_t)B * N) + 255) & ~(uintptr_t)255);
     const int chunks = (N + SC_CHUNK - 1) / SC_CHUNK;
-    for (int rep = 0; rep <= (pr ? atoi(pr) : 0); ++rep) {
+    for (int rep = 0; rep <= extra; ++rep) {
         hipLaunchKernelGGL(str_chunk_kernel<0>, dim3(chunks, B), dim3(SC_T), 0, st, xyz, lengths, N, pts, closest, tmp, aux);
         hipLaunchKernelGGL(str_chunk_kernel<1>, dim3(chunks, B), dim3(SC_T), 0, st, xyz, lengths, N, pts, closest, tmp, aux);
         hipLaunchKernelGGL(str_xoffsets_kernel, dim3(B), dim3(256), 0, st, lengths, N, aux);

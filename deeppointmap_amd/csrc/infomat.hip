@@ -532,11 +532,11 @@ extern "C" size_t dpm_infomat_workspace_bytes(int n_pairs, int N1, int N2) {
 }
 
 static int launch_grid(PairArgs A, int n_pairs, double radius, hipStream_t st) {
-    const char *fine = getenv("DPM_NN1_FINE");  // 0: cells of one radius and 3x3 blocks (the round-2 layout; A/B measurements)
+    const int fine = dpm_knob("DPM_NN1_FINE", 1);  // -DDPM_EXPERIMENT builds only; 0: cells of one radius and 3x3 blocks (the round-2 layout; A/B measurements)
     const int chunks = dpm_cdiv(A.N2, GB_CHUNK);
     hipLaunchKernelGGL(grid_bounds_kernel, dim3(chunks, n_pairs), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(n_pairs), dim3(64), 0, st, A, (float)radius, fine ? atoi(fine) : 1, chunks);
-    if (getenv("DPM_ABLATE_GRID")) return dpm_launch_status();  // timing experiments only (with DPM_ABLATE_NN1: nothing reads the grid)
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(n_pairs), dim3(64), 0, st, A, (float)radius, fine, chunks);
+    if (dpm_knob("DPM_ABLATE_GRID", 0)) return dpm_launch_status();  // -DDPM_EXPERIMENT builds only (with DPM_ABLATE_NN1: nothing reads the grid)
     hipLaunchKernelGGL(grid_rows_kernel<false>, dim3(chunks, n_pairs), dim3(256), 0, st, A);
     hipLaunchKernelGGL(grid_offsets_kernel, dim3(n_pairs), dim3(256), 0, st, A);
     hipLaunchKernelGGL(grid_rows_kernel<true>, dim3(chunks, n_pairs), dim3(256), 0, st, A);
@@ -545,10 +545,10 @@ static int launch_grid(PairArgs A, int n_pairs, double radius, hipStream_t st) {
 }
 
 static int launch_search(PairArgs A, int n_pairs, double radius, hipStream_t st) {
-    if (getenv("DPM_ABLATE_NN1")) return DPM_OK;  // timing experiments only
-    const char *ord = getenv("DPM_NN1_ORDERED");  // 0: queries in index order (A/B measurements)
+    if (dpm_knob("DPM_ABLATE_NN1", 0)) return DPM_OK;  // -DDPM_EXPERIMENT builds only
+    const int ord = dpm_knob("DPM_NN1_ORDERED", 1);  // -DDPM_EXPERIMENT builds only; 0: queries in index order (A/B measurements)
     hipLaunchKernelGGL(nn1_match_kernel, dim3(dpm_cdiv(A.N1, 256), n_pairs), dim3(256), 0, st, A,
-                       (float)(radius * radius), ord ? atoi(ord) : 1);
+                       (float)(radius * radius), ord);
     hipLaunchKernelGGL(infomat_finalize_kernel, dim3(n_pairs), dim3(64), 0, st, A);
     return dpm_launch_status();
 }

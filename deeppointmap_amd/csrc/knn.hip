@@ -1488,17 +1488,16 @@ void launch_grid_build(const float *points, const int32_t *lengths, int B, int N
     // cell edge > sqrt(r^2 + 2e-5 max(1, max |p|^2)): the expanded-form distance can undershoot the true one by ~1.5e-6 on
     // unit-ball coordinates and proportionally more on larger ones (the kernel knows the frame's extent)
     const float cs_min = (float)(sqrt(radius * radius + 2e-5) * 1.002);
-    // DPM_PRICE_KNN_BUILD=n: the (idempotent) build n more times -- what the kernel costs the pipelined step is the step's growth
-    const char *pr = getenv("DPM_PRICE_KNN_BUILD");
-    for (int rep = 0; rep <= (pr && N >= 16384 ? atoi(pr) : 0); ++rep)
+    // -DDPM_EXPERIMENT builds only, DPM_PRICE_KNN_BUILD=n: the (idempotent) build n more times -- what the kernel costs the
+    // pipelined step is the step's growth
+    const int extra = N >= 16384 ? dpm_knob("DPM_PRICE_KNN_BUILD", 0) : 0;
+    for (int rep = 0; rep <= extra; ++rep)
         hipLaunchKernelGGL(knn_grid_build_kernel, dim3(B), dim3(1024), 0, st, points, lengths, N, cs_min, (float)(radius * radius),
                            w.hdr, w.start, w.sorted, w.tie_count);
 }
-// DPM_KNN_FAST=0: every row through the one-wave-per-centre search (the round-2 path; A/B measurements)
-bool knn_fast_enabled() {
-    const char *e = getenv("DPM_KNN_FAST");  // read per call: tests flip it inside one process
-    return e ? atoi(e) != 0 : true;
-}
+// -DDPM_EXPERIMENT builds only, DPM_KNN_FAST=0: every row through the one-wave-per-centre search (the round-2 path; A/B
+// measurements, scripts/knn_bench.py)
+bool knn_fast_enabled() { return dpm_knob("DPM_KNN_FAST", 1) != 0; }
 int launch_grid_search(const float *points, const int32_t *lengths, const float *centers, int B, int N, int S, int K,
                        float r2, int32_t *idx, const KnnWs &w, const int32_t *reuse_idx, const int32_t *center_src,
                        hipStream_t st) {
@@ -1517,7 +1516,7 @@ int launch_grid_search(const float *points, const int32_t *lengths, const float 
                            S, K, r2, w.hdr, w.start, w.sorted, idx, reuse_idx, center_src, w.tie_count, w.tie_rows,
                            (const int *)nullptr, (const int32_t *)nullptr, 0, (int)rows);
     }
-    if (getenv("DPM_ABLATE_TIE")) return dpm_launch_status();  // timing experiments only: tied rows keep the plain selection
+    if (dpm_knob("DPM_ABLATE_TIE", 0)) return dpm_launch_status();  // -DDPM_EXPERIMENT builds only: tied rows keep the plain selection
     if ((long long)K * 64 <= (long long)N)  // torch.topk's partial_sort regime: heap-select replay of the queued rows
         hipLaunchKernelGGL(knn_tie_kernel, dim3(2048), dim3(TIE_T), 0, st, points, lengths, centers, N, S, K, r2,
                            w.tie_count, w.tie_rows, idx);

@@ -17,13 +17,12 @@ the three SLAM threads of the reference can share one instance (system/core.py:5
 from __future__ import annotations
 
 import copy
-import os
 import threading
 from typing import Dict, Tuple, Union
 
 import torch
 
-from . import ops
+from . import knobs, ops
 from .params import ParamTree, decoder_shapes
 
 HEADS = 8
@@ -40,8 +39,8 @@ class Decoder(ParamTree):
         self.tau = args.loss.tau
         self._dim_t: Dict[str, torch.Tensor] = {}
         self.stack_sides = True   # M != N: one launch per row-wise layer over both sides (False: the per-side loop)
-        # pair lists over shared frames: per-frame work once per frame (False / DPM_DEDUP_FRAMES=0: per pair side, A/B runs)
-        self.dedup_frames = os.environ.get("DPM_DEDUP_FRAMES", "1") != "0"
+        # pair lists over shared frames: per-frame work once per frame (False: per pair side, A/B runs)
+        self.dedup_frames = knobs.DEDUP_FRAMES
         # One-pair registrations (the reference's own call: odometry.py:108-110, mapping.py:153-155, loop_closure.py:239-242)
         # are ~50 small launches whose enqueue takes longer than their execution.  A shape (M, N, k) that keeps coming back is
         # captured once as a HIP graph over static input / output buffers and replayed from then on: same kernels, same
@@ -55,6 +54,7 @@ class Decoder(ParamTree):
         self.graph_max = 6        # captured shapes kept per decoder
         self._graphs: Dict[tuple, dict] = {}
         self._graph_lock = threading.Lock()
+        self._stamp_params = None
         self.eval()
 
     def __deepcopy__(self, memo):
@@ -65,6 +65,8 @@ class Decoder(ParamTree):
         for k, v in self.__dict__.items():
             if k == "_graphs":
                 new.__dict__[k] = {}
+            elif k == "_stamp_params":
+                new.__dict__[k] = None
             elif k == "_graph_lock":
                 new.__dict__[k] = threading.Lock()
             else:
@@ -236,7 +238,9 @@ class Decoder(ParamTree):
             # the first cross-attention block's q | k | v projection sees the frame alone as well: once per frame, the
             # attention kernel picks a pair's sequences through `order` (row-wise kernel: the same rows bit for bit)
             ca0 = pre + ".cross_attn"
-            qkv_u = ops.linear(z1u, self.p(ca0 + ".in_proj_weight"), self.p(ca0 + ".in_proj_bias")) if self.dedup_frames else None
+            # (the indexed attention kernel exists for 32-wide heads without masks; other widths project per pair side)
+            qkv_u = (ops.linear(z1u, self.p(ca0 + ".in_proj_weight"), self.p(ca0 + ".in_proj_bias"))
+                     if self.dedup_frames and E // HEADS == 32 and mask is None else None)
             zp = None
         else:
             z_in = torch.cat([ts, td], dim=0)                       # (2R, 131): [src tokens ; dst tokens]
@@ -361,7 +365,13 @@ class Decoder(ParamTree):
 
     # -- captured one-pair registrations ---------------------------------------------------------
     def _weights_stamp(self):
-        return tuple((p.data_ptr(), p._version) for p in self._flat.values())
+        """What a captured graph hangs on: where the parameters live (`_epoch`: bumped by load_state_dict / .to() /
+        invalidate_caches, ParamTree), their in-place version counters, and the generation of the weight-derived cache
+        (ops.invalidate_derived frees tensors a graph might read).  Versions only on the per-call path: 13 us for the 82
+        tensors against 42 us with a data_ptr() each.  Weights edited through `.data` need invalidate_caches(), as before."""
+        if self._stamp_params is None:
+            self._stamp_params = list(self._flat.values())
+        return (self._epoch, ops.derived_generation(), tuple([p._version for p in self._stamp_params]))
 
     def _graph_entry(self, key, M: int, N: int, num_sample, dev):
         """The graph of shape `key`, captured now if the shape has been seen often enough; None = run eagerly."""

@@ -1,0 +1,32 @@
+"""Measurement knobs of the Python host side.
+
+The values below ARE the shipped behaviour and no call of the hot path reads the environment.  Scripts under scripts/
+(A/B runs) set the attributes directly or call `apply_env()` once at start-up; `bench.py` refuses to run with any `DPM_*`
+variable in the environment unless `--allow-knobs` is given, and then records what was applied in its JSON line.  The
+kernels' own measurement switches exist only in libraries built with -DDPM_EXPERIMENT (csrc/dpm_common.h: `dpm_knob`),
+which `_lib.load()` reports through `_lib.experimental()`.
+"""
+from __future__ import annotations
+
+import os
+
+FPS_ALGO = None        # int: first-level sampling kernel for 16 384 < N <= 65 536 (None = the library's choice, algo 5)
+FUSED_LN = True        # False: Linear + LayerNorm as two kernels at every size (scripts/gemm_ln_shapes.py)
+DEDUP_FRAMES = True    # False: per-frame decoder work once per pair side instead of once per frame (new Decoder objects)
+
+_ENV = {"DPM_FPS_ALGO": ("FPS_ALGO", int), "DPM_NO_FUSED_LN": ("FUSED_LN", lambda v: v != "1"),
+        "DPM_DEDUP_FRAMES": ("DEDUP_FRAMES", lambda v: v != "0")}
+
+
+def env_knobs() -> dict:
+    """every DPM_* variable of the environment (host-side knobs, DPM_LIB, and the names an experimental library reads)"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("DPM_")}
+
+
+def apply_env() -> dict:
+    """Set the attributes above from their DPM_* variables, once; returns env_knobs()."""
+    g = globals()
+    for var, (name, conv) in _ENV.items():
+        if var in os.environ:
+            g[name] = conv(os.environ[var])
+    return env_knobs()

@@ -9,13 +9,12 @@ from __future__ import annotations
 from typing import Optional, Tuple
 
 import ctypes
-import os
 import threading
 import weakref
 
 import torch
 
-from . import _lib
+from . import _lib, knobs
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -137,8 +136,8 @@ def fps(xyz: torch.Tensor, lengths: torch.Tensor, K: int, algo: int = 0, start: 
         _lib.check(lib.dpm_fps_start(_ptr(xyz), _ptr(lengths), _ptr(start), B, N, K, _ptr(idx), _ptr(new_xyz), _ptr(new_len),
                                      _ptr(ws), _stream(xyz)), "dpm_fps_start")
         return idx, new_xyz, new_len
-    if algo == 0 and N > 16384 and "DPM_FPS_ALGO" in os.environ:  # tuning knob (scripts/, bench experiments)
-        algo = int(os.environ["DPM_FPS_ALGO"])
+    if algo == 0 and N > 16384 and knobs.FPS_ALGO is not None:  # A/B runs (scripts/); never set from the environment here
+        algo = int(knobs.FPS_ALGO)
     idx = torch.empty(B, K, device=xyz.device, dtype=torch.int32)
     new_xyz = torch.empty(B, K, 3, device=xyz.device, dtype=torch.float32)
     new_len = torch.empty(B, device=xyz.device, dtype=torch.int32)
@@ -259,6 +258,7 @@ PROJECTED_COUT = (32, 64, 128, 256, 512)
 _DERIVED: dict = {}
 _DERIVED_LOCK = threading.Lock()   # the reference drives one Encoder / Decoder from several threads (core.py:54-57)
 _RETIRED: list = []                # replaced values stay alive until the device has been synchronised once more
+_GENERATION = [0]                  # bumped by invalidate_derived(): captured graphs made before it are stale (decoder.py)
 
 
 def invalidate_derived() -> None:
@@ -267,6 +267,11 @@ def invalidate_derived() -> None:
     with _DERIVED_LOCK:
         _RETIRED.extend(v[2] for v in _DERIVED.values())
         _DERIVED.clear()
+        _GENERATION[0] += 1
+
+
+def derived_generation() -> int:
+    return _GENERATION[0]
 
 
 def _derived(tag: str, sources, make):
@@ -274,6 +279,12 @@ def _derived(tag: str, sources, make):
     stamp = tuple((t.data_ptr(), t._version) for t in sources)
     dev = sources[0].device
     cur = torch.cuda.current_stream(dev)
+    if torch.cuda.is_current_stream_capturing():
+        # Inside a capture nothing of this cache may be touched: a tensor made here would live in the graph's private pool,
+        # hold no data until the first replay and be published to eager callers with a captured event; a hit would make the
+        # capture wait on an event recorded outside it.  Code paths that are captured (Decoder._register) use no derived
+        # tensors; one that starts to must make them before the capture.
+        raise RuntimeError(f"ops._derived({tag!r}) under stream capture: make weight-derived tensors before capturing")
     with _DERIVED_LOCK:
         hit = _DERIVED.get(key)
         if hit is not None and hit[1] == stamp and all(r() is t for r, t in zip(hit[0], sources)):
@@ -438,7 +449,7 @@ def linear_layernorm(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tens
     # compute units idle and the two-kernel form is 1.5-2.8x faster (scripts/gemm_ln_shapes.py: 4096 x 1024 -> 256 takes
     # 86 us fused, 31 us as GEMM + LayerNorm)
     if (Cout in FUSED_LN_WIDTHS and x2.shape[0] >= FUSED_LN_MIN_ROWS and W.is_contiguous() and x2.is_contiguous()
-            and x.dtype == torch.float32 and Cin % 4 == 0 and os.environ.get("DPM_NO_FUSED_LN") != "1"):
+            and x.dtype == torch.float32 and Cin % 4 == 0 and knobs.FUSED_LN):
         _chk(W, torch.float32, "W")
         out = torch.empty(*x.shape[:-1], Cout, device=x.device, dtype=torch.float32)
         for n, t in (("pre", pre), ("post", post)):

@@ -101,6 +101,7 @@ class ParamTree(nn.Module):
     def __init__(self, shapes: Shapes = None):
         super().__init__()
         self._flat: Dict[str, nn.Parameter] = {}
+        self._epoch = 0   # bumped whenever parameter storage may have moved (load_state_dict, .to(), invalidate_caches)
         for key, shape in (shapes or {}).items():
             self._add(key, shape)
 
@@ -122,6 +123,13 @@ class ParamTree(nn.Module):
         Automatic on load_state_dict(); needed by hand only after in-place edits through `.data`."""
         from . import ops
         ops.invalidate_derived()
+        self._epoch += 1
+
+    def _apply(self, fn, *args, **kwargs):
+        """.to() / .cuda() / .float(): the parameters' storage moves"""
+        out = super()._apply(fn, *args, **kwargs)
+        self._epoch += 1
+        return out
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)

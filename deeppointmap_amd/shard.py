@@ -27,15 +27,22 @@ def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
-def gather_to_root(t: torch.Tensor, root: int = 0) -> Optional[torch.Tensor]:
+def _lone(force: bool) -> bool:
+    """no process group, or one rank (and the caller did not ask for the collective anyway)"""
+    return not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not force)
+
+
+def gather_to_root(t: torch.Tensor, root: int = 0, force: bool = False) -> Optional[torch.Tensor]:
     """Equal-shaped per-rank tensor (F, ...) -> on `root`: (world*F, ...) in rank order; None elsewhere.
-    A no-op (returns t) when torch.distributed is not initialised or world == 1."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    A no-op (returns t) when torch.distributed is not initialised or world == 1.
+    force=True issues the collective on a one-rank group too: the only way to execute the RCCL call path (communicator
+    creation, the collective on the caller's stream, owned receive buffers) on a single-GPU box -- tests/test_gpu_rccl.py."""
+    if _lone(force):
         return t
     world, rank = dist.get_world_size(), dist.get_rank()
     t = t.contiguous()
     if t.is_cuda and dist.get_backend() == "gloo":  # dry-run backend: gloo gathers host tensors only
-        out = gather_to_root(t.cpu(), root)
+        out = gather_to_root(t.cpu(), root, force)
         return out.to(t.device) if out is not None else None
     if rank == root:
         # one tensor of its own per rank (not views of one buffer: a collective is handed plain allocations), joined after
@@ -46,15 +53,15 @@ def gather_to_root(t: torch.Tensor, root: int = 0) -> Optional[torch.Tensor]:
     return None
 
 
-def gather_step_results(desc: torch.Tensor, edges_packed: torch.Tensor, root: int = 0):
+def gather_step_results(desc: torch.Tensor, edges_packed: torch.Tensor, root: int = 0, force: bool = False):
     """One step's exchange: descriptors (F,131,S) and packed edges (E,EDGE_FLOATS) -> rank 0, as ONE collective:
     the two tensors travel as one flat fp32 row block per rank (a collective costs a launch and a stream hand-over
     on every rank whatever its size; the edge rows are 14 KB next to 8.6 MB of descriptors)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _lone(force):
         return desc, edges_packed
     nd, ne = desc.numel(), edges_packed.numel()
     flat = torch.cat([desc.reshape(-1), edges_packed.reshape(-1).to(desc.dtype)]).unsqueeze(0)   # (1, nd + ne)
-    out = gather_to_root(flat, root)
+    out = gather_to_root(flat, root, force)
     if out is None:
         return None, None
     world = out.shape[0]
@@ -63,13 +70,13 @@ def gather_step_results(desc: torch.Tensor, edges_packed: torch.Tensor, root: in
     return d, e
 
 
-def exchange_halo(last_desc: torch.Tensor, last_pcd: Optional[torch.Tensor]):
+def exchange_halo(last_desc: torch.Tensor, last_pcd: Optional[torch.Tensor], force: bool = False):
     """Ring hand-over of a block's LAST frame to the rank that owns the following block: the first frame of rank r's
     block is registered against the last frame of rank r-1's (reference odometry.py:103-127 registers every new scan
     against its predecessor).  Sends (descriptor (131,S), scan (3,N) or None) to rank+1, returns what rank-1 sent --
     one point-to-point message per rank and step (134 KB + 786 KB at 65 536 points).  Rank 0 receives the last frame of
     the whole window: the predecessor of ITS first frame in the NEXT step (the caller keeps it until then)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _lone(force):
         return last_desc, last_pcd  # one rank: its own last frame precedes its next block
     world, rank = dist.get_world_size(), dist.get_rank()
     parts = [last_desc.reshape(-1)] + ([last_pcd.reshape(-1)] if last_pcd is not None else [])

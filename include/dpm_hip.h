@@ -37,7 +37,11 @@ typedef void *dpm_stream_t;
 #define DPM_ACT_RELU 1
 #define DPM_ACT_SIGMOID 2
 
-/* library / ABI version (major*1000+minor) and a printable name for a status code */
+/* library / ABI version (major*1000+minor) and a printable name for a status code.  The shipped library reads no
+ * environment variable in any entry point.  A build with -DDPM_EXPERIMENT (measurement switches that skip work or swap
+ * kernel layouts, read with getenv; scripts/ only) ORs DPM_VERSION_EXPERIMENT into the version so that callers can
+ * refuse it: bench.py does. */
+#define DPM_VERSION_EXPERIMENT 0x40000000
 int dpm_version(void);
 const char *dpm_error_string(int status);
 

@@ -1,4 +1,6 @@
-"""Isolated timing of the two grid-search neighbour queries of the first encoder stage (64 frames)."""
+"""Isolated timing of the two grid-search neighbour queries of the first encoder stage (64 frames).
+The A/B half (DPM_KNN_FAST flipped inside the process) needs an experimental library:
+  python deeppointmap_amd/csrc/build.py --out /tmp/libdpm_exp.so -DDPM_EXPERIMENT; DPM_LIB=/tmp/libdpm_exp.so python scripts/knn_bench.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,6 +31,9 @@ timed("SA0  N=65536 S=4096 r=0.05 K=32", lambda: ops.knn_hybrid(xyz, lengths, ne
 timed("LA0  N=4096  S=4096 r=0.10 K=32", lambda: ops.knn_hybrid(new_xyz, new_len, new_xyz, 32, 0.1))
 
 # the quarter-wave search against the one-wave-per-centre search: identical sets on every row
+from deeppointmap_amd import _lib
+if not _lib.experimental():
+    sys.exit("A/B half skipped: the shipped library has no DPM_KNN_FAST switch (see the docstring)")
 def sets(a):
     return torch.sort(a, dim=-1).values
 for name, args in (("SA0", (xyz, lengths, new_xyz, 32, 0.05)), ("LA0", (new_xyz, new_len, new_xyz, 32, 0.1))):

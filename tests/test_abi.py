@@ -131,3 +131,40 @@ def test_modules_deepcopy_and_state_dict_roundtrip(cfg_full):
     missing = Decoder(cfg_full).load_state_dict({k: v for k, v in dec.state_dict().items() if "coarse" not in k}, strict=False)
     assert set(missing.missing_keys) == {k for k in dec.state_dict() if "coarse" in k}
     assert not enc.training and not dec.training  # constructed in eval mode, like odometry.py:33,74 leave them
+
+
+def test_shipped_library_reads_no_environment_and_bench_refuses_knobs():
+    """The measurement switches (work-skipping ablations, A/B layouts) exist only behind -DDPM_EXPERIMENT: the shipped
+    sources call getenv in ONE place (dpm_common.h, inside that #ifdef), the shipped library's version carries no
+    experiment flag and imports no `getenv`, no product module reads os.environ on a call, and bench.py exits non-zero
+    when a DPM_* variable is set (before it touches a GPU) unless --allow-knobs is given."""
+    import subprocess
+    import sys
+    from deeppointmap_amd import _lib
+    csrc = os.path.join(ROOT, "deeppointmap_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+                code = line.split("//")[0]
+                if "getenv" in code:
+                    hits.append((f, i))
+    assert [h[0] for h in hits] == ["dpm_common.h"], hits
+    src = open(os.path.join(csrc, "dpm_common.h")).read()
+    assert src.index("#ifdef DPM_EXPERIMENT") < src.index("getenv(name)") < src.index("#else")
+    lib = _lib.load()
+    assert lib.dpm_version() & _lib.VERSION_EXPERIMENT == 0 and not _lib.experimental()
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        assert "getenv" not in nm.stdout.split(), "the shipped library imports getenv"
+    pkg = os.path.join(ROOT, "deeppointmap_amd")
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith(".py") and f not in ("_lib.py", "knobs.py"):
+            assert "os.environ" not in open(os.path.join(pkg, f)).read(), f
+    env = dict(os.environ, DPM_ABLATE_NN1="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "DPM_ABLATE_NN1" in out.stderr and "--allow-knobs" in out.stderr
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"],
+                         env=dict(os.environ, DPM_LIB="/nonexistent.so"), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "DPM_LIB" in out.stderr

@@ -327,6 +327,36 @@ def test_pairs_entry_equals_batched_entry(dec):
         assert n_in > 0 and torch.equal(r1[b, 20:20 + n_in], r2[b, 20:20 + n_in])
 
 
+def test_pairs_entry_at_other_decoder_widths(cfg_full):
+    """A decoder whose heads are not 32 wide (model_channel 128 / 512: heads of 16 / 64) has no indexed attention kernel:
+    the pair-list entry must fall back to projecting per pair side (it raised `unsupported shape` before) and still equal the
+    gathered-batch entry bit for bit; the 128-wide decoder is also held to the oracle."""
+    import copy
+    from deeppointmap_amd.decoder import Decoder
+    from deeppointmap_amd.weights import init_procedural
+    gen = torch.Generator().manual_seed(23)
+    for width in (128, 512):
+        cfg = copy.deepcopy(cfg_full)
+        cfg.decoder.model_channel = width
+        d = init_procedural(Decoder(cfg)).to(DEV)
+        assert d.dedup_frames
+        frames = torch.rand(5, 131, 96, generator=gen)
+        frames[:, 128:] = (torch.rand(5, 3, 96, generator=gen) * 2 - 1) * 30
+        frames = frames.to(DEV)
+        src = torch.tensor([0, 1, 2, 3, 0], dtype=torch.int32, device=DEV)
+        dst = torch.tensor([1, 2, 3, 4, 2], dtype=torch.int32, device=DEV)
+        r1 = d.registration_forward_pairs(frames, src, dst, 0.5)
+        r2 = d.registration_forward_batch(frames[src.long()], frames[dst.long()], 0.5)
+        assert torch.equal(r1[:, :16].contiguous().view(torch.int32), r2[:, :16].contiguous().view(torch.int32))
+        if width == 128:
+            tr = {}
+            d.registration_forward(frames[0], frames[1], num_sample=0.5, trace=tr)
+            sd = {k: v.detach().cpu() for k, v in d.flat().items()}
+            xo, _, yo, _ = O.descriptor_attention(sd, cfg, frames[0].cpu()[None], frames[1].cpu()[None])
+            torch.testing.assert_close(tr["x"].cpu().view(-1), xo.reshape(-1), rtol=1e-3, atol=2e-4)
+            torch.testing.assert_close(tr["y"].cpu().view(-1), yo.reshape(-1), rtol=1e-3, atol=2e-4)
+
+
 def test_pairs_entry_projects_each_frame_once(dec):
     """64 consecutive-frame pairs over 65 frames (the bench's shape: 32-query waves in the attention kernel): the first
     cross-attention block's q | k | v projection runs once per FRAME and the attention kernel picks each pair's sequences

@@ -105,21 +105,22 @@ def test_two_ranks_equal_one_process_in_sequence(pipelined):
 
 def test_bench_two_ranks_dry_run():
     """`bench.py --gpus 2` exactly as the driver launches it (python -m torch.distributed.run, one process per rank), with the
-    ranks folded onto this box's one GPU and gloo in place of RCCL (DPM_BENCH_BACKEND=gloo): the N > 1 code path -- chain mode,
+    ranks folded onto this box's one GPU and gloo in place of RCCL (--backend gloo): the N > 1 code path -- chain mode,
     halo hand-over, the gather of every step, the rank-0 consumer -- runs end to end and prints the contract's JSON line."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DPM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29950 + os.getpid() % 40), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--cpu-frames", "0", "--frames", "8", "--points", "16384"]
+           "--warmup", "1", "--cpu-frames", "0", "--frames", "8", "--points", "16384", "--backend", "gloo"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert line["value"] > 0 and line["unit"] == "frames/s" and line["higher_is_better"] is True
-    assert line["config"]["frames_per_gpu_per_step"] == 8
+    assert line["config"]["frames_per_gpu_per_step"] == 8 and "DRY RUN over gloo" in line["config"]["parallelism"]
+    assert line["rank0_consumer"]["synthetic_rows"] is True
     assert line["rank0_serial_ms"] > 0 and line["value_with_rank0_consumer"] > 0
     assert "roofline" in line and line["roofline"]["bound"] == "hbm"
