@@ -64,6 +64,8 @@ SIGNATURES = {
     "dpm_attention_split_workspace_bytes": (c_size_t, [I, I, I, I, I]),
     "dpm_attention_split": (I, [P, I, LL, P, I, LL, P, I, LL, P, I, LL, I, I, I, I, I, I, I, P, P]),
     "dpm_l2_normalize": (I, [P, I, I, P, P]),
+    "dpm_match_workspace_bytes": (c_size_t, [I, I, I, I]),
+    "dpm_match_topk": (I, [P, P, I, I, I, I, D, I, P, P, P, P]),
     "dpm_pairing_workspace_bytes": (c_size_t, [I, I, I]),
     "dpm_dual_softmax_topk": (I, [P, I, I, I, D, I, P, P, P, P]),
     "dpm_gather_pairs": (I, [P, P, P, I, I, I, I, I, P, P, P, P]),

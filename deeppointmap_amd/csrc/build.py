@@ -23,6 +23,7 @@ SOURCES = {
     "gemm.hip": [],
     "group_mlp.hip": [],
     "decoder_ops.hip": [],
+    "match.hip": [],
     "infomat.hip": [],
     "preprocess.hip": [],
     "voxel_sample.hip": [],

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
                 const float ak = Ks[j * 16 + (lane & 15)][ks * 4 + g];
 #pragma unroll
                 for (int u = 0; u < QT; ++u)
-                    sacc[u][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, qa[u][ks], sacc[u][j], 0, 0, 0);
+                    sacc[u][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, qa[u][ks], sacc[u][j], 0, 0, 0), mfma_pace();
             }
         }
         // sacc[u][j][q] = score of key n0 + 16 j + 4 g + q for query 16 u + lane&15: mask keys beyond N, online softmax
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
                     const float av = Vs[j * 16 + g * 4 + q][jd * 16 + (lane & 15)];
 #pragma unroll
                     for (int u = 0; u < QT; ++u)
-                        oacc[u][jd] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sacc[u][j][q], oacc[u][jd], 0, 0, 0);
+                        oacc[u][jd] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sacc[u][j][q], oacc[u][jd], 0, 0, 0), mfma_pace();
                 }
             }
     }
@@ -1279,7 +1279,7 @@ static int attention_launch(const float *Q, int ldq, long long sq, const float *
     // 32 queries per wave when the query count fills such blocks and there are enough of them for the chip
     const bool wide = M % 128 == 0 && (long long)(M / 128) * heads * B >= 1024;
 #define DPM_ATT(V, QT)                                                                                                  \
-    hipLaunchKernelGGL((attention_kernel<V, QT>), dim3(dpm_cdiv(M, 64 * QT), heads, B), dim3(256), 0, (hipStream_t)stream, \
+    hipLaunchKernelGGL((attention_kernel<V, QT>), dim3(dpm_cdiv(M, 64 * QT), heads, B), dim3(256), (size_t)dpm_knob("DPM_ATT_LDS_PAD", 0), (hipStream_t)stream, \
                        Q, ldq, sq, K, ldk, sk, V_, ldv, sv, out, ldo, so, M, N, scale, kv_shift, nullptr, 1, nullptr,     \
                        nullptr, seq)
     const float *V_ = V;

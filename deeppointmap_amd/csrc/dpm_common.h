@@ -55,6 +55,24 @@ __device__ __forceinline__ void valu_bound_priority() {
     if (DPM_VALU_PRIO) __builtin_amdgcn_s_setprio(DPM_VALU_PRIO);
 }
 
+// Pacing of matrix instructions (experiment of round 4, profiles/r04_corun.md): a wave whose NEXT instruction is an MFMA
+// while the matrix pipe is busy waits AT the SIMD's vector issue port and keeps every other wave's vector instructions
+// out (scripts/micro/corun_pure.hip: a matrix-only and a vector-only wave on one SIMD take the SUM of their times; with
+// the matrix wave idling after each MFMA the vector wave's work disappears in the gaps).  -DDPM_MFMA_PACE=n makes the
+// dense kernels idle n wait states (4 cycles each) after every matrix instruction.  0 = shipped.
+#ifndef DPM_MFMA_PACE
+#define DPM_MFMA_PACE 0
+#endif
+__device__ __forceinline__ void mfma_pace() {
+#if DPM_MFMA_PACE > 0
+#pragma unroll
+    for (int left = DPM_MFMA_PACE; left > 0; left -= 16) {
+        if (left >= 16) asm volatile("s_nop 15");
+        else asm volatile("s_nop %0" ::"n"((DPM_MFMA_PACE - 1) & 15));
+    }
+#endif
+}
+
 // XCD-aware workgroup order.  Workgroups are dealt round-robin to the 8 XCDs by linear id and every XCD has its own
 // 4 MB L2; with the plain order all XCDs walk through all frames at once and every L2 holds a slice of everything.
 // This maps the hardware id to a logical id such that XCD x processes the contiguous chunk [x*n/8, (x+1)*n/8) in

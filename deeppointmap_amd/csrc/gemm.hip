@@ -12,6 +12,13 @@
 //   registers while the current one feeds the MFMAs.
 #include "dpm_common.h"
 
+#include <algorithm>
+#include <type_traits>
+
+#ifndef DPM_GEMM_WS_DEFAULT
+#define DPM_GEMM_WS_DEFAULT 0   // 0: the 64 x 64 kernel everywhere (shipped: the wave-specialised kernel only ties it at K = 256, profiles/r04_corun.md); 1: the wave-specialised kernel takes the shapes it covers
+#endif
+
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_nt_mfma_kernel(const float *__restri
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[cur][j], a[cur][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[cur][j], a[cur][i], acc[i][j], 0, 0, 0), mfma_pace();
         }
         __syncthreads();
     }
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const float *__restrict__ 
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[cur][j], a[cur][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[cur][j], a[cur][i], acc[i][j], 0, 0, 0), mfma_pace();
         }
         __syncthreads();
     }
@@ -433,7 +440,216 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma128_kernel(const float *__
     }
 }
 
+// Wave-specialised variant for the big K = 256 .. 1024 shapes of the decoder (round 4).  What the measurements of
+// profiles/r04_corun.md say about this chip: a SIMD's time is (matrix-pipe busy time) + (vector-ALU busy time) -- the two never
+// overlap, neither across kernels nor across waves of one kernel -- so the only way to a shorter step is a matrix kernel
+// whose pipe is busy while it runs.  The 64 x 64 kernel above keeps eight waves per SIMD that each load, stage, synchronise
+// twice per K-tile and issue 32 MFMAs in between (48-58 % pipe utilisation).  Here a 512-thread workgroup owns a CU:
+//   waves 0-3 (one per SIMD) ONLY feed the matrix pipe: a 64 x 64 register tile each (2 x 2 waves = a 128 x 128 block),
+//             per k-step of four 8 LDS fragment reads against 16 MFMAs, ONE barrier per K-tile of 32 (128 MFMAs);
+//   waves 4-7 ONLY move data: the next K-tile global -> registers -> LDS while the current one is consumed (two stages),
+//             running ahead across tile boundaries (persistent workgroups: block b walks tiles b, b + G, ...).
+// Same instruction and k order as the kernels above, so every output element has the same bits.
+#ifdef DPM_EXPERIMENT
+__device__ long long dpm_ws_trace_buf[1024];   // s_memtime stamps of block 0, matrix wave 0 (scripts/gemm_ws_check.py)
+#define DPM_WS_STAMP(slot)                                                             \
+    do {                                                                               \
+        if (blockIdx.x == 0 && t == 0 && (slot) < 1024) dpm_ws_trace_buf[slot] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define DPM_WS_STAMP(slot) do { } while (0)
+#endif
+// PACE: wait states after every MFMA (A/B builds); ABL (timing experiments, -DDPM_EXPERIMENT builds only): 1 = no output
+// stores, 2 = no global loads, 4 = no LDS staging stores
+// The workgroup barrier of the wave-specialised kernel orders LDS traffic only: __syncthreads() also drains the vector
+// memory counter, which made the matrix waves wait for the data waves' output stores (229 against 147 us).
+__device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int PACE, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gemm_ws_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W, int ldw,
+                                                         const float *__restrict__ bias, const float *__restrict__ res, int ldr,
+                                                         float *__restrict__ out, int ldo, int R, int Cin, int Cout, int act,
+                                                         int gx, int gy, int ntiles) {
+    constexpr int BM = 128, BN = 128, KT = 32, LD = KT + 2, STAGE = (BM + BN) * LD, NS = 2, LDC = BN + 4;
+    // two operand stages (69 632 B) + the finished tile on its way out (67 584 B): more than half of the CU's 160 KB, so
+    // ONE workgroup per CU and one matrix wave per SIMD
+    __shared__ __attribute__((aligned(16))) float smem[NS * STAGE + BM * LDC];
+    float *otile = smem + NS * STAGE;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int G = gridDim.x;
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + G - 1) / G : 0;
+    const int kpt = Cin / KT, total = my_tiles * kpt;   // K-tiles per output tile (>= 2: dispatch), K-tiles of this workgroup
+    const bool swz = (gy & 7) == 0 && gy >= 64 && (G & 7) == 0;
+    auto place = [&](int L, int &row0, int &col0) {
+        int by = L / gx, bx = L - by * gx;
+        if (swz) {  // all column blocks of one row block on ONE XCD: its L2 serves X
+            const int xcd = L & 7, slot = L >> 3;
+            by = (slot / gx) * 8 + xcd, bx = slot % gx;
+        }
+        row0 = by * BM, col0 = bx * BN;
+    };
+    if (total == 0) return;
+    if (wave >= 4) {
+        // ---------------------------------------------------------------- data waves: operand staging + the tiles' way out
+        const int lt_ = t - 256, sr = lt_ >> 3, sk = (lt_ & 7) * 4;   // 8 lanes per row of 32 floats, 32 rows per pass
+        float4 xr[4], wr[4];
+        int rt = 0, rk = 0, row0, col0;   // the K-tile requested next: local tile, K-tile inside it
+        place((int)blockIdx.x, row0, col0);
+        auto request = [&]() {
+            const int k0 = rk * KT + sk;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (ABL & 2) {
+                    xr[p] = wr[p] = make_float4(1.f, 1.f, 1.f, 1.f);
+                    continue;
+                }
+                xr[p] = *reinterpret_cast<const float4 *>(X + (size_t)min(row0 + p * 32 + sr, R - 1) * ldx + k0);
+                wr[p] = *reinterpret_cast<const float4 *>(W + (size_t)min(col0 + p * 32 + sr, Cout - 1) * ldw + k0);
+            }
+            if (++rk == kpt) {
+                rk = 0, ++rt;
+                if (rt < my_tiles) place((int)blockIdx.x + rt * G, row0, col0);
+            }
+        };
+        auto store = [&](int stage) {
+            float *As = smem + stage * STAGE, *Bs = As + BM * LD;
+            if (ABL & 4) return;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float2 *d = reinterpret_cast<float2 *>(As + (p * 32 + sr) * LD + sk);
+                d[0] = make_float2(xr[p].x, xr[p].y), d[1] = make_float2(xr[p].z, xr[p].w);
+                float2 *e = reinterpret_cast<float2 *>(Bs + (p * 32 + sr) * LD + sk);
+                e[0] = make_float2(wr[p].x, wr[p].y), e[1] = make_float2(wr[p].z, wr[p].w);
+            }
+        };
+        // The finished tile (the matrix waves left it in `otile` one barrier ago): bias / residual / activation, whole
+        // 512-byte rows per store instruction.  A thread keeps its four columns for all 16 row passes.
+        const int cr = lt_ >> 5, cc = (lt_ & 31) * 4;
+        auto emit = [&](int tile_index, int p0, int p1, auto act_tag) {   // row passes [p0, p1) of 16 (8 rows each)
+            constexpr int ACT = decltype(act_tag)::value;
+            int r0, c0;
+            place((int)blockIdx.x + tile_index * G, r0, c0);
+            const int c = c0 + cc;
+            const bool cok = c < Cout;   // Cout % 4 == 0 (dispatch): a thread's four columns exist together
+            const float4 bv = bias && cok ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = p0; q < p1; q += 2) {   // two passes' residual rows in flight together
+                float4 rv[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int r = r0 + (q + p) * 8 + cr;
+                    rv[p] = res ? *reinterpret_cast<const float4 *>(res + (size_t)min(r, R - 1) * ldr + min(c, Cout - 4))
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int rl = (q + p) * 8 + cr, r = r0 + rl;
+                    float4 v = *reinterpret_cast<const float4 *>(otile + min(rl, BM - 1) * LDC + cc);
+                    v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                    if (res) v.x += rv[p].x, v.y += rv[p].y, v.z += rv[p].z, v.w += rv[p].w;
+                    v.x = apply_act(v.x, ACT), v.y = apply_act(v.y, ACT), v.z = apply_act(v.z, ACT), v.w = apply_act(v.w, ACT);
+                    if (q + p < p1 && r < R && cok && !(ABL & 1)) *reinterpret_cast<float4 *>(out + (size_t)r * ldo + c) = v;
+                }
+            }
+        };
+        auto emit_tile = [&](int tile_index, int p0, int p1) {
+            if (act == DPM_ACT_RELU) emit(tile_index, p0, p1, std::integral_constant<int, DPM_ACT_RELU>{});
+            else if (act == DPM_ACT_SIGMOID) emit(tile_index, p0, p1, std::integral_constant<int, DPM_ACT_SIGMOID>{});
+            else emit(tile_index, p0, p1, std::integral_constant<int, DPM_ACT_NONE>{});
+        };
+        const int per_step = (16 + kpt - 2) / (kpt - 1);   // row passes per step: a tile leaves over the kpt - 1 steps it has
+        // K-tile m lives in stage m % NS; at step n the matrix waves consume K-tile n while K-tile n + NS - 1 goes into the
+        // stage K-tile n - 1 left at the previous barrier.  K-tile n closes a tile when (n + 1) % kpt == 0; the matrix waves
+        // park it in `otile` between barriers n and n + 1, so it is ours from step n + 2 on (and free again long before the
+        // next tile closes, kpt >= 2 steps later).  It leaves in slices, a few row passes per step: all 64 KB at once was a
+        // store burst on every CU at the same moment whose back-pressure held the data waves -- and with them the barrier.
+        request();
+        for (int m = 0; m < NS - 1 && m < total; ++m) {
+            store(m);
+            if (m + 1 < total) request();
+        }
+        ws_barrier();
+        for (int n = 0; n < total; ++n) {
+            if (n + NS - 1 < total) store((n + NS - 1) % NS);
+            // the slice goes out BEFORE the next K-tile is requested: its bias / residual loads are waited for inside, and the
+            // in-order memory counter would make that wait cover the operand loads too (a DRAM latency per step)
+            if (n >= 2) {
+                const int q = (n - 1) / kpt, sl = (n - 1) - q * kpt;   // step sl of the tile that closed at K-tile q * kpt - 1
+                if (q >= 1 && sl <= kpt - 2 && sl * per_step < 16) emit_tile(q - 1, sl * per_step, min(16, (sl + 1) * per_step));
+            }
+            if (n + NS < total) request();
+            ws_barrier();
+        }
+        ws_barrier();   // the last tile is parked behind this one
+        emit_tile(my_tiles - 1, 0, 16);
+        return;
+    }
+    // -------------------------------------------------------------------- matrix waves
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fa = (wm * 64 + (lane & 15)) * LD + (lane >> 4), fb = (BM + wn * 64 + (lane & 15)) * LD + (lane >> 4);
+    ws_barrier();
+    int kin = 0;
+    DPM_WS_STAMP(0);
+    for (int n = 0; n < total; ++n) {
+        const float *S = smem + (n % NS) * STAGE;
+        float a[2][4], b[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[0][i] = S[fa + i * 16 * LD];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[0][j] = S[fb + j * 16 * LD];
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 4) {
+            const int cur = (kk >> 2) & 1, nxt = cur ^ 1;
+            if (kk + 4 < KT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[nxt][i] = S[fa + i * 16 * LD + kk + 4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[nxt][j] = S[fb + j * 16 * LD + kk + 4];
+            }
+            // the fragment reads of the NEXT k-step stay above this step's 16 MFMAs (512 cycles of cover); left alone
+            // the scheduler sinks them to three MFMAs before their use and every other k-step waits for LDS
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[cur][j], a[cur][i], acc[i][j], 0, 0, 0);
+                    if (PACE > 0) asm volatile("s_nop %0" ::"n"(PACE > 0 ? PACE - 1 : 0));
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        DPM_WS_STAMP(1 + 3 * n);       // MFMAs of the K-tile issued
+        ws_barrier();
+        DPM_WS_STAMP(2 + 3 * n);       // barrier passed
+        if (++kin == kpt) {
+            // the tile is complete: park it in LDS for the data waves (a lane owns four consecutive columns of one row per
+            // block: W is the instruction's A operand) and go on with the next tile's MFMAs
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    *reinterpret_cast<float4 *>(otile + (wm * 64 + i * 16 + (lane & 15)) * LDC + wn * 64 + j * 16 + (lane >> 4) * 4) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            kin = 0;
+        }
+        DPM_WS_STAMP(3 + 3 * n);       // (tile parked, when the K-tile closed one)
+    }
+    ws_barrier();
+}
+
 }  // namespace
+
+#ifdef DPM_EXPERIMENT
+extern "C" int dpm_debug_ws_trace(long long *host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dpm_ws_trace_buf), sizeof(long long) * (size_t)std::min(n, 1024));
+}
+#endif
 
 extern "C" int dpm_linear_batched(const float *x, int ldx, long long sx, const float *W, int ldw, long long sw,
                                   const float *bias, const float *residual, int ldr, long long sr, float *out, int ldo,
@@ -459,12 +675,38 @@ extern "C" int dpm_linear_batched(const float *x, int ldx, long long sx, const f
                            bias, residual, ldr, sr, out, ldo, so, R, Cin, Cout, act, gx, gy, ntiles);
         return dpm_launch_status();
     }
+    // wave-specialised 128 x 128 kernel: big unbatched shapes with whole K-tiles and at least one tile per CU
+    const long long tiles_ws = (long long)dpm_cdiv(R, 128) * dpm_cdiv(Cout, 128);
+    const int ws_mode = dpm_knob("DPM_GEMM_WS", DPM_GEMM_WS_DEFAULT);
+    if (ws_mode && batch == 1 && vec && vec_out && Cin % 32 == 0 && Cin >= 64 && Cout >= 128 && tiles_ws >= 256 && tiles_ws < (1 << 30)) {
+        const int gx = dpm_cdiv(Cout, 128), gy = dpm_cdiv(R, 128), ntiles = gx * gy;
+        const int G = (int)std::min<long long>(ntiles, 256);
+#ifdef DPM_EXPERIMENT
+#define DPM_WS_ABL(m, abl)                                                                                                   \
+    if (ws_mode == m) {                                                                                                      \
+        hipLaunchKernelGGL((gemm_ws_kernel<0, abl>), dim3(G), dim3(512), 0, st, x, ldx, W, ldw, bias, residual, ldr, out, ldo, R, \
+                           Cin, Cout, act, gx, gy, ntiles);                                                                   \
+        return dpm_launch_status();                                                                                          \
+    }
+        DPM_WS_ABL(11, 1) DPM_WS_ABL(12, 2) DPM_WS_ABL(13, 3) DPM_WS_ABL(17, 7)
+#undef DPM_WS_ABL
+#endif
+        if (ws_mode == 2)
+            hipLaunchKernelGGL((gemm_ws_kernel<2>), dim3(G), dim3(512), 0, st, x, ldx, W, ldw, bias, residual, ldr, out, ldo, R, Cin,
+                               Cout, act, gx, gy, ntiles);
+        else
+            hipLaunchKernelGGL((gemm_ws_kernel<0>), dim3(G), dim3(512), 0, st, x, ldx, W, ldw, bias, residual, ldr, out, ldo, R, Cin,
+                               Cout, act, gx, gy, ntiles);
+        return dpm_launch_status();
+    }
     const bool t64 = big >= 192 || (R > 1024 && Cout > 32);
     const dim3 grid = t64 ? dim3(dpm_cdiv(Cout, 64), dpm_cdiv(R, 64), batch) : dim3(dpm_cdiv(Cout, 32), dpm_cdiv(R, 32), batch);
 #define DPM_GEMM_LAUNCH(BM, BN, V, KF)                                                                                \
-    hipLaunchKernelGGL((gemm_nt_mfma_kernel<BM, BN, V, 32, KF>), grid, dim3(256), 0, st, x, ldx, sx, W, ldw, sw, bias,   \
+    hipLaunchKernelGGL((gemm_nt_mfma_kernel<BM, BN, V, 32, KF>), grid, dim3(256), lds_pad, st, x, ldx, sx, W, ldw, sw, bias,   \
                        residual, ldr, sr, out, ldo, so, R, Cin, Cout, act)
     const bool kfull = vec && Cin % 32 == 0;
+    // -DDPM_EXPERIMENT builds only: unused dynamic LDS caps the workgroups per CU (scripts/corun_micro.py: occupancy shapes)
+    const size_t lds_pad = (size_t)dpm_knob("DPM_GEMM_LDS_PAD", 0);
     if (t64) {
         if (kfull) DPM_GEMM_LAUNCH(64, 64, true, true);
         else if (vec) DPM_GEMM_LAUNCH(64, 64, true, false);

@@ -576,7 +576,7 @@ int launch_gather(const float *P, const float *A, const float *cvec, const float
     const long long total = (long long)B * S;
     if (total >= (1LL << 30)) return DPM_EUNSUPPORTED;
     const int cpw = total >= (1 << 16) ? 8 : (total >= (1 << 13) ? 2 : 1);  // centres per wave
-    hipLaunchKernelGGL((group_gather_ln_max_kernel<COUT, V, AFFINE>), dim3(dpm_cdiv(total, 4LL * cpw)), dim3(256), 0, st, P,
+    hipLaunchKernelGGL((group_gather_ln_max_kernel<COUT, V, AFFINE>), dim3(dpm_cdiv(total, 4LL * cpw)), dim3(256), (size_t)dpm_knob("DPM_GATHER_LDS_PAD", 0), st, P,
                        A, cvec, xyz, centers, idx, Wr, ldwr, gamma, beta, N, S, K, total, cpw, inv_r, out);
     return dpm_launch_status();
 }

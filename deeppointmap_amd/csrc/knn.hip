@@ -1505,7 +1505,7 @@ int launch_grid_search(const float *points, const int32_t *lengths, const float 
     if (rows > 0x7fffffffLL / KMAX) return DPM_EUNSUPPORTED;
     if (knn_fast_enabled()) {
         // a quarter wave per centre; what it cannot finish is listed for the full search (few rows: a fixed small grid)
-        hipLaunchKernelGGL(knn_grid_fast_kernel, dim3(dpm_cdiv(S, WPB * 64 / QL), B), dim3(WPB * 64), 0, st, lengths, centers, N, S,
+        hipLaunchKernelGGL(knn_grid_fast_kernel, dim3(dpm_cdiv(S, WPB * 64 / QL), B), dim3(WPB * 64), (size_t)dpm_knob("DPM_KNN_LDS_PAD", 0), st, lengths, centers, N, S,
                            K, r2, w.hdr, w.start, w.sorted, idx, reuse_idx, center_src, w.tie_count, w.tie_rows, w.tie_count + 1,
                            w.todo_rows, w.todo_cap);
         hipLaunchKernelGGL(knn_grid_kernel, dim3((unsigned)(rows / WPB + 1 < 2048 ? rows / WPB + 1 : 2048)), dim3(WPB * 64), 0, st, points, lengths,

@@ -38,6 +38,7 @@ class Decoder(ParamTree):
         self.attention_layers = self.decoder_cfg.attention_layers
         self.tau = args.loss.tau
         self._dim_t: Dict[str, torch.Tensor] = {}
+        self.fused_match = True   # similarity -> dual softmax -> top-k as one operator where it applies (ops.match_supported)
         self.stack_sides = True   # M != N: one launch per row-wise layer over both sides (False: the per-side loop)
         # pair lists over shared frames: per-frame work once per frame (False: per pair side, A/B runs)
         self.dedup_frames = knobs.DEDUP_FRAMES
@@ -323,8 +324,12 @@ class Decoder(ParamTree):
         else:
             a = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", x, ops.ACT_RELU)))
             b = ops.l2_normalize(self._lin("similarity_head.2", self._lin("similarity_head.0", y, ops.ACT_RELU)))
-        S = ops.similarity_batched(a.view(B, M, E), b.view(B, N, E))
-        conf, flat = ops.dual_softmax_topk(S, self.tau, k)
+        if self.fused_match and ops.match_supported(M, N, E, k):
+            # one operator, the M x N matrix never in memory (csrc/match.hip); the choice hangs on the pair's shape alone
+            conf, flat = ops.match_topk(a.view(B, M, E), b.view(B, N, E), self.tau, k)
+        else:
+            S = ops.similarity_batched(a.view(B, M, E), b.view(B, N, E))
+            conf, flat = ops.dual_softmax_topk(S, self.tau, k)
         # offset head on both pair directions                                           (decoder.py:204-207)
         X, si, di = ops.gather_pairs(x.view(B, M, E), y.view(B, N, E), flat)
         X = X.view(B * 2 * k, 2 * E)

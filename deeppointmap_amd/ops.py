@@ -585,6 +585,30 @@ def dual_softmax_topk(S: torch.Tensor, tau: float, k: int):
     return (val[0], idx[0]) if single else (val, idx)
 
 
+MATCH_MAX_N, MATCH_MAX_K = 256, 2048   # dpm_match_topk: columns one workgroup holds, pairs its lists hold
+
+
+def match_supported(M: int, N: int, C: int, k: int) -> bool:
+    """shapes dpm_match_topk takes (a function of ONE pair's shape, never of the batch)"""
+    return N <= MATCH_MAX_N and k <= MATCH_MAX_K and C % 32 == 0 and 1 <= k <= M * N and M <= 64 * 65535
+
+
+def match_topk(a: torch.Tensor, b: torch.Tensor, tau: float, k: int):
+    """a (B,M,C), b (B,N,C) L2-normalised head outputs -> (values (B,k), flat idx (B,k) int32), sorted descending: similarity,
+    dual softmax and top-k of decoder.py:185-191 without the (M,N) matrix in memory.  Raises ValueError for shapes outside
+    match_supported()."""
+    _chk(a, torch.float32, "a"), _chk(b, torch.float32, "b")
+    B, M, C = a.shape
+    N = b.shape[1]
+    lib = _lib.load()
+    val = torch.empty(B, k, device=a.device, dtype=torch.float32)
+    idx = torch.empty(B, k, device=a.device, dtype=torch.int32)
+    ws = torch.empty(lib.dpm_match_workspace_bytes(B, M, N, k), device=a.device, dtype=torch.uint8)
+    _lib.check(lib.dpm_match_topk(_ptr(a), _ptr(b), B, M, N, C, float(tau), k, _ptr(val), _ptr(idx), _ptr(ws), _stream(a)),
+               "dpm_match_topk")
+    return val, idx
+
+
 def gather_pairs(x: torch.Tensor, y: torch.Tensor, flat: torch.Tensor):
     """x (B,M,E), y (B,N,E), flat (B,k) -> X (B,2k,2E), src_idx (B,k), dst_idx (B,k)   (2-D inputs: B = 1, 2-D outputs)."""
     _chk(x, torch.float32, "x"), _chk(y, torch.float32, "y"), _chk(flat, torch.int32, "flat")

@@ -304,6 +304,16 @@ int dpm_attention_split(const float *Q, int ldq, long long sq, const float *K, i
 /* F.normalize(x, p=2, dim=-1) (decoder.py:185): x / max(||x||, 1e-12), rows (R,C). */
 int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stream);
 
+/* Decoder._descriptor_pairing from the L2-normalised head outputs on (decoder.py:185-191) as ONE operator: a (batch,M,C),
+ * b (batch,N,C) row-major -> S = a b^T (fp32 MFMA), P = softmax_row(S/tau) * softmax_col(S/tau), the k largest entries of
+ * the flattened P sorted descending (ties: smaller flat index first): out_val (batch,k), out_idx (batch,k) with
+ * row = idx / N, col = idx % N.  The M x N matrix never exists in memory: two launches over row strips of 64, the strip
+ * recomputed in the second (csrc/match.hip).  DPM_EUNSUPPORTED for N > 256, k > 2048, C % 32 != 0 or unaligned operands:
+ * the caller then runs dpm_linear_batched + dpm_dual_softmax_topk (same values up to the last bit of the column sums). */
+size_t dpm_match_workspace_bytes(int batch, int M, int N, int k);
+int dpm_match_topk(const float *a, const float *b, int batch, int M, int N, int C, double tau, int k, float *out_val,
+                   int32_t *out_idx, void *workspace, dpm_stream_t stream);
+
 /* Decoder._descriptor_pairing tail (decoder.py:186-191): S (M,N) similarity, overwritten with
  * P = softmax_row(S/tau) * softmax_col(S/tau); then the k largest entries of the flattened P,
  * sorted descending: out_val (k), out_idx (k) flat indices (row = idx / N, col = idx % N).

@@ -141,6 +141,77 @@ def test_dual_softmax_topk_vs_torch(ops):
         assert set(idx.cpu().tolist()) == set(gi.tolist())
 
 
+def test_fused_match_vs_torch_and_vs_the_unfused_operators(ops):
+    """dpm_match_topk (similarity -> dual softmax -> top-k in two launches, the M x N matrix never in memory) against torch
+    in double and against the five-launch path it replaces: ragged strips (M % 64 != 0), narrow tiles (N < 256, N % 64 != 0),
+    one strip, 64 strips (a map tile against a scan), k up to the list capacity, batches."""
+    gen = torch.Generator().manual_seed(17)
+    for B, M, N, C, k in [(1, 256, 256, 256, 128), (3, 256, 256, 256, 128), (1, 300, 77, 64, 1), (2, 64, 64, 32, 2048),
+                          (1, 37, 200, 96, 500), (1, 1024, 256, 256, 640), (1, 4096, 256, 256, 1088), (2, 130, 256, 64, 193)]:
+        a = torch.nn.functional.normalize(torch.randn(B, M, C, generator=gen), dim=2)
+        b = torch.nn.functional.normalize(torch.randn(B, N, C, generator=gen), dim=2)
+        assert ops.match_supported(M, N, C, k)
+        val, idx = ops.match_topk(a.to(DEV), b.to(DEV), 0.1, k)
+        S = ops.similarity_batched(a.to(DEV), b.to(DEV))
+        v0, i0 = ops.dual_softmax_topk(S, 0.1, k)   # S now holds the unfused path's P
+        for p in range(B):
+            Sd = a[p].double() @ b[p].double().t()
+            P = torch.softmax(Sd / 0.1, 1) * torch.softmax(Sd / 0.1, 0)
+            wv, wi = torch.topk(P.reshape(-1), k)
+            torch.testing.assert_close(val[p].cpu().double(), wv, rtol=3e-5, atol=1e-12)
+            assert bool((val[p, :-1] >= val[p, 1:]).all()), "top-k must come out sorted descending"
+            got = idx[p].cpu().long()
+            assert len(set(got.tolist())) == k and int(got.min()) >= 0 and int(got.max()) < M * N
+            # every selected entry carries the value of its own position (the indices are not merely plausible) ...
+            torch.testing.assert_close(val[p].cpu().double(), P.reshape(-1)[got], rtol=3e-5, atol=1e-12)
+            # ... and nothing outside the selection beats the smallest selected value by more than rounding
+            rest = P.reshape(-1).clone()
+            rest[got] = 0
+            assert float(rest.max()) <= float(val[p, -1]) * (1 + 3e-5) + 1e-12
+        # against the operators it replaces: same values to the last bits of the column sums, same pairs wherever the
+        # k-th and (k+1)-th values are further apart than that
+        torch.testing.assert_close(val, v0, rtol=2e-6, atol=1e-30)
+        Pm = S.view(B, -1)
+        for p in range(B):
+            srt = torch.sort(Pm[p], descending=True).values
+            if k < M * N and float(srt[k - 1] - srt[k]) > 1e-5 * float(srt[k - 1]):
+                assert set(idx[p].tolist()) == set(i0[p].tolist()), (B, M, N, k)
+
+
+def test_fused_match_ties_padding_and_batch_independence(ops):
+    """exact ties at the k-th value go to the smaller flat indices (the rule of dpm_dual_softmax_topk); a pair's result
+    does not depend on the batch it travels in; rows of zeros (tau so small that most products underflow) still give k
+    valid, distinct pairs."""
+    gen = torch.Generator().manual_seed(3)
+    # duplicated descriptors: rows 0..63 of a repeat rows 64..127, so P has exactly equal entries in pairs of rows
+    base = torch.nn.functional.normalize(torch.randn(64, 32, generator=gen), dim=1)
+    a = torch.cat([base, base, base]).unsqueeze(0).to(DEV)          # (1,192,32)
+    b = torch.nn.functional.normalize(torch.randn(1, 100, 32, generator=gen), dim=2).to(DEV)
+    for k in (1, 7, 300, 2048):
+        val, idx = ops.match_topk(a, b, 0.1, k)
+        S = ops.similarity_batched(a, b)
+        v0, i0 = ops.dual_softmax_topk(S, 0.1, k)
+        assert torch.equal(idx, i0), k       # identical rows -> identical column folds -> the same tie order to the index
+        torch.testing.assert_close(val, v0, rtol=2e-6, atol=0)
+    # batch independence, bit for bit
+    A = torch.nn.functional.normalize(torch.randn(5, 256, 256, generator=gen), dim=2).to(DEV)
+    Bm = torch.nn.functional.normalize(torch.randn(5, 256, 256, generator=gen), dim=2).to(DEV)
+    v, i = ops.match_topk(A, Bm, 0.1, 128)
+    for p in (0, 3):
+        v1, i1 = ops.match_topk(A[p:p + 1].contiguous(), Bm[p:p + 1].contiguous(), 0.1, 128)
+        assert torch.equal(v[p], v1[0]) and torch.equal(i[p], i1[0])
+    # underflow: tau = 1e-3 leaves a few non-zero products per matrix, the rest are exact zeros tied at the threshold
+    v, i = ops.match_topk(A[:2].contiguous(), Bm[:2].contiguous(), 1e-3, 1000)
+    S = ops.similarity_batched(A[:2].contiguous(), Bm[:2].contiguous())
+    v0, i0 = ops.dual_softmax_topk(S, 1e-3, 1000)
+    assert torch.equal(v == 0, v0 == 0)
+    for p in range(2):
+        assert len(set(i[p].tolist())) == 1000
+        nz = int((v0[p] > 0).sum())
+        assert set(i[p, :nz].tolist()) == set(i0[p, :nz].tolist())
+        assert torch.equal(i[p, nz:], i0[p, nz:])    # among the zeros: the smallest flat indices, ascending
+
+
 def test_topk_ties_and_exact_values(ops):
     # many equal values: result must still be a valid top-k (multiset of values equal), deterministic
     P = (torch.randint(0, 6, (128, 128)).float() / 8).to(DEV)
