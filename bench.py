@@ -419,7 +419,10 @@ def main():
             "metric": "LiDAR frames/s (encode+match+register), 65 536 pts/frame",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" + (" (Linear / Conv1d layers with K <= 512 as exact three-way bf16 splits: 6 bf16 products per fp32 "
+                              "product, fp32 accumulate -- fp32 accuracy, bf16 matrix pipe; all else fp32)" if knobs.GEMM_BF16X3 else ""),
+            "data": "synthetic",
             "config": {"workload": f"synthetic {F}x{N}-pt scans per GPU: Encoder.forward + consecutive-frame "
                                    "registration_forward (256x256) + information matrix per frame",
                        "frames_per_gpu_per_step": F, "points_per_frame": N,
@@ -455,18 +458,34 @@ def main():
         if "rank0_serial_ms" in extras:
             line["value_with_rank0_consumer"] = round(world * F / (dt / args.steps + extras["rank0_serial_ms"] * 1e-3), 1)
         if gemm_ms > 0:
+            rows = gemm_flops[0] // (2 * 768 * 256)
+            if knobs.GEMM_BF16X3:
+                # the projection runs on the bf16 matrix pipe: every fp32 operand split exactly into three bf16 terms, six
+                # term products per fp32 product.  `achieved` counts the EXECUTED bf16 flops against the dense bf16 peak;
+                # `fp32_equivalent` is the fp32 product it delivers against the fp32 matrix peak it would otherwise run at.
+                PEAK, mult = 2500.0, 6
+                kern = ("gemm_b3_kernel<64,64> (csrc/gemm_b3.hip: fp32 GEMM as an exact three-way bf16 split, 6 products, fp32 "
+                        f"accumulate) on the decoder's 256->768 attention projections ({rows} token rows per launch)")
+                note = ("v_mfma_f32_16x16x32_bf16, dense bf16 peak ~2500 TFLOP/s; achieved = 6 x the fp32 product's flops; timed "
+                        "with HIP events on its launch stream while the other pipeline stages share the chip")
+            else:
+                PEAK, mult = 157.3, 1
+                kern = f"gemm_nt_mfma_kernel<64,64> on the decoder's 256->768 attention projections ({rows} token rows per launch)"
+                note = ("exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak); timed with HIP events on its "
+                        "launch stream while the other pipeline stages share the chip")
             tf = gemm_flops[0] / (gemm_ms * 1e-3) / 1e12
-            line["roofline_mfma"] = {
-                "kernel": "gemm_nt_mfma_kernel<64,64> on the decoder's 256->768 attention projections "
-                          f"({gemm_flops[0] // (2 * 768 * 256)} token rows per launch)",
-                "bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
-                "avg_launch_ms": round(gemm_ms, 4), "flops_per_launch": gemm_flops[0],
-                "note": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak); timed with HIP events on its "
-                        "launch stream while the other pipeline stages share the chip"}
+            line["roofline_mfma"] = {"kernel": kern, "bound": "mfma", "achieved": round(mult * tf, 2), "peak": PEAK,
+                                     "unit": "TFLOP/s", "frac": round(mult * tf / PEAK, 4), "avg_launch_ms": round(gemm_ms, 4),
+                                     "flops_per_launch": mult * gemm_flops[0], "note": note}
+            if mult > 1:
+                line["roofline_mfma"]["fp32_equivalent"] = {"achieved": round(tf, 2), "peak": 157.3, "frac": round(tf / 157.3, 4),
+                                                            "flops_per_launch": gemm_flops[0]}
             if "gemm_ms" in alone:  # the same launch with the chip to itself (outside the timed region)
                 ta = gemm_flops[0] / (alone["gemm_ms"] * 1e-3) / 1e12
-                line["roofline_mfma"]["alone"] = {"launch_ms": round(alone["gemm_ms"], 4), "achieved": round(ta, 2),
-                                                  "frac": round(ta / 157.3, 4)}
+                line["roofline_mfma"]["alone"] = {"launch_ms": round(alone["gemm_ms"], 4), "achieved": round(mult * ta, 2),
+                                                  "frac": round(mult * ta / PEAK, 4)}
+                if mult > 1:
+                    line["roofline_mfma"]["alone"]["fp32_equivalent_frac"] = round(ta / 157.3, 4)
         if world == 1 and args.cpu_frames > 0:
             # torch's intra-op pool stops scaling (and then collapses) well below the box's core count on
             # these small ops: 16 threads measured fastest on the 256-core GPU host (8: 0.83, 16: 0.63,

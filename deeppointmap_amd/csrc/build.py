@@ -21,6 +21,7 @@ SOURCES = {
     "knn.hip": [],
     "encoder_ops.hip": [],
     "gemm.hip": [],
+    "gemm_b3.hip": [],
     "group_mlp.hip": [],
     "decoder_ops.hip": [],
     "match.hip": [],

@@ -1,0 +1,207 @@
+// fp32 GEMM through the bf16 matrix pipe: out = act(X W^T + bias + residual) with every fp32 operand split EXACTLY into
+// three bf16 terms and the product formed from the six term pairs that matter (round 4).
+//
+// Why: profiles/r04_corun.md -- on this chip a SIMD's time is (matrix-pipe busy) + (vector-ALU busy), the two never overlap,
+// so the cycles v_mfma_f32_16x16x4_f32 holds the matrix pipe (it runs at the fp32 VECTOR rate, 1/16 of the bf16 rate) are
+// cycles nothing else can use.  x = hi + mid + lo with hi / mid / lo the top, middle and bottom 8 bits of the 24-bit
+// significand, each a truncation, reproduces x bit for bit; a pair product of two bf16 values is exact in fp32;
+//     x w = hi hi + hi mid + mid hi + hi lo + lo hi + mid mid        (+ three terms below 2^-23 |x w|),
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16: six bf16 instructions of 4 passes do the work of eight fp32 ones of 8
+// passes -- 3/8 of the matrix-pipe time.  The result carries fp32-accumulation rounding like the kernels of gemm.hip (measured
+// against fp64 in tests/test_gpu_ops.py at the same error level) but not their bits: a layer uses ONE of the two kernels
+// whatever the batch it sees (ops.linear decides by layer shape, never by row count).
+//
+// Same structure as gemm_nt_mfma_kernel<64,64> on purpose (eight small workgroups per CU hide each other's latencies: the
+// 128 x 128 form of round 2 was faster alone and slower inside the pipeline): block tile 64 x 64, 4 waves as 2 x 2, wave tile
+// 32 x 32 = 2 x 2 blocks of 16 x 16; K-tile 32 = ONE bf16 instruction deep.  Weights arrive pre-split (dpm_split_bf16x3, once
+// per weight version), activations are split while they are staged: LDS holds three bf16 planes per operand, rows 80 bytes
+// apart (16-byte aligned ds_read_b128 fragments: a lane's 8 consecutive k), 30 720 B per workgroup.
+#include "dpm_common.h"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+__device__ __forceinline__ float b3_act(float v, int act) {
+    if (act == DPM_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == DPM_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+// x -> (hi, mid, lo) as the upper 16 bits of three floats; the split is exact (each term a truncation, each remainder exact)
+__device__ __forceinline__ void split3(float x, unsigned &hi, unsigned &mid, unsigned &lo) {
+    hi = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(hi);
+    mid = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(mid);
+    lo = __float_as_uint(r2) & 0xFFFF0000u;
+}
+// two such terms -> one dword holding [a | b] as consecutive bf16 (a at the lower address)
+__device__ __forceinline__ unsigned pack2(unsigned a, unsigned b) { return (a >> 16) | b; }
+
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ W, long long n, uint16_t *__restrict__ planes) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned h, m, l;
+    split3(W[i], h, m, l);
+    planes[i] = (uint16_t)(h >> 16), planes[n + i] = (uint16_t)(m >> 16), planes[2 * n + i] = (uint16_t)(l >> 16);
+}
+
+constexpr int B3_KT = 32, B3_LD = B3_KT + 8;   // K-tile, LDS row stride in bf16 (80 bytes)
+
+// BM x BN = 64 x 64 (wave tile 32 x 32 = 2 x 2 blocks) or 32 x 32 (one block per wave) for problems too small to fill the chip
+// with 64 x 64 tiles; an output element sees the same instructions in the same order either way (same bits).
+// XVEC: the rows of X are 16-byte aligned (false: four scalar loads per group -- a token matrix with rows of 131 floats must
+// take the same kernel as one with rows of 132, or a layer's bits would depend on how its input happens to be laid out)
+template <int BM, int BN, bool XVEC>
+__global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ Wp, int ldw,
+                                                      long long plane, const float *__restrict__ bias,
+                                                      const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo,
+                                                      int R, int Cin, int Cout, int act) {
+    constexpr int LDC = BN + 4, MB = BM / 32, NB = BN / 32, PX = BM / 32, WT = BN * 4;   // WT: threads that stage W (16 B each)
+    constexpr int SM = 3 * (BM + BN) * B3_LD;
+    static_assert(sizeof(uint16_t) * SM >= sizeof(float) * BM * LDC, "the staged output tile reuses the operand planes");
+    __shared__ __attribute__((aligned(16))) uint16_t smem[SM];   // 30 720 B at 64 x 64: X planes, then W planes
+    uint16_t (*Xs)[BM][B3_LD] = reinterpret_cast<uint16_t (*)[BM][B3_LD]>(smem);
+    uint16_t (*Ws)[BN][B3_LD] = reinterpret_cast<uint16_t (*)[BN][B3_LD]>(smem + 3 * BM * B3_LD);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+    int by = blockIdx.y, bx = blockIdx.x;
+    if ((gridDim.y & 7) == 0 && gridDim.y >= 64) {  // all column blocks of one row block on ONE XCD: its L2 serves X
+        const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, slot = L >> 3;
+        by = (int)((slot / gridDim.x) * 8 + xcd), bx = (int)(slot % gridDim.x);
+    }
+    const int row0 = by * BM, col0 = bx * BN;
+    // staging: X as fp32 float4 (PX per thread: rows xr_ + 32 p, 4 consecutive k), W planes as 8 bf16 = 16 bytes (one per plane
+    // per staging thread: row wr_, 8 consecutive k)
+    const int xr_ = t >> 3, xk = (t & 7) * 4, wr_ = min(t >> 2, BN - 1), wk = (t & 3) * 8;
+    const float *xp[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) xp[p] = X + (size_t)min(row0 + p * 32 + xr_, R - 1) * ldx + xk;
+    const uint16_t *wp = Wp + (size_t)min(col0 + wr_, Cout - 1) * ldw + wk;
+    auto load_x = [&](const float *p) {
+        if (XVEC) return *reinterpret_cast<const f32x4 *>(p);
+        return f32x4{p[0], p[1], p[2], p[3]};
+    };
+    f32x4 xv[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) xv[p] = load_x(xp[p]);
+    u32x4 w0 = *reinterpret_cast<const u32x4 *>(wp), w1 = *reinterpret_cast<const u32x4 *>(wp + plane),
+          w2 = *reinterpret_cast<const u32x4 *>(wp + 2 * plane);
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    auto stage_x = [&](const f32x4 &v, int r) {
+        unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+        split3(v[0], h0, m0, l0), split3(v[1], h1, m1, l1), split3(v[2], h2, m2, l2), split3(v[3], h3, m3, l3);
+        *reinterpret_cast<u32x2 *>(&Xs[0][r][xk]) = u32x2{pack2(h0, h1), pack2(h2, h3)};
+        *reinterpret_cast<u32x2 *>(&Xs[1][r][xk]) = u32x2{pack2(m0, m1), pack2(m2, m3)};
+        *reinterpret_cast<u32x2 *>(&Xs[2][r][xk]) = u32x2{pack2(l0, l1), pack2(l2, l3)};
+    };
+    for (int k0 = 0; k0 < Cin; k0 += B3_KT) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) stage_x(xv[p], p * 32 + xr_);
+        if (WT == 256 || t < WT) {
+            *reinterpret_cast<u32x4 *>(&Ws[0][wr_][wk]) = w0;
+            *reinterpret_cast<u32x4 *>(&Ws[1][wr_][wk]) = w1;
+            *reinterpret_cast<u32x4 *>(&Ws[2][wr_][wk]) = w2;
+        }
+        __syncthreads();
+        {   // the next K-tile is requested while this one feeds the MFMAs -- unconditionally (the last trip re-reads its own
+            // tile): behind a branch the prefetch group is serialised behind a full wait (gemm.hip, load4)
+            const int kn = min(k0 + B3_KT, Cin - B3_KT);
+#pragma unroll
+            for (int p = 0; p < PX; ++p) xv[p] = load_x(xp[p] + kn);
+            w0 = *reinterpret_cast<const u32x4 *>(wp + kn), w1 = *reinterpret_cast<const u32x4 *>(wp + plane + kn);
+            w2 = *reinterpret_cast<const u32x4 *>(wp + 2 * plane + kn);
+        }
+        bf16x8 a[3][NB], b[3][MB];   // a: W fragments (the instruction's A operand), b: X fragments
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) a[pl][j] = *reinterpret_cast<const bf16x8 *>(&Ws[pl][wn * (BN / 2) + j * 16 + fr][fk]);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) b[pl][i] = *reinterpret_cast<const bf16x8 *>(&Xs[pl][wm * (BM / 2) + i * 16 + fr][fk]);
+        }
+        // smallest terms first; (plane of W, plane of X): (1,1) (2,0) (0,2) (1,0) (0,1) (0,0)
+#define DPM_B3(PWQ, PXQ)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PWQ][j], b[PXQ][i], acc[i][j], 0, 0, 0)
+        DPM_B3(1, 1);
+        DPM_B3(2, 0);
+        DPM_B3(0, 2);
+        DPM_B3(1, 0);
+        DPM_B3(0, 1);
+        DPM_B3(0, 0);
+#undef DPM_B3
+        __syncthreads();
+    }
+    // D[m][n] with W as the A operand: n = lane & 15 -> output row, m = (lane >> 4) * 4 + reg -> output column: a lane owns
+    // four consecutive columns of one row.  The tile goes through LDS once more so that every store writes whole rows.
+    float *ct = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            *reinterpret_cast<float4 *>(&ct[(wm * (BM / 2) + i * 16 + (lane & 15)) * LDC + wn * (BN / 2) + j * 16 + (lane >> 4) * 4]) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    __syncthreads();
+    constexpr int TPR = BN / 4, RPS = 256 / TPR;   // threads per tile row, rows per store pass
+    const int cr = t / TPR, cc = (t % TPR) * 4, c = col0 + cc;
+    if (c < Cout) {   // Cout % 4 == 0 (dispatch): a thread's four columns exist together
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4 *>(bias + c);
+#pragma unroll
+        for (int p = 0; p < BM / RPS; ++p) {
+            const int r = row0 + p * RPS + cr;
+            if (r >= R) continue;
+            float4 v = *reinterpret_cast<const float4 *>(&ct[(p * RPS + cr) * LDC + cc]);
+            v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+            if (res) {
+                const float4 rv = *reinterpret_cast<const float4 *>(res + (size_t)r * ldr + c);
+                v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
+            }
+            v.x = b3_act(v.x, act), v.y = b3_act(v.y, act), v.z = b3_act(v.z, act), v.w = b3_act(v.w, act);
+            *reinterpret_cast<float4 *>(out + (size_t)r * ldo + c) = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dpm_split_bf16x3(const float *W, long long n, void *planes, dpm_stream_t stream) {
+    DPM_CHECK_ARG(W && planes && n >= 1);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(dpm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, W, n, (uint16_t *)planes);
+    return dpm_launch_status();
+}
+
+extern "C" int dpm_linear_bf16x3(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride, const float *bias,
+                                 const float *residual, int ldr, float *out, int ldo, int R, int Cin, int Cout, int act,
+                                 dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && w_planes && out && R >= 1 && Cin >= 1 && Cout >= 1 && ldx >= Cin && ldw >= Cin && ldo >= Cout);
+    DPM_CHECK_ARG(act >= DPM_ACT_NONE && act <= DPM_ACT_SIGMOID && (!residual || ldr >= Cout) && plane_stride >= (long long)Cout * ldw);
+    auto al = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+    if (Cin % B3_KT != 0 || Cout % 4 != 0 || ldw % 8 != 0 || plane_stride % 8 != 0 || ldo % 4 != 0 || !al(w_planes) || !al(out) ||
+        !al(bias) || (residual && (!al(residual) || ldr % 4 != 0)))
+        return DPM_EUNSUPPORTED;
+    const bool xvec = ldx % 4 == 0 && al(x);
+    // tile choice as in dpm_linear: 64 x 64 from 192 such tiles on (or tall problems), 32 x 32 below -- the bits do not depend on it
+    const long long big = (long long)dpm_cdiv(R, 64) * dpm_cdiv(Cout, 64);
+#define DPM_B3_LAUNCH(T, V)                                                                                                   \
+    hipLaunchKernelGGL((gemm_b3_kernel<T, T, V>), dim3(dpm_cdiv(Cout, T), dpm_cdiv(R, T)), dim3(256), 0, (hipStream_t)stream, x, ldx, \
+                       (const uint16_t *)w_planes, ldw, plane_stride, bias, residual, ldr, out, ldo, R, Cin, Cout, act)
+    if (big >= 192 || (R > 1024 && Cout > 32)) {
+        if (xvec) DPM_B3_LAUNCH(64, true);
+        else DPM_B3_LAUNCH(64, false);
+    } else {
+        if (xvec) DPM_B3_LAUNCH(32, true);
+        else DPM_B3_LAUNCH(32, false);
+    }
+#undef DPM_B3_LAUNCH
+    return dpm_launch_status();
+}

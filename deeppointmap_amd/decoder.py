@@ -38,7 +38,7 @@ class Decoder(ParamTree):
         self.attention_layers = self.decoder_cfg.attention_layers
         self.tau = args.loss.tau
         self._dim_t: Dict[str, torch.Tensor] = {}
-        self.fused_match = True   # similarity -> dual softmax -> top-k as one operator where it applies (ops.match_supported)
+        self.fused_match = knobs.FUSED_MATCH   # similarity -> dual softmax -> top-k as one operator where it applies (ops.match_supported)
         self.stack_sides = True   # M != N: one launch per row-wise layer over both sides (False: the per-side loop)
         # pair lists over shared frames: per-frame work once per frame (False: per pair side, A/B runs)
         self.dedup_frames = knobs.DEDUP_FRAMES

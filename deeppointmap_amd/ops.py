@@ -280,10 +280,14 @@ def _derived(tag: str, sources, make):
     dev = sources[0].device
     cur = torch.cuda.current_stream(dev)
     if torch.cuda.is_current_stream_capturing():
-        # Inside a capture nothing of this cache may be touched: a tensor made here would live in the graph's private pool,
-        # hold no data until the first replay and be published to eager callers with a captured event; a hit would make the
-        # capture wait on an event recorded outside it.  Code paths that are captured (Decoder._register) use no derived
-        # tensors; one that starts to must make them before the capture.
+        # Inside a capture the cache is read-only: a tensor MADE here would live in the graph's private pool, hold no data
+        # until the first replay and be published to eager callers with a captured event; and a hit must not make the
+        # capture wait on an event recorded outside it -- it has to be complete already (Decoder captures a shape only after
+        # eager calls of the same shape, which made every derived tensor of the path long before).
+        with _DERIVED_LOCK:
+            hit = _DERIVED.get(key)
+            if hit is not None and hit[1] == stamp and all(r() is t for r, t in zip(hit[0], sources)) and hit[3].query():
+                return hit[2]
         raise RuntimeError(f"ops._derived({tag!r}) under stream capture: make weight-derived tensors before capturing")
     with _DERIVED_LOCK:
         hit = _DERIVED.get(key)
@@ -358,8 +362,8 @@ def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radi
     if not fused and Cout in (32, 64, 128):
         W2 = W.reshape(Cout, Cin + 3)
         A, cvec = _derived("affine-stage0", (W, W0, b0, bias), lambda: (
-            linear(W2[:, :Cin], W0.reshape(Cin, 3).t().contiguous()),                     # (Cout,3) = W_f W0
-            linear(W2[:, :Cin], b0.reshape(1, Cin), residual=bias.reshape(Cout, 1))))     # (Cout,1) = W_f b0 + b
+            linear(W2[:, :Cin], W0.reshape(Cin, 3).t().contiguous(), exact=True),                     # (Cout,3) = W_f W0
+            linear(W2[:, :Cin], b0.reshape(1, Cin), residual=bias.reshape(Cout, 1), exact=True)))     # (Cout,1) = W_f b0 + b
         _lib.check(_lib.load().dpm_group_affine_ln_max(_ptr(A), _ptr(cvec), _ptr(xyz), _ptr(centers), _ptr(idx),
                                                        W2.data_ptr() + 4 * Cin, Cin + 3, _ptr(gamma), _ptr(beta), B, N, S,
                                                        K, Cout, float(radius), _ptr(out), _stream(xyz)),
@@ -372,14 +376,24 @@ def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radi
     return out
 
 
+BF16X3_MAX_K = 512   # layers up to this reduction length take the bf16x3 kernel (longer ones are the encoder's few-row tails)
+
+
 def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, exact: bool = False) -> torch.Tensor:
     """x (..., Cin) (last dim contiguous rows), W (Cout, Cin[,1[,1]]) -> (..., Cout).
 
-    `out` may be a column slice of a wider row-major buffer (its row stride is honoured)."""
+    `out` may be a column slice of a wider row-major buffer (its row stride is honoured).
+    Which of the two GEMM kernels runs is a property of the LAYER (its Cin, Cout and the `exact` request), never of the row
+    count: a frame's result does not depend on the batch it travels in.  exact=True: the fp32-MFMA kernel (callers whose
+    result must equal another kernel's bit for bit: linear_layernorm's two-kernel form against its fused form)."""
     if W.dtype != torch.float32 or not W.is_cuda:
         raise ValueError("W must be an fp32 GPU tensor")
     Cout, Cin = W.shape[0], W.shape[1]
+    if knobs.GEMM_BF16X3 and not exact and Cin % 32 == 0 and Cin <= BF16X3_MAX_K and Cout % 4 == 0 and W.numel() == Cout * Cin:
+        done = linear_bf16x3(x, W, bias, act, residual, out)
+        if done is not None:
+            return done
     if W.dim() == 2 and W.stride(1) == 1 and W.stride(0) >= Cin:
         ldw = W.stride(0)      # a column range of a wider weight matrix (e.g. the feature columns of a Conv2d weight)
     else:
@@ -403,6 +417,60 @@ def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     _lib.check(_lib.load().dpm_linear(_ptr(x2), x2.stride(0), _ptr(W), ldw, _ptr(bias), _ptr(r2),
                                       Cout if r2 is not None else 0, _ptr(o2), o2.stride(0), R, Cin, Cout, act,
                                       _stream(x)), "dpm_linear")
+    return out
+
+
+def _weight_planes(W: torch.Tensor):
+    """The three bf16 planes (hi | mid | lo, csrc/gemm_b3.hip) of the PARAMETER a weight (view) belongs to, made once per
+    weight version, and where W's first row sits in them: -> (planes (3, n) int16, element offset, plane stride n), or None
+    when W is not a block of whole rows of a contiguous fp32 tensor."""
+    base = W._base if W._base is not None else W
+    Cin = W.shape[1]
+    W2 = W if W.dim() == 2 else W.reshape(W.shape[0], Cin)
+    if (base.dtype != torch.float32 or not base.is_cuda or not base.is_contiguous() or W2.stride(1) != 1 or
+            W2.stride(0) != Cin or base.numel() % 8 != 0):
+        return None
+    off = W2.storage_offset() - base.storage_offset()
+    if off < 0 or off + W2.numel() > base.numel():
+        return None
+
+    def make():
+        planes = torch.empty(3, base.numel(), device=base.device, dtype=torch.int16)
+        _lib.check(_lib.load().dpm_split_bf16x3(_ptr(base), base.numel(), _ptr(planes), _stream(base)), "dpm_split_bf16x3")
+        return planes
+    return _derived("bf16x3-planes", (base,), make), off, base.numel()
+
+
+def linear_bf16x3(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+                  residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """linear() on the bf16 matrix pipe: every fp32 operand split exactly into three bf16 terms, six term products
+    accumulated in fp32 (csrc/gemm_b3.hip; fp32-accumulation accuracy, not the fp32 kernel's bits).  Returns None when the
+    shape / layout is not covered (the caller runs linear())."""
+    Cout, Cin = W.shape[0], W.shape[1]
+    if Cin % 32 != 0 or Cout % 4 != 0 or x.dtype != torch.float32 or not x.is_cuda or x.stride(-1) != 1:
+        return None
+    if bias is not None and bias.data_ptr() % 16:
+        return None
+    wp = _weight_planes(W)
+    if wp is None:
+        return None
+    planes, off, n = wp
+    x2 = x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x
+    if x2.dim() != 2:
+        return None
+    if out is None:
+        out = torch.empty(*x.shape[:-1], Cout, device=x.device, dtype=torch.float32)
+    o2 = out.reshape(-1, Cout) if out.is_contiguous() else out
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, Cout)
+        _chk(r2, torch.float32, "residual")
+    st = _lib.load().dpm_linear_bf16x3(_ptr(x2), x2.stride(0), planes.data_ptr() + 2 * off, Cin, n, _ptr(bias), _ptr(r2),
+                                       Cout if r2 is not None else 0, _ptr(o2), o2.stride(0), x2.shape[0], Cin, Cout, act,
+                                       _stream(x))
+    if st == -2:
+        return None
+    _lib.check(st, "dpm_linear_bf16x3")
     return out
 
 
@@ -463,7 +531,7 @@ def linear_layernorm(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tens
             return out
         if st != -2:  # anything but "unsupported shape"
             _lib.check(st, "dpm_linear_layernorm")
-    y = linear(x, W, bias, residual=pre)
+    y = linear(x, W, bias, residual=pre, exact=True)   # the fused kernel's arithmetic: same bits in either form
     return layernorm(y, gamma, beta, act=act, post=post)
 
 

@@ -301,6 +301,19 @@ int dpm_attention_split(const float *Q, int ldq, long long sq, const float *K, i
                         int ldv, long long sv, float *out, int ldo, long long so, int B, int M, int N, int heads,
                         int head_dim, int kv_shift, int nsplit, void *workspace, dpm_stream_t stream);
 
+/* The same contraction as dpm_linear (Conv1d(k=1) / nn.Linear: network/encoder/utils.py:358-389, the decoder's projections
+ * and heads) on the bf16 matrix pipe with every fp32 operand split exactly into three bf16 terms and six of the nine term
+ * products accumulated in fp32 (the three dropped ones are below 2^-23 of the product): fp32-accumulation accuracy at 3/8 of
+ * the matrix-pipe time of the exact-fp32 instruction (csrc/gemm_b3.hip).  dpm_split_bf16x3 makes the weight planes once per
+ * weight version: planes = 3 x n bf16 (hi | mid | lo), plane p of element i at planes[p * n + i].  dpm_linear_bf16x3 takes a row
+ * block of such planes: w_planes -> plane 0 of the first weight row, rows ldw elements apart, planes plane_stride elements
+ * apart.  DPM_EUNSUPPORTED for Cin % 32 != 0, Cout % 4 != 0 or unaligned bias / residual / output (x may have any row stride);
+ * a caller that falls back to dpm_linear then must do so for EVERY call of that layer (the two kernels differ in the last bits). */
+int dpm_split_bf16x3(const float *W, long long n, void *planes, dpm_stream_t stream);
+int dpm_linear_bf16x3(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride, const float *bias,
+                      const float *residual, int ldr, float *out, int ldo, int R, int Cin, int Cout, int act,
+                      dpm_stream_t stream);
+
 /* F.normalize(x, p=2, dim=-1) (decoder.py:185): x / max(||x||, 1e-12), rows (R,C). */
 int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stream);
 

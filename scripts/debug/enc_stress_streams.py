@@ -1,0 +1,68 @@
+"""debug: ONE process, two HIP streams: the reduced encoder over and over on one stream (every pass must equal the first bit
+for bit) while another stream runs a GEMM loop -- bf16x3 (`1`) or fp32 MFMA (`0`).  Companion of enc_stress.py, where a bf16x3
+GEMM in ANOTHER process makes the first-level gather kernel return a few wrong elements once in ~250 passes."""
+import os, sys, threading
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root)
+import torch
+from deeppointmap_amd import knobs, ops, synthetic
+from deeppointmap_amd.config import reduced_args
+from deeppointmap_amd.encoder import Encoder
+from deeppointmap_amd.weights import init_procedural
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "1"   # 1: both bf16x3 tile variants, allocating; 64 / 32: one variant into a guarded preallocated buffer; 0: fp32
+noise_b3 = mode != "0"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+knobs.GEMM_BF16X3 = False          # the encoder under test runs fp32 GEMMs only
+enc = init_procedural(Encoder(reduced_args())).to(dev)
+pts, pad = synthetic.frames(4, 8192, start=40)
+x = torch.randn(4096, 256, device=dev); W = torch.randn(768, 256, device=dev) / 16; b = torch.randn(768, device=dev)
+xs = torch.randn(512, 32, device=dev); Ws = torch.randn(32, 32, device=dev); bs = torch.randn(32, device=dev)
+stop = False
+
+
+GUARD = 64
+buf64 = torch.zeros(4096 + 2 * GUARD, 768, device=dev)
+buf32 = torch.zeros(512 + 2 * GUARD, 32, device=dev)
+
+
+def noise():
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        while not stop:
+            for _ in range(20):
+                if mode == "1":
+                    ops.linear_bf16x3(x, W, b), ops.linear_bf16x3(xs, Ws, bs)
+                elif mode == "64":
+                    ops.linear_bf16x3(x, W, b, out=buf64[GUARD:GUARD + 4096])
+                elif mode == "32":
+                    ops.linear_bf16x3(xs, Ws, bs, out=buf32[GUARD:GUARD + 512])
+                else:
+                    ops.linear(x, W, b, exact=True), ops.linear(xs, Ws, bs, exact=True)
+            s.synchronize()
+
+
+th = threading.Thread(target=noise); th.start()
+first, bad, firsts, alld = {}, [], {}, {}
+for it in range(iters):
+    f = it % 4
+    tr = {}
+    out = enc(pts[f:f + 1], pad[f:f + 1], trace=tr, descriptor_scale=60.0)
+    snap = {k: (torch.sort(v, dim=-1).values if k.endswith(".idx") and not k.endswith("fps.idx") else v.clone()) for k, v in tr.items() if isinstance(v, torch.Tensor)}
+    snap["desc"] = out.clone()
+    if f not in first:
+        first[f] = snap
+    else:
+        ks = [k for k in snap if not torch.equal(snap[k], first[f][k])]
+        if ks:
+            bad.append((it, f, ks[0], int((snap[ks[0]] != first[f][ks[0]]).sum())))
+            firsts[ks[0]] = firsts.get(ks[0], 0) + 1
+            # is the FIRST differing tensor the only root?  recompute nothing, just list which keys differ
+            alld[tuple(ks[:3])] = alld.get(tuple(ks[:3]), 0) + 1
+stop = True; th.join()
+g64 = float(buf64[:GUARD].abs().sum() + buf64[GUARD + 4096:].abs().sum()); g32 = float(buf32[:GUARD].abs().sum() + buf32[GUARD + 512:].abs().sum())
+print(f"mode {mode} guards touched: {g64} {g32};", end=" ")
+print("first differing tensor:", firsts, "| leading differing keys:", alld)
+print(f"noise stream: {'bf16x3' if noise_b3 else 'fp32 MFMA'} GEMMs; {len(bad)} of {iters} encoder passes differ from the first: {bad[:6]}")

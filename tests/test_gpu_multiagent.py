@@ -67,6 +67,7 @@ def _cloud_summary(cloud):
     b = cloud.backend
     toks = sorted(b.poses)
     return dict(arrivals=list(cloud.arrivals), tokens=toks, poses=torch.stack([b.poses[t] for t in toks]).numpy(),
+                desc=torch.stack([b.desc[t].cpu() for t in toks]).numpy(),
                 coor=[b.coor[t] for t in toks], edges=[(a, c, e["type"]) for (a, c), e in b.edges.items()],
                 edge_SE3=np.stack([e["SE3"].numpy() for e in b.edges.values()]), stats=dict(b.stats))
 
@@ -150,7 +151,9 @@ def test_two_agents_and_a_cloud_equal_one_process():
     want = _cloud_summary(cloud)
     assert got["tokens"] == want["tokens"] and got["edges"] == want["edges"] and got["stats"] == want["stats"]
     assert got["coor"] == want["coor"]
-    assert np.array_equal(got["poses"], want["poses"]) and np.array_equal(got["edge_SE3"], want["edge_SE3"])
+    assert np.array_equal(got["desc"], want["desc"]), f"the agents' descriptors differ by {np.abs(got['desc'] - want['desc']).max():.3e}"
+    dp, de = float(np.abs(got["poses"] - want["poses"]).max()), float(np.abs(got["edge_SE3"] - want["edge_SE3"]).max())
+    assert dp == 0.0 and de == 0.0, f"cloud of ranks vs one process: poses differ by {dp:.3e}, edge transforms by {de:.3e}"
     # the traffic did what config 5 is about: loops between the agents were closed, the optimiser ran over both agents'
     # key-frames and their coordinate systems became one
     cross = [(a, b) for a, b, ty in want["edges"] if ty == "loop" and (a >> 16) != (b >> 16)]

@@ -326,6 +326,49 @@ def test_fused_linear_layernorm_kernel_vs_torch(ops, monkeypatch):
         assert torch.equal(fused, split), key
 
 
+def test_bf16x3_linear_vs_fp64_and_layout_independence(ops, monkeypatch):
+    """The bf16x3 GEMM (csrc/gemm_b3.hip: every fp32 operand split exactly into three bf16 terms, six term products accumulated
+    in fp32) is what ops.linear runs for layers with K <= 512 when knobs.GEMM_BF16X3 is set: (i) its error against fp64 is at the level of the exact-fp32 MFMA
+    kernel's (the tolerance every other GEMM test uses), also on values spanning many binades; (ii) a row's bits do not depend
+    on the tile variant (row count), the row stride of the input (131- against 132-float token rows), a weight being a row block
+    of a larger parameter, or the batch the row travels in."""
+    from deeppointmap_amd import knobs
+    monkeypatch.setattr(knobs, "GEMM_BF16X3", True)   # opt-in (knobs.py says why): the kernel and its dispatch are tested all the same
+    gen = torch.Generator(device=DEV).manual_seed(31)
+    for R, Cin, Cout, relu in [(32768, 256, 768, False), (1000, 96, 132, True), (257, 512, 256, True), (70000, 32, 32, False),
+                               (64, 128, 512, False), (3, 64, 4, True)]:
+        x = torch.randn(R, Cin, device=DEV, generator=gen) * torch.exp2(torch.randint(-12, 12, (R, 1), device=DEV, generator=gen).float())
+        W = torch.randn(Cout, Cin, device=DEV, generator=gen) / Cin ** 0.5
+        b, res = torch.randn(Cout, device=DEV, generator=gen), torch.randn(R, Cout, device=DEV, generator=gen)
+        y3 = ops.linear(x, W, b, act=ops.ACT_RELU if relu else ops.ACT_NONE, residual=res)
+        y32 = ops.linear(x, W, b, act=ops.ACT_RELU if relu else ops.ACT_NONE, residual=res, exact=True)
+        assert not torch.equal(y3, y32) or R < 8          # (two different kernels ran)
+        n = min(R, 2048)
+        want = x[:n].double() @ W.double().t() + b.double() + res[:n].double()
+        want = torch.relu(want) if relu else want
+        scale = (x[:n].double().abs() @ W.double().abs().t()) + 1.0     # size of the terms that were summed
+        e3 = ((y3[:n].double() - want).abs() / scale).max()
+        e32 = ((y32[:n].double() - want).abs() / scale).max()
+        assert float(e3) < 4e-7 and float(e3) < 2.0 * float(e32) + 1e-8, (R, Cin, Cout, float(e3), float(e32))
+    x = torch.randn(4096, 256, device=DEV, generator=gen)
+    W = torch.randn(768, 256, device=DEV, generator=gen) / 16
+    b = torch.randn(768, device=DEV, generator=gen)
+    big = ops.linear(x, W, b)
+    assert torch.equal(ops.linear(x[:256].contiguous(), W, b), big[:256])          # 32 x 32 tiles against 64 x 64
+    assert torch.equal(ops.linear(x[1000:2280].contiguous(), W, b), big[1000:2280])
+    assert torch.equal(ops.linear(x, W[256:], b[256:]), big[:, 256:])               # row block of the parameter: the same planes
+    wide = torch.zeros(4096, 259, device=DEV)                                       # rows of 259 floats: scalar loads
+    wide[:, :256] = x
+    assert torch.equal(ops.linear(wide[:, :256], W, b), big)
+    wide2 = torch.zeros(4096, 260, device=DEV)
+    wide2[:, 4:] = x
+    assert torch.equal(ops.linear(wide2[:, 4:], W, b), big)
+    # weights edited in place: the planes follow
+    with torch.no_grad():
+        W.mul_(0.5)
+    torch.testing.assert_close(ops.linear(x, W, b), (big - b) * 0.5 + b, rtol=1e-5, atol=1e-5)
+
+
 def test_linear_large_tiles_vs_torch(ops):
     """The shapes that take the 128x128 persistent kernel (K >= 1024, >= 512 output tiles) and the 64x64 kernel's
     staged epilogue with ragged edges, against an fp64 product."""
