@@ -13,8 +13,13 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "libdpm_hip.so")
 ARCH = "gfx950"
+# -packed-fp32-ops off: no v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 anywhere.  Round 4 found that a wave's packed fp32
+# instructions return wrong results now and then while ANOTHER wave on the chip -- another stream, even another process --
+# executes v_mfma_f32_16x16x32_bf16 (scripts/debug/enc_stress*.py, scripts/micro/pk_vs_mfma.hip: the encoder's first-level
+# gather kernel, 52 packed instructions, lost a few maxima in up to 30 % of its launches next to the bf16x3 GEMM; recompiled
+# without them: 0 of 1 200).  The packed forms buy 1.15-1.2x on the multiply-adds they cover (scripts/micro/pk_fma_rate.hip).
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-          "-ffp-contract=off"]
+          "-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 SOURCES = {
     "fps.hip": [],
     "fps_tree.hip": [],

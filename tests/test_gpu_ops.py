@@ -333,7 +333,7 @@ def test_bf16x3_linear_vs_fp64_and_layout_independence(ops, monkeypatch):
     on the tile variant (row count), the row stride of the input (131- against 132-float token rows), a weight being a row block
     of a larger parameter, or the batch the row travels in."""
     from deeppointmap_amd import knobs
-    monkeypatch.setattr(knobs, "GEMM_BF16X3", True)   # opt-in (knobs.py says why): the kernel and its dispatch are tested all the same
+    monkeypatch.setattr(knobs, "GEMM_BF16X3", True)
     gen = torch.Generator(device=DEV).manual_seed(31)
     for R, Cin, Cout, relu in [(32768, 256, 768, False), (1000, 96, 132, True), (257, 512, 256, True), (70000, 32, 32, False),
                                (64, 128, 512, False), (3, 64, 4, True)]:
