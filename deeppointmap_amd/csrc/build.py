@@ -13,11 +13,17 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "libdpm_hip.so")
 ARCH = "gfx950"
-# -packed-fp32-ops off: no v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 anywhere.  Round 4 found that a wave's packed fp32
-# instructions return wrong results now and then while ANOTHER wave on the chip -- another stream, even another process --
-# executes v_mfma_f32_16x16x32_bf16 (scripts/debug/enc_stress*.py, scripts/micro/pk_vs_mfma.hip: the encoder's first-level
-# gather kernel, 52 packed instructions, lost a few maxima in up to 30 % of its launches next to the bf16x3 GEMM; recompiled
-# without them: 0 of 1 200).  The packed forms buy 1.15-1.2x on the multiply-adds they cover (scripts/micro/pk_fma_rate.hip).
+# -packed-fp32-ops off: no v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 anywhere.  Round 4: with the packed forms compiled in
+# (hipcc 7.2 packs adjacent fp32 multiply-adds on its own; the encoder's first-level gather kernel held 52 of them) that kernel
+# returned a few wrong maxima in a few rows in up to 40 % of its launches WHILE ANOTHER WAVE ON THE CHIP EXECUTED bf16 MATRIX
+# INSTRUCTIONS -- the bf16x3 GEMM on another stream, in another process on the same GPU, even a register-only MFMA
+# micro-benchmark in another process -- and never otherwise (fp32 MFMA neighbours: 0 of 2 400 passes).  Same source without
+# the packed forms: 0 of 1 800 passes, 0 of 15 runs of the three-process test that had failed one time in five
+# (scripts/debug/enc_stress.py, enc_stress_streams.py, sa0_forensics.py).  NOT understood further: a register-only
+# v_pk_fma_f32 loop next to MFMA waves computes correctly (scripts/micro/pk_vs_mfma.hip), longer wait states in front of the
+# kernel's hand-written DPP steps change nothing -- it is the compiled sequence around the packed forms, not the instruction
+# alone.  They buy 1.15-1.2x on the multiply-adds they cover (scripts/micro/pk_fma_rate.hip) and nothing in the pipelined bench
+# (4.74 ms per step without them, 4.79 with, fp32 GEMMs both times).
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 SOURCES = {
