@@ -55,6 +55,7 @@ SIGNATURES = {
     "dpm_linear_batched": (I, [P, I, LL, P, I, LL, P, P, I, LL, P, I, LL, I, I, I, I, I, P]),
     "dpm_split_bf16x3": (I, [P, LL, P, P]),
     "dpm_linear_bf16x3": (I, [P, I, P, I, LL, P, P, I, P, I, I, I, I, I, P]),
+    "dpm_linear_layernorm_bf16x3": (I, [P, I, P, I, LL, P, P, P, P, P, P, I, I, I, I, I, P]),
     "dpm_layernorm": (I, [P, I, P, P, P, P, P, I, I, I, I, P]),
     "dpm_linear_layernorm": (I, [P, I, P, I, P, P, P, P, P, P, I, I, I, I, I, P]),
     "dpm_three_interp_cat": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),

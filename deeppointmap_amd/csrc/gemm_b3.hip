@@ -172,6 +172,148 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
     }
 }
 
+// GEMM + LayerNorm in one kernel on the bf16x3 product (the fp32 form: gemm_ln_kernel, gemm.hip): out = act(LN(X W^T + bias +
+// pre) * gamma + beta + post) for layers whose output row fits one workgroup (Cout = BN in {32, 64, 128, 256}).  The main loop
+// is gemm_b3_kernel's (same instructions in the same order per output element, so the pre-norm values are the plain kernel's
+// bits and the two-kernel form -- dpm_linear_bf16x3 + dpm_layernorm -- gives identical rows); WGM x WGN waves of (BM / WGM) x
+// (BN / WGN), 512 threads at 256 columns.  The epilogue stages the whole tile in LDS (inside the operand planes' footprint)
+// and normalises it row-wise with the lane-group arithmetic of layernorm_vec_kernel / gemm_ln_kernel.
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_ln_b3_kernel(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ Wp,
+                                                                   int ldw, long long plane, const float *__restrict__ bias,
+                                                                   const float *__restrict__ pre, const float *__restrict__ gamma,
+                                                                   const float *__restrict__ beta, const float *__restrict__ post,
+                                                                   float *__restrict__ out, int ldo, int R, int Cin, int act) {
+    constexpr int T = 64 * WGM * WGN, WM = BM / WGM, WN = BN / WGN, MB = WM / 16, NB = WN / 16, LDC = BN + 4;
+    constexpr int XF = BM * 8, PX = (XF + T - 1) / T;          // float4 groups of the X tile, per thread
+    constexpr int WF = BN * 4, PW = (WF + T - 1) / T;          // 16-byte groups of one W plane tile, per thread
+    constexpr int SM = 3 * (BM + BN) * B3_LD;
+    static_assert(MB >= 1 && NB >= 1 && sizeof(uint16_t) * SM >= sizeof(float) * BM * LDC, "tile shape / staged output tile");
+    __shared__ __attribute__((aligned(16))) uint16_t smem[SM];
+    uint16_t (*Xs)[BM][B3_LD] = reinterpret_cast<uint16_t (*)[BM][B3_LD]>(smem);
+    uint16_t (*Ws)[BN][B3_LD] = reinterpret_cast<uint16_t (*)[BN][B3_LD]>(smem + 3 * BM * B3_LD);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w / WGN, wn = w % WGN;
+    const int row0 = blockIdx.x * BM;
+    const float *xp[PX];
+    int xrow[PX], xk[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        const int g = min(p * T + t, XF - 1);
+        xrow[p] = g >> 3, xk[p] = (g & 7) * 4;
+        xp[p] = X + (size_t)min(row0 + xrow[p], R - 1) * ldx + xk[p];
+    }
+    const uint16_t *wp[PW];
+    int wrow[PW], wk[PW];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) {
+        const int g = min(p * T + t, WF - 1);
+        wrow[p] = g >> 2, wk[p] = (g & 3) * 8;
+        wp[p] = Wp + (size_t)wrow[p] * ldw + wk[p];
+    }
+    f32x4 xv[PX];
+    u32x4 wv[PW][3];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) xv[p] = *reinterpret_cast<const f32x4 *>(xp[p]);
+#pragma unroll
+    for (int p = 0; p < PW; ++p)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wv[p][pl] = *reinterpret_cast<const u32x4 *>(wp[p] + pl * plane);
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    for (int k0 = 0; k0 < Cin; k0 += B3_KT) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            if (XF % T == 0 || p * T + t < XF) {
+                unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+                split3(xv[p][0], h0, m0, l0), split3(xv[p][1], h1, m1, l1), split3(xv[p][2], h2, m2, l2), split3(xv[p][3], h3, m3, l3);
+                *reinterpret_cast<u32x2 *>(&Xs[0][xrow[p]][xk[p]]) = u32x2{pack2(h0, h1), pack2(h2, h3)};
+                *reinterpret_cast<u32x2 *>(&Xs[1][xrow[p]][xk[p]]) = u32x2{pack2(m0, m1), pack2(m2, m3)};
+                *reinterpret_cast<u32x2 *>(&Xs[2][xrow[p]][xk[p]]) = u32x2{pack2(l0, l1), pack2(l2, l3)};
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            if (WF % T == 0 || p * T + t < WF) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(&Ws[pl][wrow[p]][wk[p]]) = wv[p][pl];
+            }
+        }
+        __syncthreads();
+        {
+            const int kn = min(k0 + B3_KT, Cin - B3_KT);   // unconditional prefetch (the last trip re-reads its own tile)
+#pragma unroll
+            for (int p = 0; p < PX; ++p) xv[p] = *reinterpret_cast<const f32x4 *>(xp[p] + kn);
+#pragma unroll
+            for (int p = 0; p < PW; ++p)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wv[p][pl] = *reinterpret_cast<const u32x4 *>(wp[p] + pl * plane + kn);
+        }
+        bf16x8 a[3][NB], b[3][MB];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) a[pl][j] = *reinterpret_cast<const bf16x8 *>(&Ws[pl][wn * WN + j * 16 + fr][fk]);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) b[pl][i] = *reinterpret_cast<const bf16x8 *>(&Xs[pl][wm * WM + i * 16 + fr][fk]);
+        }
+#define DPM_B3(PWQ, PXQ)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PWQ][j], b[PXQ][i], acc[i][j], 0, 0, 0)
+        DPM_B3(1, 1);
+        DPM_B3(2, 0);
+        DPM_B3(0, 2);
+        DPM_B3(1, 0);
+        DPM_B3(0, 1);
+        DPM_B3(0, 0);
+#undef DPM_B3
+        __syncthreads();
+    }
+    float *ct = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            *reinterpret_cast<float4 *>(&ct[(wm * WM + i * 16 + (lane & 15)) * LDC + wn * WN + j * 16 + (lane >> 4) * 4]) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    __syncthreads();
+    // row-wise: G = BN / 4 lanes hold one row (a float4 each); the two LayerNorm sums are lane-group reductions, neighbours
+    // first -- the association of layernorm_vec_kernel and gemm_ln_kernel (bit-identical rows in every form)
+    constexpr int G = BN / 4, RPS = T / G;
+    const int cr = t / G, cc = (t % G) * 4;
+    const float4 bv = bias ? *reinterpret_cast<const float4 *>(bias + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g4 = *reinterpret_cast<const float4 *>(gamma + cc), b4 = *reinterpret_cast<const float4 *>(beta + cc);
+    auto gsum = [](float v) {
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, 64);
+        return v;
+    };
+#pragma unroll 4
+    for (int p = 0; p < BM / RPS; ++p) {
+        const int r = row0 + p * RPS + cr, rr = min(r, R - 1);
+        float4 v = *reinterpret_cast<const float4 *>(&ct[(p * RPS + cr) * LDC + cc]);
+        v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+        if (pre) {
+            const float4 pv = *reinterpret_cast<const float4 *>(pre + (size_t)rr * BN + cc);
+            v.x += pv.x, v.y += pv.y, v.z += pv.z, v.w += pv.w;
+        }
+        const float mu = gsum((v.x + v.y) + (v.z + v.w)) / (float)BN;
+        v.x -= mu, v.y -= mu, v.z -= mu, v.w -= mu;
+        const float rs = rsqrtf(gsum(fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)))) / (float)BN + 1e-5f);
+        float4 o = make_float4(fmaf(v.x * rs, g4.x, b4.x), fmaf(v.y * rs, g4.y, b4.y), fmaf(v.z * rs, g4.z, b4.z),
+                               fmaf(v.w * rs, g4.w, b4.w));
+        if (post) {
+            const float4 pv = *reinterpret_cast<const float4 *>(post + (size_t)rr * BN + cc);
+            o.x += pv.x, o.y += pv.y, o.z += pv.z, o.w += pv.w;
+        }
+        o.x = b3_act(o.x, act), o.y = b3_act(o.y, act), o.z = b3_act(o.z, act), o.w = b3_act(o.w, act);
+        if (r < R) *reinterpret_cast<float4 *>(out + (size_t)r * ldo + cc) = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int dpm_split_bf16x3(const float *W, long long n, void *planes, dpm_stream_t stream) {
@@ -203,5 +345,31 @@ extern "C" int dpm_linear_bf16x3(const float *x, int ldx, const void *w_planes, 
         else DPM_B3_LAUNCH(32, false);
     }
 #undef DPM_B3_LAUNCH
+    return dpm_launch_status();
+}
+
+// dpm_linear_layernorm on the bf16x3 product: same contract (pre / post packed (R, Cout), Cout in {32, 64, 128, 256}), weights as
+// the planes of dpm_split_bf16x3.  DPM_EUNSUPPORTED for other widths, Cin % 32 != 0 or unaligned operands: the caller then runs
+// dpm_linear_bf16x3 + dpm_layernorm (identical rows).
+extern "C" int dpm_linear_layernorm_bf16x3(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride,
+                                           const float *bias, const float *pre, const float *gamma, const float *beta,
+                                           const float *post, float *out, int ldo, int R, int Cin, int Cout, int act,
+                                           dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && w_planes && gamma && beta && out && R >= 1 && Cin >= 1 && Cout >= 1 && ldx >= Cin && ldw >= Cin && ldo >= Cout);
+    DPM_CHECK_ARG(act >= DPM_ACT_NONE && act <= DPM_ACT_SIGMOID && plane_stride >= (long long)Cout * ldw);
+    auto al = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+    if (Cin % B3_KT != 0 || ldx % 4 != 0 || ldw % 8 != 0 || plane_stride % 8 != 0 || ldo % 4 != 0 || !al(x) || !al(w_planes) ||
+        !al(bias) || !al(pre) || !al(gamma) || !al(beta) || !al(post) || !al(out))
+        return DPM_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+#define DPM_GLN3(BM, BN, WGM, WGN)                                                                                             \
+    hipLaunchKernelGGL((gemm_ln_b3_kernel<BM, BN, WGM, WGN>), dim3(dpm_cdiv(R, BM)), dim3(64 * WGM * WGN), 0, st, x, ldx,           \
+                       (const uint16_t *)w_planes, ldw, plane_stride, bias, pre, gamma, beta, post, out, ldo, R, Cin, act)
+    if (Cout == 256) DPM_GLN3(64, 256, 2, 4);
+    else if (Cout == 128) DPM_GLN3(64, 128, 2, 2);
+    else if (Cout == 64) DPM_GLN3(64, 64, 2, 2);
+    else if (Cout == 32) DPM_GLN3(64, 32, 2, 2);
+    else return DPM_EUNSUPPORTED;
+#undef DPM_GLN3
     return dpm_launch_status();
 }

@@ -16,11 +16,16 @@ FUSED_LN = True        # False: Linear + LayerNorm as two kernels at every size 
 # alone, +2.7 % frames/s in the pipelined bench, error against fp64 at the fp32 kernel's level.  False: the fp32-MFMA kernel
 # everywhere.  (The library is compiled without packed fp32 instructions because of this kernel: csrc/build.py says why.)
 GEMM_BF16X3 = True
+# ... and the Linear + LayerNorm layers with 128 <= K <= 512 (both forms: fused gemm_ln_b3_kernel / GEMM + LayerNorm, identical
+# rows).  Off: the fused kernel is 25 % faster alone on the decoder's 32 768 x 256 -> 256 blocks (44 against 59 us) and the
+# pipelined step is LONGER with it (4.555 against 4.52 ms, three alternating 40-step runs): 512 threads and 77 KB of LDS per
+# workgroup against the fp32 form's 256 threads and 39 KB (scripts/gemm_ln_b3_check.py).
+GEMM_LN_BF16X3 = False
 FUSED_MATCH = True     # similarity -> dual softmax -> top-k as one operator (csrc/match.hip) where it applies; False: the five-launch form
 DEDUP_FRAMES = True    # False: per-frame decoder work once per pair side instead of once per frame (new Decoder objects)
 
 _ENV = {"DPM_FPS_ALGO": ("FPS_ALGO", int), "DPM_NO_FUSED_LN": ("FUSED_LN", lambda v: v != "1"),
-        "DPM_DEDUP_FRAMES": ("DEDUP_FRAMES", lambda v: v != "0"), "DPM_GEMM_BF16X3": ("GEMM_BF16X3", lambda v: v == "1"),
+        "DPM_DEDUP_FRAMES": ("DEDUP_FRAMES", lambda v: v != "0"), "DPM_GEMM_BF16X3": ("GEMM_BF16X3", lambda v: v == "1"), "DPM_GEMM_LN_BF16X3": ("GEMM_LN_BF16X3", lambda v: v == "1"),
         "DPM_FUSED_MATCH": ("FUSED_MATCH", lambda v: v != "0")}
 
 

@@ -376,6 +376,7 @@ def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radi
     return out
 
 
+BF16X3_LN_MIN_K = 128
 BF16X3_MAX_K = 512   # layers up to this reduction length take the bf16x3 kernel (longer ones are the encoder's few-row tails)
 
 
@@ -513,6 +514,31 @@ def linear_layernorm(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tens
     to the summation order of the row statistics)."""
     Cout, Cin = W.shape[0], W.shape[1]
     x2 = x.reshape(-1, x.shape[-1])
+    # Layers the bf16x3 kernel covers (a property of the layer: K <= 512 in whole K-tiles, whole weight rows) take it in BOTH forms
+    # -- fused from FUSED_LN_MIN_ROWS rows on, GEMM + LayerNorm below -- with identical rows either way
+    # (from K = 128 on: with shorter reductions the kernels are bound by their epilogues and the fp32 form's smaller row tiles win)
+    if (knobs.GEMM_BF16X3 and knobs.GEMM_LN_BF16X3 and Cin % 32 == 0 and BF16X3_LN_MIN_K <= Cin <= BF16X3_MAX_K and Cout % 4 == 0 and W.numel() == Cout * Cin
+            and x.dtype == torch.float32):
+        wp = _weight_planes(W)
+        if wp is not None and (bias is None or bias.data_ptr() % 16 == 0):
+            if Cout in FUSED_LN_WIDTHS and x2.shape[0] >= FUSED_LN_MIN_ROWS and x2.is_contiguous() and knobs.FUSED_LN:
+                planes, off, n = wp
+                out = torch.empty(*x.shape[:-1], Cout, device=x.device, dtype=torch.float32)
+                for nm, t in (("pre", pre), ("post", post)):
+                    if t is not None:
+                        _chk(t, torch.float32, nm)
+                        if t.numel() != out.numel():
+                            raise ValueError(f"{nm} must have the shape of the output")
+                st = _lib.load().dpm_linear_layernorm_bf16x3(_ptr(x2), x2.stride(0), planes.data_ptr() + 2 * off, Cin, n, _ptr(bias),
+                                                             _ptr(pre), _ptr(gamma), _ptr(beta), _ptr(post), _ptr(out), Cout,
+                                                             x2.shape[0], Cin, Cout, act, _stream(x))
+                if st == 0:
+                    return out
+                if st != -2:
+                    _lib.check(st, "dpm_linear_layernorm_bf16x3")
+            y = linear_bf16x3(x, W, bias, residual=pre)
+            if y is not None:
+                return layernorm(y, gamma, beta, act=act, post=post)
     # the fused kernel owns whole output rows (64 rows per workgroup): below FUSED_LN_MIN_ROWS it leaves most of the 256
     # compute units idle and the two-kernel form is 1.5-2.8x faster (scripts/gemm_ln_shapes.py: 4096 x 1024 -> 256 takes
     # 86 us fused, 31 us as GEMM + LayerNorm)

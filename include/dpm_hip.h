@@ -313,6 +313,12 @@ int dpm_split_bf16x3(const float *W, long long n, void *planes, dpm_stream_t str
 int dpm_linear_bf16x3(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride, const float *bias,
                       const float *residual, int ldr, float *out, int ldo, int R, int Cin, int Cout, int act,
                       dpm_stream_t stream);
+/* dpm_linear_layernorm (Conv1d(k=1) / Linear + LayerNorm1d, network/encoder/utils.py:358-413, descriptor_attention.py:36-48)
+ * on the bf16x3 product, weights as planes of dpm_split_bf16x3; rows identical to dpm_linear_bf16x3 followed by dpm_layernorm.
+ * DPM_EUNSUPPORTED for Cout outside {32, 64, 128, 256}, Cin % 32 != 0 or unaligned operands. */
+int dpm_linear_layernorm_bf16x3(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride,
+                                const float *bias, const float *pre, const float *gamma, const float *beta, const float *post,
+                                float *out, int ldo, int R, int Cin, int Cout, int act, dpm_stream_t stream);
 
 /* F.normalize(x, p=2, dim=-1) (decoder.py:185): x / max(||x||, 1e-12), rows (R,C). */
 int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stream);

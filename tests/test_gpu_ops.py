@@ -296,10 +296,13 @@ def test_linear_layernorm_interp_vs_torch(ops):
         torch.testing.assert_close(y, want, rtol=1e-5, atol=2e-5)
 
 
-def test_fused_linear_layernorm_kernel_vs_torch(ops, monkeypatch):
+@pytest.mark.parametrize("ln_b3", [False, True])
+def test_fused_linear_layernorm_kernel_vs_torch(ops, monkeypatch, ln_b3):
     """dpm_linear_layernorm (GEMM with the LayerNorm in its epilogue) at every fused width, ragged row counts, with and
     without the pre / post residuals -- the row threshold of ops.linear_layernorm lifted so that small inputs reach it --
     and the two-kernel form the wrapper takes below the threshold, both against an fp64 reference."""
+    from deeppointmap_amd import knobs
+    monkeypatch.setattr(knobs, "GEMM_LN_BF16X3", ln_b3)   # True: the bf16x3 forms for 128 <= K <= 512 (opt-in, knobs.py)
     gen = torch.Generator(device=DEV).manual_seed(9)
     both = {}
     for min_rows in (0, 1 << 30):
