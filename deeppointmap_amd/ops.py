@@ -680,11 +680,15 @@ def dual_softmax_topk(S: torch.Tensor, tau: float, k: int):
 
 
 MATCH_MAX_N, MATCH_MAX_K = 256, 2048   # dpm_match_topk: columns one workgroup holds, pairs its lists hold
+MATCH_MAX_MERGE = 8192                 # candidates (strips x k) the last workgroup of a pair merges
 
 
 def match_supported(M: int, N: int, C: int, k: int) -> bool:
     """shapes dpm_match_topk takes (a function of ONE pair's shape, never of the batch)"""
-    return N <= MATCH_MAX_N and k <= MATCH_MAX_K and C % 32 == 0 and 1 <= k <= M * N and M <= 64 * 65535
+    # ... and few enough row strips that ONE workgroup merges their candidates quickly: a 4096 x 256 map tile (64 strips x 1088
+    # candidates) spent 485 us in that merge against ~200 us for the whole five-kernel form
+    strips = -(-M // 64)
+    return (N <= MATCH_MAX_N and k <= MATCH_MAX_K and C % 32 == 0 and 1 <= k <= M * N and strips * min(k, 64 * N) <= MATCH_MAX_MERGE)
 
 
 def match_topk(a: torch.Tensor, b: torch.Tensor, tau: float, k: int):
