@@ -37,10 +37,11 @@ __device__ __forceinline__ void split3(float x, unsigned &hi, unsigned &mid, uns
     const float r1 = x - __uint_as_float(hi);
     mid = __float_as_uint(r1) & 0xFFFF0000u;
     const float r2 = r1 - __uint_as_float(mid);
-    lo = __float_as_uint(r2) & 0xFFFF0000u;
+    lo = __float_as_uint(r2);   // the truncation to 16 bits happens where the term is stored (pack2 / the plane store)
 }
-// two such terms -> one dword holding [a | b] as consecutive bf16 (a at the lower address)
-__device__ __forceinline__ unsigned pack2(unsigned a, unsigned b) { return (a >> 16) | b; }
+// two such terms -> one dword holding [a | b] as consecutive bf16 (a at the lower address): the upper halves of both
+// registers in one v_perm_b32
+__device__ __forceinline__ unsigned pack2(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ W, long long n, uint16_t *__restrict__ planes) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -120,6 +121,8 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
             w0 = *reinterpret_cast<const u32x4 *>(wp + kn), w1 = *reinterpret_cast<const u32x4 *>(wp + plane + kn);
             w2 = *reinterpret_cast<const u32x4 *>(wp + 2 * plane + kn);
         }
+        // (the scheduler sinks these loads below the matrix instructions to save 20 registers; pinning them up here with
+        // sched_barrier(0) was measured -- 116 us alone either way, 4.47 against 4.48 ms per pipelined step -- and not kept)
         bf16x8 a[3][NB], b[3][MB];   // a: W fragments (the instruction's A operand), b: X fragments
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {

@@ -24,6 +24,7 @@ constexpr int MT_KCAP = 2048;                                  // largest k of t
 constexpr int MT_SMEM = (MT_ROWS + MT_COLS) * MT_LD;           // floats: 43 520 B of operand tiles
 constexpr int MT_PLD = MT_COLS + 4;                            // row stride of the P tile in LDS
 constexpr int MT_SMEM2 = MT_ROWS * MT_PLD + 2 * MT_KCAP;       // second kernel: P tile (over the dead operand tiles) + lists
+constexpr int MT_MCAP = MT_ROWS * MT_PLD / 2;                  // candidates (value, index) the dead P tile holds for the merge: 8 320
 static_assert(MT_SMEM2 >= MT_SMEM && MT_SMEM >= 2 * MT_COLS, "the P tile and the column statistics reuse the operand tiles");
 
 struct MatchWs {
@@ -200,9 +201,10 @@ __device__ __forceinline__ void pick_bin(const unsigned *hist, unsigned *sc /* [
 
 // items(f): calls f(value bits, flat index) for each of the thread's valid items (values >= 0: their bit patterns order
 // like the floats).  Leaves the k largest -- ties at the k-th value resolved toward smaller flat indices -- sorted
-// (value descending, index ascending) in sv / si.  k <= number of valid items, k <= MT_KCAP.
+// (value descending, index ascending) in sv / si -- or, with sorted == false, in arbitrary order (a strip's candidates: the
+// merge selects and sorts again).  k <= number of valid items, k <= MT_KCAP.
 template <class Items>
-__device__ __forceinline__ void block_topk(Items &&items, int k, float *sv, int *si, unsigned *hist, unsigned *sc) {
+__device__ __forceinline__ void block_topk(Items &&items, int k, float *sv, int *si, unsigned *hist, unsigned *sc, bool sorted) {
     const int t = threadIdx.x;
     auto select = [&](auto &&key_of, auto &&member, bool desc, unsigned want) {
         // 4 x 8-bit MSB radix select of the want-th key in walking order among the items with member(u, idx)
@@ -246,15 +248,23 @@ __device__ __forceinline__ void block_topk(Items &&items, int k, float *sv, int 
     if (t == 0) sc[4] = 0u;
     int np2 = 1;
     while (np2 < k) np2 <<= 1;
-    for (int e = k + t; e < np2; e += MT_T) sv[e] = -1.f, si[e] = 0x7fffffff;
+    if (sorted)
+        for (int e = k + t; e < np2; e += MT_T) sv[e] = -1.f, si[e] = 0x7fffffff;
     __syncthreads();
-    items([&](unsigned u, int idx) {
-        if (u > thr || (u == thr && (unsigned)idx <= ithr)) {
-            const unsigned p = atomicAdd(&sc[4], 1u);
-            sv[p] = __uint_as_float(u), si[p] = idx;
-        }
+    const int lane = t & 63;
+    items([&](unsigned u, int idx) {   // one counter update per wave and step, not one per survivor
+        const bool take = u > thr || (u == thr && (unsigned)idx <= ithr);
+        const unsigned long long m = __ballot(take);
+        if (!take) return;
+        const int leader = __builtin_ctzll(m);
+        unsigned base = 0u;
+        if (lane == leader) base = atomicAdd(&sc[4], (unsigned)__builtin_popcountll(m));
+        base = (unsigned)__shfl((int)base, leader, 64);
+        const unsigned p = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        sv[p] = __uint_as_float(u), si[p] = idx;
     });
     __syncthreads();
+    if (!sorted) return;
     for (int size = 2; size <= np2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int e = t; e < np2 / 2; e += MT_T) {
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(MT_T) void match_topk_kernel(const float *__restric
         if (t < N)
             for (int r = 0; r < rows_here; ++r) f(__float_as_uint(pt[r * MT_PLD + t]), (row0 + r) * N + t);
     };
-    block_topk(tile_items, kl, sv, si, hist, sc);
+    block_topk(tile_items, kl, sv, si, hist, sc, strips == 1);
     if (strips == 1) {
         for (int e = t; e < k; e += MT_T) out_v[(size_t)pair * k + e] = sv[e], out_i[(size_t)pair * k + e] = si[e];
         return;
@@ -345,6 +355,35 @@ __global__ __launch_bounds__(MT_T) void match_topk_kernel(const float *__restric
     const float *av = ws.cand_v + (size_t)pair * strips * kcap;
     const int *ai = ws.cand_i + (size_t)pair * strips * kcap;
     const int last_rows = M - (strips - 1) * MT_ROWS, kl_last = min(k, last_rows * N);
+    const int total = (strips - 1) * kcap + kl_last;   // the lists lie back to back, only the last one is short
+    if (total <= MT_MCAP) {
+        // the candidates once through LDS (over the dead P tile), every load of a thread in flight together: the selection's
+        // five walks over memory with agent-scope loads were most of this kernel's time
+        float *mv = pt;
+        int *mi = reinterpret_cast<int *>(pt + MT_MCAP);
+        for (int e0 = 0; e0 < total; e0 += 8 * MT_T) {
+            float v[8];
+            int ix[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = min(e0 + q * MT_T + t, total - 1);
+                v[q] = __hip_atomic_load(av + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ix[q] = __hip_atomic_load(ai + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + q * MT_T + t;
+                if (e < total) mv[e] = v[q], mi[e] = ix[q];
+            }
+        }
+        __syncthreads();
+        auto lds_items = [&](auto &&f) {
+            for (int e = t; e < total; e += MT_T) f(__float_as_uint(mv[e]), mi[e]);
+        };
+        block_topk(lds_items, k, sv, si, hist, sc, true);
+        for (int e = t; e < k; e += MT_T) out_v[(size_t)pair * k + e] = sv[e], out_i[(size_t)pair * k + e] = si[e];
+        return;
+    }
     auto mem_items = [&](auto &&f) {
         for (int s = 0; s < strips; ++s) {
             const int n_s = s == strips - 1 ? kl_last : kcap;
@@ -357,7 +396,7 @@ __global__ __launch_bounds__(MT_T) void match_topk_kernel(const float *__restric
         }
     };
     __syncthreads();
-    block_topk(mem_items, k, sv, si, hist, sc);
+    block_topk(mem_items, k, sv, si, hist, sc, true);
     for (int e = t; e < k; e += MT_T) out_v[(size_t)pair * k + e] = sv[e], out_i[(size_t)pair * k + e] = si[e];
 }
 

@@ -27,14 +27,14 @@ for R, K, N in [(32768, 256, 768), (16384, 256, 768), (32768, 256, 256), (32768,
     W = torch.randn(N, K, device=dev) / K ** 0.5
     b = torch.randn(N, device=dev)
     res = torch.randn(R, N, device=dev)
-    o32 = ops.linear(x, W, b, act=ops.ACT_RELU, residual=res)
+    o32 = ops.linear(x, W, b, act=ops.ACT_RELU, residual=res, exact=True)
     o3 = ops.linear_bf16x3(x, W, b, act=ops.ACT_RELU, residual=res)
     assert o3 is not None, (R, K, N)
     n = min(R, 512)
     ref = torch.relu(x[:n].double() @ W.double().t() + b.double() + res[:n].double())
     e32, e3 = (o32[:n].double() - ref).abs(), (o3[:n].double() - ref).abs()
     out = torch.empty(R, N, device=dev)
-    t32 = timed(lambda: ops.linear(x, W, b, out=out))
+    t32 = timed(lambda: ops.linear(x, W, b, out=out, exact=True))
     t3 = timed(lambda: ops.linear_bf16x3(x, W, b, out=out))
     print(f"| {R} | {K} | {N} | {t32:.1f} | {2 * R * K * N / t32 / 1e6:.1f} | {t3:.1f} | {2 * R * K * N / t3 / 1e6:.1f} | {float(e32.max()):.2e} | "
           f"{float(e3.max()):.2e} | {float((e3.pow(2).mean() / e32.pow(2).mean()).sqrt()):.2f} |")
