@@ -181,20 +181,24 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
 // bits and the two-kernel form -- dpm_linear_bf16x3 + dpm_layernorm -- gives identical rows); WGM x WGN waves of (BM / WGM) x
 // (BN / WGN), 512 threads at 256 columns.  The epilogue stages the whole tile in LDS (inside the operand planes' footprint)
 // and normalises it row-wise with the lane-group arithmetic of layernorm_vec_kernel / gemm_ln_kernel.
-template <int BM, int BN, int WGM, int WGN>
+// NP > 1: the BN columns in NP passes of BN / NP over the same rows (X staged and split again per pass, W tile and LDS footprint
+// 1 / NP as large, the accumulators of all passes kept): 32 x 256 with NP = 2 has gemm_b3_kernel's loop, wave tile and 38 KB.
+template <int BM, int BN, int WGM, int WGN, int NP = 1>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_ln_b3_kernel(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ Wp,
                                                                    int ldw, long long plane, const float *__restrict__ bias,
                                                                    const float *__restrict__ pre, const float *__restrict__ gamma,
                                                                    const float *__restrict__ beta, const float *__restrict__ post,
                                                                    float *__restrict__ out, int ldo, int R, int Cin, int act) {
-    constexpr int T = 64 * WGM * WGN, WM = BM / WGM, WN = BN / WGN, MB = WM / 16, NB = WN / 16, LDC = BN + 4;
+    constexpr int BNP = BN / NP;                               // columns per pass
+    constexpr int T = 64 * WGM * WGN, WM = BM / WGM, WN = BNP / WGN, MB = WM / 16, NB = WN / 16, LDC = BN + 4;
     constexpr int XF = BM * 8, PX = (XF + T - 1) / T;          // float4 groups of the X tile, per thread
-    constexpr int WF = BN * 4, PW = (WF + T - 1) / T;          // 16-byte groups of one W plane tile, per thread
-    constexpr int SM = 3 * (BM + BN) * B3_LD;
-    static_assert(MB >= 1 && NB >= 1 && sizeof(uint16_t) * SM >= sizeof(float) * BM * LDC, "tile shape / staged output tile");
+    constexpr int WF = BNP * 4, PW = (WF + T - 1) / T;         // 16-byte groups of one W plane tile, per thread
+    constexpr int SM = 3 * (BM + BNP) * B3_LD;
+    static_assert(MB >= 1 && NB >= 1 && BN % NP == 0 && sizeof(uint16_t) * SM >= sizeof(float) * BM * LDC,
+                  "tile shape / staged output tile");
     __shared__ __attribute__((aligned(16))) uint16_t smem[SM];
     uint16_t (*Xs)[BM][B3_LD] = reinterpret_cast<uint16_t (*)[BM][B3_LD]>(smem);
-    uint16_t (*Ws)[BN][B3_LD] = reinterpret_cast<uint16_t (*)[BN][B3_LD]>(smem + 3 * BM * B3_LD);
+    uint16_t (*Ws)[BNP][B3_LD] = reinterpret_cast<uint16_t (*)[BNP][B3_LD]>(smem + 3 * BM * B3_LD);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w / WGN, wn = w % WGN;
     const int row0 = blockIdx.x * BM;
     const float *xp[PX];
@@ -221,12 +225,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_ln_b3_kernel(const float 
     for (int p = 0; p < PW; ++p)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) wv[p][pl] = *reinterpret_cast<const u32x4 *>(wp[p] + pl * plane);
-    f32x4 acc[MB][NB];
+    f32x4 acc[NP][MB][NB];
 #pragma unroll
-    for (int i = 0; i < MB; ++i)
+    for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[ps][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = (lane >> 4) * 8;
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps)
     for (int k0 = 0; k0 < Cin; k0 += B3_KT) {
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
@@ -247,13 +255,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_ln_b3_kernel(const float 
         }
         __syncthreads();
         {
-            const int kn = min(k0 + B3_KT, Cin - B3_KT);   // unconditional prefetch (the last trip re-reads its own tile)
+            // unconditional prefetch: the next K-tile of this pass, the first one of the next pass, or (the very last trip)
+            // its own tile again
+            const bool wrap = k0 + B3_KT >= Cin && ps + 1 < NP;
+            const int kn = wrap ? 0 : min(k0 + B3_KT, Cin - B3_KT);
+            const size_t wo = (size_t)(wrap ? ps + 1 : ps) * BNP * ldw + kn;
 #pragma unroll
             for (int p = 0; p < PX; ++p) xv[p] = *reinterpret_cast<const f32x4 *>(xp[p] + kn);
 #pragma unroll
             for (int p = 0; p < PW; ++p)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wv[p][pl] = *reinterpret_cast<const u32x4 *>(wp[p] + pl * plane + kn);
+                for (int pl = 0; pl < 3; ++pl) wv[p][pl] = *reinterpret_cast<const u32x4 *>(wp[p] + pl * plane + wo);
         }
         bf16x8 a[3][NB], b[3][MB];
 #pragma unroll
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_ln_b3_kernel(const float 
         }
 #define DPM_B3(PWQ, PXQ)                                                                                   \
     _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)        \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PWQ][j], b[PXQ][i], acc[i][j], 0, 0, 0)
+        acc[ps][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PWQ][j], b[PXQ][i], acc[ps][i][j], 0, 0, 0)
         DPM_B3(1, 1);
         DPM_B3(2, 0);
         DPM_B3(0, 2);
@@ -277,11 +289,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_ln_b3_kernel(const float 
     }
     float *ct = reinterpret_cast<float *>(smem);
 #pragma unroll
-    for (int i = 0; i < MB; ++i)
+    for (int ps = 0; ps < NP; ++ps)
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-            *reinterpret_cast<float4 *>(&ct[(wm * WM + i * 16 + (lane & 15)) * LDC + wn * WN + j * 16 + (lane >> 4) * 4]) =
-                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                *reinterpret_cast<float4 *>(&ct[(wm * WM + i * 16 + (lane & 15)) * LDC + ps * BNP + wn * WN + j * 16 + (lane >> 4) * 4]) =
+                    make_float4(acc[ps][i][j][0], acc[ps][i][j][1], acc[ps][i][j][2], acc[ps][i][j][3]);
     __syncthreads();
     // row-wise: G = BN / 4 lanes hold one row (a float4 each); the two LayerNorm sums are lane-group reductions, neighbours
     // first -- the association of layernorm_vec_kernel and gemm_ln_kernel (bit-identical rows in every form)
@@ -365,13 +379,18 @@ extern "C" int dpm_linear_layernorm_bf16x3(const float *x, int ldx, const void *
         !al(bias) || !al(pre) || !al(gamma) || !al(beta) || !al(post) || !al(out))
         return DPM_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-#define DPM_GLN3(BM, BN, WGM, WGN)                                                                                             \
-    hipLaunchKernelGGL((gemm_ln_b3_kernel<BM, BN, WGM, WGN>), dim3(dpm_cdiv(R, BM)), dim3(64 * WGM * WGN), 0, st, x, ldx,           \
+#define DPM_GLN3(BM, BN, WGM, WGN, NP)                                                                                         \
+    hipLaunchKernelGGL((gemm_ln_b3_kernel<BM, BN, WGM, WGN, NP>), dim3(dpm_cdiv(R, BM)), dim3(64 * WGM * WGN), 0, st, x, ldx,       \
                        (const uint16_t *)w_planes, ldw, plane_stride, bias, pre, gamma, beta, post, out, ldo, R, Cin, act)
-    if (Cout == 256) DPM_GLN3(64, 256, 2, 4);
-    else if (Cout == 128) DPM_GLN3(64, 128, 2, 2);
-    else if (Cout == 64) DPM_GLN3(64, 64, 2, 2);
-    else if (Cout == 32) DPM_GLN3(64, 32, 2, 2);
+    // every configuration gives the same bits (same instructions in the same order per output element).  256 columns: two
+    // passes of 128 over 32 rows -- 256 threads and 38 KB per workgroup; the one-pass 64 x 256 form (512 threads, 77 KB) was
+    // faster alone and slower inside the pipeline
+    if (Cout == 256) {
+        if (dpm_knob("DPM_GLN3_WIDE", 0)) DPM_GLN3(64, 256, 2, 4, 1);
+        else DPM_GLN3(32, 256, 1, 4, 2);
+    } else if (Cout == 128) DPM_GLN3(64, 128, 2, 2, 1);
+    else if (Cout == 64) DPM_GLN3(64, 64, 2, 2, 1);
+    else if (Cout == 32) DPM_GLN3(64, 32, 2, 2, 1);
     else return DPM_EUNSUPPORTED;
 #undef DPM_GLN3
     return dpm_launch_status();

@@ -17,10 +17,11 @@ FUSED_LN = True        # False: Linear + LayerNorm as two kernels at every size 
 # everywhere.  (The library is compiled without packed fp32 instructions because of this kernel: csrc/build.py says why.)
 GEMM_BF16X3 = True
 # ... and the Linear + LayerNorm layers with 128 <= K <= 512 (both forms: fused gemm_ln_b3_kernel / GEMM + LayerNorm, identical
-# rows).  Off: the fused kernel is 25 % faster alone on the decoder's 32 768 x 256 -> 256 blocks (44 against 59 us) and the
-# pipelined step is LONGER with it (4.555 against 4.52 ms, three alternating 40-step runs): 512 threads and 77 KB of LDS per
-# workgroup against the fp32 form's 256 threads and 39 KB (scripts/gemm_ln_b3_check.py).
-GEMM_LN_BF16X3 = False
+# rows).  At 256 columns the fused kernel makes two passes of 128 columns over 32 rows (256 threads, 38 KB of LDS: the fp32
+# form's footprint): 56 against 59 us alone on the decoder's 32 768 x 256 -> 256 blocks, 4.48 against 4.52 ms per pipelined step
+# (four alternating 60-step runs each: fewer matrix-pipe cycles are what counts next to the feature stage).  The one-pass
+# 64 x 256 form (512 threads, 77 KB) was 44 us alone and made the pipelined step LONGER (4.555 against 4.52 ms).
+GEMM_LN_BF16X3 = True
 FUSED_MATCH = True     # similarity -> dual softmax -> top-k as one operator (csrc/match.hip) where it applies; False: the five-launch form
 DEDUP_FRAMES = True    # False: per-frame decoder work once per pair side instead of once per frame (new Decoder objects)
 

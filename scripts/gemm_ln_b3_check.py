@@ -29,7 +29,7 @@ for R, K, N in [(32768, 256, 256), (16384, 256, 256), (65536, 64, 256), (262144,
     z = torch.nn.functional.layer_norm(x[:n].double() @ W.double().t() + b.double() + pre[:n].double(), (N,), gm.double(), bt.double(), 1e-5) + post[:n].double()
     res = {}
     for b3 in (False, True):
-        knobs.GEMM_BF16X3 = b3
+        knobs.GEMM_BF16X3 = knobs.GEMM_LN_BF16X3 = b3
         y = ops.linear_layernorm(x, W, b, gm, bt, pre=pre, post=post)
         res[b3] = (timed(lambda: ops.linear_layernorm(x, W, b, gm, bt, pre=pre, post=post)), float((y[:n].double() - z).abs().max()), y)
     knobs.FUSED_LN = False
