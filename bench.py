@@ -420,8 +420,9 @@ def main():
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" + (" (Linear / Conv1d layers with K <= 512 as exact three-way bf16 splits: 6 bf16 products per fp32 "
-                              "product, fp32 accumulate -- fp32 accuracy, bf16 matrix pipe; all else fp32)" if knobs.GEMM_BF16X3 else ""),
+            "dtype": "f32 (attention scores K Q^T" + (", Linear / Conv1d layers with K <= 512" if knobs.GEMM_BF16X3 else "") +
+                     " as exact three-way bf16 splits: 6 bf16 products per fp32 product, fp32 accumulate -- fp32 accuracy, bf16 matrix "
+                     "pipe; all else fp32)",
             "data": "synthetic",
             "config": {"workload": f"synthetic {F}x{N}-pt scans per GPU: Encoder.forward + consecutive-frame "
                                    "registration_forward (256x256) + information matrix per frame",

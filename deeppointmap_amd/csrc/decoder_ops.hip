@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256) void posemb_kernel(const float *__restrict__ x
 constexpr int HD = 32;
 constexpr int RES_HDR = 20;  // floats before the inlier-confidence list in a Kabsch `result`
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
 // max / sum over the 16 lanes of a DPP row (lanes sharing lane>>4).  Written out as one DPP-operand instruction
 // per step: from update_dpp + fmaxf the compiler builds copy + s_nop + mov_dpp + canonicalise + max.  s_nop 1 = the
@@ -107,7 +110,13 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
                                                         float *__restrict__ part_ml = nullptr,
                                                         const int32_t *__restrict__ seq = nullptr) {
     constexpr int TK = 64;                 // keys per tile
-    __shared__ __attribute__((aligned(16))) float Ks[TK][HD + 2];  // A operand of S^T: A[i=key][k=d] = Ks[key][d]
+    // A operand of S^T = K Q^T, which runs as an exact bf16x3 product (round 4; gemm_b3.hip has the arithmetic: both operands
+    // split into three bf16 terms, six term products per score, fp32 accumulate -- 3/8 of the exact-fp32 instruction's
+    // matrix-pipe time at the same accuracy): three bf16 planes of the K tile, rows 80 bytes apart (16-byte aligned fragment
+    // reads: a lane's 8 consecutive d), A[i=key][k=d] = Ks3[plane][key][d].  HD = 32 is ONE instruction deep.
+    constexpr int KLD = HD + 8;
+    static_assert(HD == 32, "the score product is one v_mfma_f32_16x16x32_bf16 deep");
+    __shared__ __attribute__((aligned(16))) uint16_t Ks3[3][TK][KLD];
     // A operand of O^T: A[i=d][k=key] = Vs[key][d].  Row stride 36: 16-byte aligned rows, and the four lane groups of
     // a fragment read (rows 4 apart) land 16 banks apart -- every bank serves exactly two lanes, the b32 minimum.
     __shared__ __attribute__((aligned(16))) float Vs[TK][HD + 4];
@@ -135,13 +144,18 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
     const float *Kb = Kp + (size_t)bk * sk + h * HD;
     const float *Vb = V + (size_t)bk * sv + h * HD;
 
-    // Q^T fragments (B operand: B[k=lane>>4][j=lane&15] = Q[query lane&15][d = 4 ks + (lane>>4)]), pre-scaled
-    float qa[QT][HD / 4];
+    // Q^T fragments (B operand: B[k = 8 g + e][j = lane&15] = Q[query lane&15][d = 8 g + e]), pre-scaled, split once
+    bf16x8 qb[QT][3];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         const int qr = min(q0 + 16 * u + (lane & 15), M - 1);
+        const float *qp = Qb + (size_t)qr * ldq + 8 * g;
+        unsigned hh[8], mm[8], ll[8];
 #pragma unroll
-        for (int ks = 0; ks < HD / 4; ++ks) qa[u][ks] = Qb[(size_t)qr * ldq + ks * 4 + g] * scale;
+        for (int e = 0; e < 8; ++e) split3(qp[e] * scale, hh[e], mm[e], ll[e]);
+        qb[u][0] = __builtin_bit_cast(bf16x8, u32x4{pack2(hh[0], hh[1]), pack2(hh[2], hh[3]), pack2(hh[4], hh[5]), pack2(hh[6], hh[7])});
+        qb[u][1] = __builtin_bit_cast(bf16x8, u32x4{pack2(mm[0], mm[1]), pack2(mm[2], mm[3]), pack2(mm[4], mm[5]), pack2(mm[6], mm[7])});
+        qb[u][2] = __builtin_bit_cast(bf16x8, u32x4{pack2(ll[0], ll[1]), pack2(ll[2], ll[3]), pack2(ll[4], ll[5]), pack2(ll[6], ll[7])});
     }
     f32x4 oacc[QT][2];  // O^T[d = 16 jd + 4 g + q][query 16 u + lane&15]
     float mrow[QT], lrow[QT];  // running max / this lane's share of the sum, query 16 u + lane&15
@@ -173,27 +187,41 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int e = t + p * 256, kr = e >> 3, c4 = (e & 7) * 4;
-            float2 *kd = reinterpret_cast<float2 *>(&Ks[kr][c4]);  // row stride 136 B: 8-byte aligned
-            kd[0] = make_float2(kreg[p].x, kreg[p].y), kd[1] = make_float2(kreg[p].z, kreg[p].w);
+            unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+            split3(kreg[p].x, h0, m0, l0), split3(kreg[p].y, h1, m1, l1), split3(kreg[p].z, h2, m2, l2), split3(kreg[p].w, h3, m3, l3);
+            *reinterpret_cast<u32x2 *>(&Ks3[0][kr][c4]) = u32x2{pack2(h0, h1), pack2(h2, h3)};
+            *reinterpret_cast<u32x2 *>(&Ks3[1][kr][c4]) = u32x2{pack2(m0, m1), pack2(m2, m3)};
+            *reinterpret_cast<u32x2 *>(&Ks3[2][kr][c4]) = u32x2{pack2(l0, l1), pack2(l2, l3)};
             *reinterpret_cast<float4 *>(&Vs[kr][c4]) = vreg[p];     // row stride 144 B: 16-byte aligned
         }
         __syncthreads();
         if (n0 + TK < n_end) fetch(n0 + TK);
-        // S^T tile: 64 keys x 16 queries = 4 MFMA blocks (16 keys each), 8 k-steps over d
+        // S^T tile: 64 keys x 16 queries = 4 MFMA blocks (16 keys each), each six bf16 instructions (smallest terms first;
+        // (plane of K, plane of Q): (1,1) (2,0) (0,2) (1,0) (0,1) (0,0)); two key blocks at a time, so that 2 QT independent
+        // accumulators lie between two instructions on the same one
         f32x4 sacc[QT][4];
 #pragma unroll
         for (int u = 0; u < QT; ++u)
 #pragma unroll
             for (int j = 0; j < 4; ++j) sacc[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < HD / 4; ++ks) {
+        for (int jp = 0; jp < 4; jp += 2) {
+            bf16x8 ka[2][3];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float ak = Ks[j * 16 + (lane & 15)][ks * 4 + g];
+            for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int u = 0; u < QT; ++u)
-                    sacc[u][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, qa[u][ks], sacc[u][j], 0, 0, 0), mfma_pace();
-            }
+                for (int pl = 0; pl < 3; ++pl)
+                    ka[jj][pl] = *reinterpret_cast<const bf16x8 *>(&Ks3[pl][(jp + jj) * 16 + (lane & 15)][8 * g]);
+#define DPM_S3(PK, PQ)                                                                                              \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) _Pragma("unroll") for (int u = 0; u < QT; ++u)                \
+        sacc[u][jp + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[jj][PK], qb[u][PQ], sacc[u][jp + jj], 0, 0, 0), mfma_pace()
+            DPM_S3(1, 1);
+            DPM_S3(2, 0);
+            DPM_S3(0, 2);
+            DPM_S3(1, 0);
+            DPM_S3(0, 1);
+            DPM_S3(0, 0);
+#undef DPM_S3
         }
         // sacc[u][j][q] = score of key n0 + 16 j + 4 g + q for query 16 u + lane&15: mask keys beyond N, online softmax
 #pragma unroll

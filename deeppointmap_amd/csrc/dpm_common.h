@@ -73,6 +73,20 @@ __device__ __forceinline__ void mfma_pace() {
 #endif
 }
 
+// ---- exact three-way bf16 split of an fp32 value (csrc/gemm_b3.hip says what it is for): x = hi + mid + lo, each term a
+// truncation to the top 16 bits of a float, each remainder exact.  hi / mid come back masked, lo unmasked (its truncation
+// happens where the term is stored: pack2 / a 16-bit store of the upper half).
+__device__ __forceinline__ void split3(float x, unsigned &hi, unsigned &mid, unsigned &lo) {
+    hi = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(hi);
+    mid = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(mid);
+    lo = __float_as_uint(r2);
+}
+// two such terms -> one dword holding [a | b] as consecutive bf16 (a at the lower address): the upper halves of both
+// registers in one v_perm_b32
+__device__ __forceinline__ unsigned pack2(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
 // XCD-aware workgroup order.  Workgroups are dealt round-robin to the 8 XCDs by linear id and every XCD has its own
 // 4 MB L2; with the plain order all XCDs walk through all frames at once and every L2 holds a slice of everything.
 // This maps the hardware id to a logical id such that XCD x processes the contiguous chunk [x*n/8, (x+1)*n/8) in

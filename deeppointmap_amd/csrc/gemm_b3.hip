@@ -31,18 +31,7 @@ __device__ __forceinline__ float b3_act(float v, int act) {
     return v;
 }
 
-// x -> (hi, mid, lo) as the upper 16 bits of three floats; the split is exact (each term a truncation, each remainder exact)
-__device__ __forceinline__ void split3(float x, unsigned &hi, unsigned &mid, unsigned &lo) {
-    hi = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(hi);
-    mid = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(mid);
-    lo = __float_as_uint(r2);   // the truncation to 16 bits happens where the term is stored (pack2 / the plane store)
-}
-// two such terms -> one dword holding [a | b] as consecutive bf16 (a at the lower address): the upper halves of both
-// registers in one v_perm_b32
-__device__ __forceinline__ unsigned pack2(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-
+// split3 / pack2: dpm_common.h
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ W, long long n, uint16_t *__restrict__ planes) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;

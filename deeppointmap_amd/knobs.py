@@ -16,6 +16,7 @@ FUSED_LN = True        # False: Linear + LayerNorm as two kernels at every size 
 # alone, +2.7 % frames/s in the pipelined bench, error against fp64 at the fp32 kernel's level.  False: the fp32-MFMA kernel
 # everywhere.  (The library is compiled without packed fp32 instructions because of this kernel: csrc/build.py says why.)
 GEMM_BF16X3 = True
+BF16X3_MAX_K = 512     # layers up to this reduction length take the bf16x3 kernel (longer ones are the encoder's few-row tails)
 # ... and the Linear + LayerNorm layers with 128 <= K <= 512 (both forms: fused gemm_ln_b3_kernel / GEMM + LayerNorm, identical
 # rows).  At 256 columns the fused kernel makes two passes of 128 columns over 32 rows (256 threads, 38 KB of LDS: the fp32
 # form's footprint): 56 against 59 us alone on the decoder's 32 768 x 256 -> 256 blocks, 4.48 against 4.52 ms per pipelined step
@@ -26,7 +27,7 @@ FUSED_MATCH = True     # similarity -> dual softmax -> top-k as one operator (cs
 DEDUP_FRAMES = True    # False: per-frame decoder work once per pair side instead of once per frame (new Decoder objects)
 
 _ENV = {"DPM_FPS_ALGO": ("FPS_ALGO", int), "DPM_NO_FUSED_LN": ("FUSED_LN", lambda v: v != "1"),
-        "DPM_DEDUP_FRAMES": ("DEDUP_FRAMES", lambda v: v != "0"), "DPM_GEMM_BF16X3": ("GEMM_BF16X3", lambda v: v == "1"), "DPM_GEMM_LN_BF16X3": ("GEMM_LN_BF16X3", lambda v: v == "1"),
+        "DPM_DEDUP_FRAMES": ("DEDUP_FRAMES", lambda v: v != "0"), "DPM_GEMM_BF16X3": ("GEMM_BF16X3", lambda v: v == "1"), "DPM_BF16X3_MAX_K": ("BF16X3_MAX_K", int), "DPM_GEMM_LN_BF16X3": ("GEMM_LN_BF16X3", lambda v: v == "1"),
         "DPM_FUSED_MATCH": ("FUSED_MATCH", lambda v: v != "0")}
 
 

@@ -377,7 +377,6 @@ def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radi
 
 
 BF16X3_LN_MIN_K = 128
-BF16X3_MAX_K = 512   # layers up to this reduction length take the bf16x3 kernel (longer ones are the encoder's few-row tails)
 
 
 def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
@@ -391,7 +390,7 @@ def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     if W.dtype != torch.float32 or not W.is_cuda:
         raise ValueError("W must be an fp32 GPU tensor")
     Cout, Cin = W.shape[0], W.shape[1]
-    if knobs.GEMM_BF16X3 and not exact and Cin % 32 == 0 and Cin <= BF16X3_MAX_K and Cout % 4 == 0 and W.numel() == Cout * Cin:
+    if knobs.GEMM_BF16X3 and not exact and Cin % 32 == 0 and Cin <= knobs.BF16X3_MAX_K and Cout % 4 == 0 and W.numel() == Cout * Cin:
         done = linear_bf16x3(x, W, bias, act, residual, out)
         if done is not None:
             return done
@@ -517,7 +516,7 @@ def linear_layernorm(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tens
     # Layers the bf16x3 kernel covers (a property of the layer: K <= 512 in whole K-tiles, whole weight rows) take it in BOTH forms
     # -- fused from FUSED_LN_MIN_ROWS rows on, GEMM + LayerNorm below -- with identical rows either way
     # (from K = 128 on: with shorter reductions the kernels are bound by their epilogues and the fp32 form's smaller row tiles win)
-    if (knobs.GEMM_BF16X3 and knobs.GEMM_LN_BF16X3 and Cin % 32 == 0 and BF16X3_LN_MIN_K <= Cin <= BF16X3_MAX_K and Cout % 4 == 0 and W.numel() == Cout * Cin
+    if (knobs.GEMM_BF16X3 and knobs.GEMM_LN_BF16X3 and Cin % 32 == 0 and BF16X3_LN_MIN_K <= Cin <= knobs.BF16X3_MAX_K and Cout % 4 == 0 and W.numel() == Cout * Cin
             and x.dtype == torch.float32):
         wp = _weight_planes(W)
         if wp is not None and (bias is None or bias.data_ptr() % 16 == 0):

@@ -261,7 +261,9 @@ int dpm_posemb(const float *xyz, int ld, const float *dim_t, int F, int E, int R
 /* Scaled-dot-product core of nn.MultiheadAttention (descriptor_attention.py:14-15,35-45):
  * out[b,m,h*d:(h+1)*d] = softmax(Q_h K_h^T / sqrt(d)) V_h; no masks, dropout 0.  head_dim 32 (every shipped config:
  * model_channel 256, 8 heads) runs on the matrix cores; 8, 16, 64 and 128 (other Decoder(args)) through a generic kernel;
- * other widths return DPM_EUNSUPPORTED.
+ * other widths return DPM_EUNSUPPORTED.  At head_dim 32 the score product Q K^T is computed on the bf16 matrix pipe from exact
+ * three-way bf16 splits of both operands (six term products, fp32 accumulate: fp32-accumulation accuracy; dpm_linear_bf16x3
+ * below has the arithmetic), the product with V in exact fp32 -- in every dpm_attention* entry point alike.
  * Q/K/V/out: row leading dims ld*, batch strides s* (in floats). */
 int dpm_attention(const float *Q, int ldq, long long sq, const float *K, int ldk, long long sk,
                   const float *V, int ldv, long long sv, float *out, int ldo, long long so, int B, int M,
