@@ -112,9 +112,9 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
     constexpr int TK = 64;                 // keys per tile
     // A operand of S^T = K Q^T, which runs as an exact bf16x3 product (round 4; gemm_b3.hip has the arithmetic: both operands
     // split into three bf16 terms, six term products per score, fp32 accumulate -- 3/8 of the exact-fp32 instruction's
-    // matrix-pipe time at the same accuracy): three bf16 planes of the K tile, rows 80 bytes apart (16-byte aligned fragment
-    // reads: a lane's 8 consecutive d), A[i=key][k=d] = Ks3[plane][key][d].  HD = 32 is ONE instruction deep.
-    constexpr int KLD = HD + 8;
+    // matrix-pipe time at the same accuracy): three bf16 planes of the K tile in the swizzled 64-byte rows of b3_col (dpm_common.h:
+    // conflict-free 16-byte fragment reads), A[i=key][k=d] = Ks3[plane][key][b3_col(key, d)].  HD = 32 is ONE instruction deep.
+    constexpr int KLD = HD;
     static_assert(HD == 32, "the score product is one v_mfma_f32_16x16x32_bf16 deep");
     __shared__ __attribute__((aligned(16))) uint16_t Ks3[3][TK][KLD];
     // A operand of O^T: A[i=d][k=key] = Vs[key][d].  Row stride 36: 16-byte aligned rows, and the four lane groups of
@@ -189,9 +189,9 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
             const int e = t + p * 256, kr = e >> 3, c4 = (e & 7) * 4;
             unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
             split3(kreg[p].x, h0, m0, l0), split3(kreg[p].y, h1, m1, l1), split3(kreg[p].z, h2, m2, l2), split3(kreg[p].w, h3, m3, l3);
-            *reinterpret_cast<u32x2 *>(&Ks3[0][kr][c4]) = u32x2{pack2(h0, h1), pack2(h2, h3)};
-            *reinterpret_cast<u32x2 *>(&Ks3[1][kr][c4]) = u32x2{pack2(m0, m1), pack2(m2, m3)};
-            *reinterpret_cast<u32x2 *>(&Ks3[2][kr][c4]) = u32x2{pack2(l0, l1), pack2(l2, l3)};
+            *reinterpret_cast<u32x2 *>(&Ks3[0][kr][b3_col(kr, c4)]) = u32x2{pack2(h0, h1), pack2(h2, h3)};
+            *reinterpret_cast<u32x2 *>(&Ks3[1][kr][b3_col(kr, c4)]) = u32x2{pack2(m0, m1), pack2(m2, m3)};
+            *reinterpret_cast<u32x2 *>(&Ks3[2][kr][b3_col(kr, c4)]) = u32x2{pack2(l0, l1), pack2(l2, l3)};
             *reinterpret_cast<float4 *>(&Vs[kr][c4]) = vreg[p];     // row stride 144 B: 16-byte aligned
         }
         __syncthreads();
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    ka[jj][pl] = *reinterpret_cast<const bf16x8 *>(&Ks3[pl][(jp + jj) * 16 + (lane & 15)][8 * g]);
+                    ka[jj][pl] = *reinterpret_cast<const bf16x8 *>(&Ks3[pl][(jp + jj) * 16 + (lane & 15)][b3_col(lane & 15, 8 * g)]);
 #define DPM_S3(PK, PQ)                                                                                              \
     _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) _Pragma("unroll") for (int u = 0; u < QT; ++u)                \
         sacc[u][jp + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[jj][PK], qb[u][PQ], sacc[u][jp + jj], 0, 0, 0), mfma_pace()

@@ -87,6 +87,15 @@ __device__ __forceinline__ void split3(float x, unsigned &hi, unsigned &mid, uns
 // registers in one v_perm_b32
 __device__ __forceinline__ unsigned pack2(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
+// LDS image of a bf16 operand plane of the bf16x3 kernels: rows of 32 k = 64 bytes, NO padding, the four 16-byte chunks of
+// a row (8 consecutive k: what one lane of v_mfma_f32_16x16x32_bf16 holds) stored at chunk ^ F(row), F = (-(row >> 2)) & 3.
+// ds_read_b128 serves a fragment read in four groups of 16 lanes -- rows {0-3, 12-15} of k-chunk c with rows {4-11} of
+// chunk c + 1, and vice versa (MI355X guide, LDS table) --: with this F the 16 lanes of every group hit 16 different 16-byte
+// bank groups; the staging writes (8 or 16 bytes per lane, a row's lanes side by side) cover whole rows = contiguous bytes.
+// The padded image of the first version (rows 80 bytes apart) spent 49 % of its LDS cycles in bank conflicts and kept the
+// LDS pipe 74 % busy (PMC, profiles/r04_gemm_b3_pmc.md).  b3_col: element offset of k inside row `row`.
+__device__ __forceinline__ int b3_col(int row, int k) { return ((((k >> 3) ^ (0 - (row >> 2))) & 3) << 3) | (k & 7); }
+
 // XCD-aware workgroup order.  Workgroups are dealt round-robin to the 8 XCDs by linear id and every XCD has its own
 // 4 MB L2; with the plain order all XCDs walk through all frames at once and every L2 holds a slice of everything.
 // This maps the hardware id to a logical id such that XCD x processes the contiguous chunk [x*n/8, (x+1)*n/8) in

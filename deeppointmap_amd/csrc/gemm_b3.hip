@@ -14,8 +14,9 @@
 // Same structure as gemm_nt_mfma_kernel<64,64> on purpose (eight small workgroups per CU hide each other's latencies: the
 // 128 x 128 form of round 2 was faster alone and slower inside the pipeline): block tile 64 x 64, 4 waves as 2 x 2, wave tile
 // 32 x 32 = 2 x 2 blocks of 16 x 16; K-tile 32 = ONE bf16 instruction deep.  Weights arrive pre-split (dpm_split_bf16x3, once
-// per weight version), activations are split while they are staged: LDS holds three bf16 planes per operand, rows 80 bytes
-// apart (16-byte aligned ds_read_b128 fragments: a lane's 8 consecutive k), 30 720 B per workgroup.
+// per weight version), activations are split while they are staged: LDS holds three bf16 planes per operand in rows of 64
+// bytes whose 16-byte chunks (a lane's 8 consecutive k: one ds_read_b128 per fragment) are swizzled against bank conflicts
+// (b3_col, dpm_common.h), 24 576 B per workgroup.
 #include "dpm_common.h"
 
 namespace {
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restri
     planes[i] = (uint16_t)(h >> 16), planes[n + i] = (uint16_t)(m >> 16), planes[2 * n + i] = (uint16_t)(l >> 16);
 }
 
-constexpr int B3_KT = 32, B3_LD = B3_KT + 8;   // K-tile, LDS row stride in bf16 (80 bytes)
+constexpr int B3_KT = 32, B3_LD = B3_KT;       // K-tile; LDS rows of 64 bytes, chunks swizzled (b3_col, dpm_common.h)
 
 // BM x BN = 64 x 64 (wave tile 32 x 32 = 2 x 2 blocks) or 32 x 32 (one block per wave) for problems too small to fill the chip
 // with 64 x 64 tiles; an output element sees the same instructions in the same order either way (same bits).
@@ -52,9 +53,8 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
                                                       const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo,
                                                       int R, int Cin, int Cout, int act) {
     constexpr int LDC = BN + 4, MB = BM / 32, NB = BN / 32, PX = BM / 32, WT = BN * 4;   // WT: threads that stage W (16 B each)
-    constexpr int SM = 3 * (BM + BN) * B3_LD;
-    static_assert(sizeof(uint16_t) * SM >= sizeof(float) * BM * LDC, "the staged output tile reuses the operand planes");
-    __shared__ __attribute__((aligned(16))) uint16_t smem[SM];   // 30 720 B at 64 x 64: X planes, then W planes
+    constexpr int SM0 = 3 * (BM + BN) * B3_LD, SM1 = 2 * BM * LDC, SM = SM0 > SM1 ? SM0 : SM1;   // operand planes | staged output tile
+    __shared__ __attribute__((aligned(16))) uint16_t smem[SM];   // 24 576 B at 64 x 64: X planes, then W planes
     uint16_t (*Xs)[BM][B3_LD] = reinterpret_cast<uint16_t (*)[BM][B3_LD]>(smem);
     uint16_t (*Ws)[BN][B3_LD] = reinterpret_cast<uint16_t (*)[BN][B3_LD]>(smem + 3 * BM * B3_LD);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
@@ -89,17 +89,17 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
     auto stage_x = [&](const f32x4 &v, int r) {
         unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
         split3(v[0], h0, m0, l0), split3(v[1], h1, m1, l1), split3(v[2], h2, m2, l2), split3(v[3], h3, m3, l3);
-        *reinterpret_cast<u32x2 *>(&Xs[0][r][xk]) = u32x2{pack2(h0, h1), pack2(h2, h3)};
-        *reinterpret_cast<u32x2 *>(&Xs[1][r][xk]) = u32x2{pack2(m0, m1), pack2(m2, m3)};
-        *reinterpret_cast<u32x2 *>(&Xs[2][r][xk]) = u32x2{pack2(l0, l1), pack2(l2, l3)};
+        *reinterpret_cast<u32x2 *>(&Xs[0][r][b3_col(r, xk)]) = u32x2{pack2(h0, h1), pack2(h2, h3)};
+        *reinterpret_cast<u32x2 *>(&Xs[1][r][b3_col(r, xk)]) = u32x2{pack2(m0, m1), pack2(m2, m3)};
+        *reinterpret_cast<u32x2 *>(&Xs[2][r][b3_col(r, xk)]) = u32x2{pack2(l0, l1), pack2(l2, l3)};
     };
     for (int k0 = 0; k0 < Cin; k0 += B3_KT) {
 #pragma unroll
         for (int p = 0; p < PX; ++p) stage_x(xv[p], p * 32 + xr_);
         if (WT == 256 || t < WT) {
-            *reinterpret_cast<u32x4 *>(&Ws[0][wr_][wk]) = w0;
-            *reinterpret_cast<u32x4 *>(&Ws[1][wr_][wk]) = w1;
-            *reinterpret_cast<u32x4 *>(&Ws[2][wr_][wk]) = w2;
+            *reinterpret_cast<u32x4 *>(&Ws[0][wr_][b3_col(wr_, wk)]) = w0;
+            *reinterpret_cast<u32x4 *>(&Ws[1][wr_][b3_col(wr_, wk)]) = w1;
+            *reinterpret_cast<u32x4 *>(&Ws[2][wr_][b3_col(wr_, wk)]) = w2;
         }
         __syncthreads();
         {   // the next K-tile is requested while this one feeds the MFMAs -- unconditionally (the last trip re-reads its own
@@ -116,9 +116,9 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) a[pl][j] = *reinterpret_cast<const bf16x8 *>(&Ws[pl][wn * (BN / 2) + j * 16 + fr][fk]);
+            for (int j = 0; j < NB; ++j) a[pl][j] = *reinterpret_cast<const bf16x8 *>(&Ws[pl][wn * (BN / 2) + j * 16 + fr][b3_col(fr, fk)]);
 #pragma unroll
-            for (int i = 0; i < MB; ++i) b[pl][i] = *reinterpret_cast<const bf16x8 *>(&Xs[pl][wm * (BM / 2) + i * 16 + fr][fk]);
+            for (int i = 0; i < MB; ++i) b[pl][i] = *reinterpret_cast<const bf16x8 *>(&Xs[pl][wm * (BM / 2) + i * 16 + fr][b3_col(fr, fk)]);
         }
         // smallest terms first; (plane of W, plane of X): (1,1) (2,0) (0,2) (1,0) (0,1) (0,0)
 #define DPM_B3(PWQ, PXQ)                                                                                   \
@@ -182,9 +182,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_ln_b3_kernel(const float 
     constexpr int T = 64 * WGM * WGN, WM = BM / WGM, WN = BNP / WGN, MB = WM / 16, NB = WN / 16, LDC = BN + 4;
     constexpr int XF = BM * 8, PX = (XF + T - 1) / T;          // float4 groups of the X tile, per thread
     constexpr int WF = BNP * 4, PW = (WF + T - 1) / T;         // 16-byte groups of one W plane tile, per thread
-    constexpr int SM = 3 * (BM + BNP) * B3_LD;
-    static_assert(MB >= 1 && NB >= 1 && BN % NP == 0 && sizeof(uint16_t) * SM >= sizeof(float) * BM * LDC,
-                  "tile shape / staged output tile");
+    constexpr int SM0 = 3 * (BM + BNP) * B3_LD, SM1 = 2 * BM * LDC, SM = SM0 > SM1 ? SM0 : SM1;   // operand planes | staged output tile
+    static_assert(MB >= 1 && NB >= 1 && BN % NP == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
     __shared__ __attribute__((aligned(16))) uint16_t smem[SM];
     uint16_t (*Xs)[BM][B3_LD] = reinterpret_cast<uint16_t (*)[BM][B3_LD]>(smem);
     uint16_t (*Ws)[BNP][B3_LD] = reinterpret_cast<uint16_t (*)[BNP][B3_LD]>(smem + 3 * BM * B3_LD);
@@ -230,16 +229,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_ln_b3_kernel(const float 
             if (XF % T == 0 || p * T + t < XF) {
                 unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
                 split3(xv[p][0], h0, m0, l0), split3(xv[p][1], h1, m1, l1), split3(xv[p][2], h2, m2, l2), split3(xv[p][3], h3, m3, l3);
-                *reinterpret_cast<u32x2 *>(&Xs[0][xrow[p]][xk[p]]) = u32x2{pack2(h0, h1), pack2(h2, h3)};
-                *reinterpret_cast<u32x2 *>(&Xs[1][xrow[p]][xk[p]]) = u32x2{pack2(m0, m1), pack2(m2, m3)};
-                *reinterpret_cast<u32x2 *>(&Xs[2][xrow[p]][xk[p]]) = u32x2{pack2(l0, l1), pack2(l2, l3)};
+                *reinterpret_cast<u32x2 *>(&Xs[0][xrow[p]][b3_col(xrow[p], xk[p])]) = u32x2{pack2(h0, h1), pack2(h2, h3)};
+                *reinterpret_cast<u32x2 *>(&Xs[1][xrow[p]][b3_col(xrow[p], xk[p])]) = u32x2{pack2(m0, m1), pack2(m2, m3)};
+                *reinterpret_cast<u32x2 *>(&Xs[2][xrow[p]][b3_col(xrow[p], xk[p])]) = u32x2{pack2(l0, l1), pack2(l2, l3)};
             }
         }
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             if (WF % T == 0 || p * T + t < WF) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(&Ws[pl][wrow[p]][wk[p]]) = wv[p][pl];
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(&Ws[pl][wrow[p]][b3_col(wrow[p], wk[p])]) = wv[p][pl];
             }
         }
         __syncthreads();
@@ -260,9 +259,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_ln_b3_kernel(const float 
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) a[pl][j] = *reinterpret_cast<const bf16x8 *>(&Ws[pl][wn * WN + j * 16 + fr][fk]);
+            for (int j = 0; j < NB; ++j) a[pl][j] = *reinterpret_cast<const bf16x8 *>(&Ws[pl][wn * WN + j * 16 + fr][b3_col(fr, fk)]);
 #pragma unroll
-            for (int i = 0; i < MB; ++i) b[pl][i] = *reinterpret_cast<const bf16x8 *>(&Xs[pl][wm * WM + i * 16 + fr][fk]);
+            for (int i = 0; i < MB; ++i) b[pl][i] = *reinterpret_cast<const bf16x8 *>(&Xs[pl][wm * WM + i * 16 + fr][b3_col(fr, fk)]);
         }
 #define DPM_B3(PWQ, PXQ)                                                                                   \
     _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)        \
