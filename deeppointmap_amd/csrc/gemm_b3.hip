@@ -41,10 +41,16 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restri
     planes[i] = (uint16_t)(h >> 16), planes[n + i] = (uint16_t)(m >> 16), planes[2 * n + i] = (uint16_t)(l >> 16);
 }
 
+// 64 x 128 tiles (wave tile 32 x 64: every split X fragment feeds four column blocks instead of two -- the split is vector-ALU
+// work that ADDS to the matrix time on this chip) for problems with at least this many of them (one round of four workgroups
+// per CU): 32 768 x 256 -> 768 97 -> 93 us alone, pipelined step 4.30 -> 4.28 ms.  Same bits as the other tile shapes.  0: never.
+#ifndef DPM_B3_WIDE
+#define DPM_B3_WIDE 1024
+#endif
 constexpr int B3_KT = 32, B3_LD = B3_KT;       // K-tile; LDS rows of 64 bytes, chunks swizzled (b3_col, dpm_common.h)
 
-// BM x BN = 64 x 64 (wave tile 32 x 32 = 2 x 2 blocks) or 32 x 32 (one block per wave) for problems too small to fill the chip
-// with 64 x 64 tiles; an output element sees the same instructions in the same order either way (same bits).
+// BM x BN = 64 x 128 (wave tile 32 x 64) for the large problems, 64 x 64 (wave tile 32 x 32 = 2 x 2 blocks), or 32 x 32 (one block
+// per wave) for problems too small to fill the chip with 64 x 64 tiles; an output element sees the same instructions in the same order either way (same bits).
 // XVEC: the rows of X are 16-byte aligned (false: four scalar loads per group -- a token matrix with rows of 131 floats must
 // take the same kernel as one with rows of 132, or a layer's bits would depend on how its input happens to be laid out)
 template <int BM, int BN, bool XVEC>
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
                                                       long long plane, const float *__restrict__ bias,
                                                       const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo,
                                                       int R, int Cin, int Cout, int act) {
-    constexpr int LDC = BN + 4, MB = BM / 32, NB = BN / 32, PX = BM / 32, WT = BN * 4;   // WT: threads that stage W (16 B each)
+    constexpr int LDC = BN + 4, MB = BM / 32, NB = BN / 32, PX = BM / 32, WT = BN * 4, PW = (WT + 255) / 256;   // WT: 16-byte pieces of a W plane tile
     constexpr int SM0 = 3 * (BM + BN) * B3_LD, SM1 = 2 * BM * LDC, SM = SM0 > SM1 ? SM0 : SM1;   // operand planes | staged output tile
     __shared__ __attribute__((aligned(16))) uint16_t smem[SM];   // 24 576 B at 64 x 64: X planes, then W planes
     uint16_t (*Xs)[BM][B3_LD] = reinterpret_cast<uint16_t (*)[BM][B3_LD]>(smem);
@@ -66,11 +72,13 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
     const int row0 = by * BM, col0 = bx * BN;
     // staging: X as fp32 float4 (PX per thread: rows xr_ + 32 p, 4 consecutive k), W planes as 8 bf16 = 16 bytes (one per plane
     // per staging thread: row wr_, 8 consecutive k)
-    const int xr_ = t >> 3, xk = (t & 7) * 4, wr_ = min(t >> 2, BN - 1), wk = (t & 3) * 8;
+    const int xr_ = t >> 3, xk = (t & 7) * 4, wr_ = min(t >> 2, BN - 1), wk = (t & 3) * 8;   // W piece p: row wr_ + 64 p
     const float *xp[PX];
 #pragma unroll
     for (int p = 0; p < PX; ++p) xp[p] = X + (size_t)min(row0 + p * 32 + xr_, R - 1) * ldx + xk;
-    const uint16_t *wp = Wp + (size_t)min(col0 + wr_, Cout - 1) * ldw + wk;
+    const uint16_t *wp[PW];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) wp[p] = Wp + (size_t)min(col0 + p * 64 + wr_, Cout - 1) * ldw + wk;
     auto load_x = [&](const float *p) {
         if (XVEC) return *reinterpret_cast<const f32x4 *>(p);
         return f32x4{p[0], p[1], p[2], p[3]};
@@ -78,8 +86,11 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
     f32x4 xv[PX];
 #pragma unroll
     for (int p = 0; p < PX; ++p) xv[p] = load_x(xp[p]);
-    u32x4 w0 = *reinterpret_cast<const u32x4 *>(wp), w1 = *reinterpret_cast<const u32x4 *>(wp + plane),
-          w2 = *reinterpret_cast<const u32x4 *>(wp + 2 * plane);
+    u32x4 wv[PW][3];
+#pragma unroll
+    for (int p = 0; p < PW; ++p)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wv[p][pl] = *reinterpret_cast<const u32x4 *>(wp[p] + pl * plane);
     f32x4 acc[MB][NB];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -96,10 +107,11 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
     for (int k0 = 0; k0 < Cin; k0 += B3_KT) {
 #pragma unroll
         for (int p = 0; p < PX; ++p) stage_x(xv[p], p * 32 + xr_);
-        if (WT == 256 || t < WT) {
-            *reinterpret_cast<u32x4 *>(&Ws[0][wr_][b3_col(wr_, wk)]) = w0;
-            *reinterpret_cast<u32x4 *>(&Ws[1][wr_][b3_col(wr_, wk)]) = w1;
-            *reinterpret_cast<u32x4 *>(&Ws[2][wr_][b3_col(wr_, wk)]) = w2;
+        if (WT >= 256 || t < WT) {
+#pragma unroll
+            for (int p = 0; p < PW; ++p)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(&Ws[pl][p * 64 + wr_][b3_col(wr_, wk)]) = wv[p][pl];
         }
         __syncthreads();
         {   // the next K-tile is requested while this one feeds the MFMAs -- unconditionally (the last trip re-reads its own
@@ -107,8 +119,10 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
             const int kn = min(k0 + B3_KT, Cin - B3_KT);
 #pragma unroll
             for (int p = 0; p < PX; ++p) xv[p] = load_x(xp[p] + kn);
-            w0 = *reinterpret_cast<const u32x4 *>(wp + kn), w1 = *reinterpret_cast<const u32x4 *>(wp + plane + kn);
-            w2 = *reinterpret_cast<const u32x4 *>(wp + 2 * plane + kn);
+#pragma unroll
+            for (int p = 0; p < PW; ++p)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wv[p][pl] = *reinterpret_cast<const u32x4 *>(wp[p] + pl * plane + kn);
         }
         // (the scheduler sinks these loads below the matrix instructions to save 20 registers; pinning them up here with
         // sched_barrier(0) was measured -- 116 us alone either way, 4.47 against 4.48 ms per pipelined step -- and not kept)
@@ -339,15 +353,17 @@ extern "C" int dpm_linear_bf16x3(const float *x, int ldx, const void *w_planes, 
     const bool xvec = ldx % 4 == 0 && al(x);
     // tile choice as in dpm_linear: 64 x 64 from 192 such tiles on (or tall problems), 32 x 32 below -- the bits do not depend on it
     const long long big = (long long)dpm_cdiv(R, 64) * dpm_cdiv(Cout, 64);
-#define DPM_B3_LAUNCH(T, V)                                                                                                   \
-    hipLaunchKernelGGL((gemm_b3_kernel<T, T, V>), dim3(dpm_cdiv(Cout, T), dpm_cdiv(R, T)), dim3(256), 0, (hipStream_t)stream, x, ldx, \
+#define DPM_B3_LAUNCH(TM, TN, V)                                                                                              \
+    hipLaunchKernelGGL((gemm_b3_kernel<TM, TN, V>), dim3(dpm_cdiv(Cout, TN), dpm_cdiv(R, TM)), dim3(256), 0, (hipStream_t)stream, x, ldx, \
                        (const uint16_t *)w_planes, ldw, plane_stride, bias, residual, ldr, out, ldo, R, Cin, Cout, act)
-    if (big >= 192 || (R > 1024 && Cout > 32)) {
-        if (xvec) DPM_B3_LAUNCH(64, true);
-        else DPM_B3_LAUNCH(64, false);
+    if (DPM_B3_WIDE && xvec && Cout % 128 == 0 && (long long)dpm_cdiv(R, 64) * (Cout / 128) >= DPM_B3_WIDE) {
+        DPM_B3_LAUNCH(64, 128, true);
+    } else if (big >= 192 || (R > 1024 && Cout > 32)) {
+        if (xvec) DPM_B3_LAUNCH(64, 64, true);
+        else DPM_B3_LAUNCH(64, 64, false);
     } else {
-        if (xvec) DPM_B3_LAUNCH(32, true);
-        else DPM_B3_LAUNCH(32, false);
+        if (xvec) DPM_B3_LAUNCH(32, 32, true);
+        else DPM_B3_LAUNCH(32, 32, false);
     }
 #undef DPM_B3_LAUNCH
     return dpm_launch_status();
