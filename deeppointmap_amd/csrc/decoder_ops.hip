@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void posemb_kernel(const float *__restrict__ x
 // reductions), P transposed through a per-wave LDS tile into the A-operand layout, O += P V.
 // ------------------------------------------------------------------------------------------
 constexpr int HD = 32;
+constexpr float LOG2E = 1.44269504088896340736f;
 constexpr int RES_HDR = 20;  // floats before the inlier-confidence list in a Kabsch `result`
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -223,29 +224,40 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
             DPM_S3(0, 0);
 #undef DPM_S3
         }
-        // sacc[u][j][q] = score of key n0 + 16 j + 4 g + q for query 16 u + lane&15: mask keys beyond N, online softmax
+        // sacc[u][j][q] = score of key n0 + 16 j + 4 g + q for query 16 u + lane&15: mask keys beyond N, online softmax.
+        // Only a ragged last tile is tested against N (uniform branch: a compare + select per score saved on whole tiles).
+        if (n0 + TK > N || MASK) {
+#pragma unroll
+            for (int u = 0; u < QT; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + j * 16 + g * 4 + q;
+                        if (n >= N || (MASK && km[min(n, N - 1)])) sacc[u][j][q] = -__builtin_inff();
+                    }
+        }
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
             float mx = -__builtin_inff();
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + j * 16 + g * 4 + q;
-                    if (n >= N || (MASK && km[min(n, N - 1)])) sacc[u][j][q] = -__builtin_inff();
-                    mx = fmaxf(mx, sacc[u][j][q]);
-                }
+                for (int q = 0; q < 4; ++q) mx = fmaxf(mx, sacc[u][j][q]);
             mx = rows4_max(mx);
             const float nm = fmaxf(mrow[u], mx);
             // exp(-inf) = 0 on the first tile; with masks a whole tile may be padding while the running max is still -inf:
-            // nothing has been accumulated then, the factor is irrelevant (and -inf - -inf would be NaN)
-            const float corr = (MASK && nm == -__builtin_inff()) ? 1.f : __expf(mrow[u] - nm);
+            // nothing has been accumulated then, the factor is irrelevant (and -inf - -inf would be NaN).
+            // e^(s - nm) as ONE multiply-add into v_exp_f32 (2^(s log2 e - nm log2 e)) instead of subtract, multiply, v_exp_f32
+            const bool dead = MASK && nm == -__builtin_inff();
+            const float nml = nm * LOG2E;
+            const float corr = dead ? 1.f : __builtin_amdgcn_exp2f(fmaf(mrow[u], LOG2E, -nml));
             float ps = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float pv = (MASK && nm == -__builtin_inff()) ? 0.f : __expf(sacc[u][j][q] - nm);
+                    const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[u][j][q], LOG2E, -nml));
                     sacc[u][j][q] = pv;
                     ps += pv;
                 }
