@@ -386,12 +386,14 @@ extern "C" int dpm_linear_layernorm_bf16x3(const float *x, int ldx, const void *
 #define DPM_GLN3(BM, BN, WGM, WGN, NP)                                                                                         \
     hipLaunchKernelGGL((gemm_ln_b3_kernel<BM, BN, WGM, WGN, NP>), dim3(dpm_cdiv(R, BM)), dim3(64 * WGM * WGN), 0, st, x, ldx,       \
                        (const uint16_t *)w_planes, ldw, plane_stride, bias, pre, gamma, beta, post, out, ldo, R, Cin, act)
-    // every configuration gives the same bits (same instructions in the same order per output element).  256 columns: two
-    // passes of 128 over 32 rows -- 256 threads and 38 KB per workgroup; the one-pass 64 x 256 form (512 threads, 77 KB) was
-    // faster alone and slower inside the pipeline
+    // every configuration gives the same bits (same instructions in the same order per output element).  256 columns: 64 rows
+    // in one pass, 512 threads (wave tile 32 x 64, X split once).  History: with the first version's padded LDS rows this form
+    // was faster alone (44 against 59 us) and made the pipelined step LONGER, so 32 rows x two passes of 128 columns (256
+    // threads, 38 KB) shipped for a while; with the swizzled rows (half the LDS cycles) the one-pass form wins both ways:
+    // 4.19-4.20 against 4.27 ms per step.
     if (Cout == 256) {
-        if (dpm_knob("DPM_GLN3_WIDE", 0)) DPM_GLN3(64, 256, 2, 4, 1);
-        else DPM_GLN3(32, 256, 1, 4, 2);
+        if (dpm_knob("DPM_GLN3_TWOPASS", 0)) DPM_GLN3(32, 256, 1, 4, 2);
+        else DPM_GLN3(64, 256, 2, 4, 1);
     } else if (Cout == 128) DPM_GLN3(64, 128, 2, 2, 1);
     else if (Cout == 64) DPM_GLN3(64, 64, 2, 2, 1);
     else if (Cout == 32) DPM_GLN3(64, 32, 2, 2, 1);

@@ -18,10 +18,8 @@ FUSED_LN = True        # False: Linear + LayerNorm as two kernels at every size 
 GEMM_BF16X3 = True
 BF16X3_MAX_K = 512     # layers up to this reduction length take the bf16x3 kernel (longer ones are the encoder's few-row tails)
 # ... and the Linear + LayerNorm layers with 128 <= K <= 512 (both forms: fused gemm_ln_b3_kernel / GEMM + LayerNorm, identical
-# rows).  At 256 columns the fused kernel makes two passes of 128 columns over 32 rows (256 threads, 38 KB of LDS: the fp32
-# form's footprint): 56 against 59 us alone on the decoder's 32 768 x 256 -> 256 blocks, 4.48 against 4.52 ms per pipelined step
-# (four alternating 60-step runs each: fewer matrix-pipe cycles are what counts next to the feature stage).  The one-pass
-# 64 x 256 form (512 threads, 77 KB) was 44 us alone and made the pipelined step LONGER (4.555 against 4.52 ms).
+# rows).  Pipelined step 4.27 -> 4.19 ms against the fp32 fused kernel's 4.33 (csrc/gemm_b3.hip, dpm_linear_layernorm_bf16x3,
+# has the history of its tile shapes).
 GEMM_LN_BF16X3 = True
 FUSED_MATCH = True     # similarity -> dual softmax -> top-k as one operator (csrc/match.hip) where it applies; False: the five-launch form
 DEDUP_FRAMES = True    # False: per-frame decoder work once per pair side instead of once per frame (new Decoder objects)
