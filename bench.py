@@ -430,7 +430,8 @@ def main():
                        "parallelism": f"frame-sharded x{world}, one RCCL gather of descriptors+edges per step" +
                                       ("" if backend == "nccl" or world == 1 else f" (DRY RUN over {backend}, ranks folded onto the visible GPUs)"),
                        "pipeline": "none" if args.no_pipeline else "HIP-stream pipeline: geometry (staging+FPS chain) of batches i, i-1 on two alternating streams | features of batch i-2 | registration+information matrices of batch i-3",
-                       "weights": "procedural (deeppointmap_amd/weights.py)"},
+                       "weights": "procedural (deeppointmap_amd/weights.py)",
+                       "allocator_reserve_gib": 0 if args.no_pipeline else hot.reserve_bytes >> 30},
             "roofline": {"kernel": "str_chunk/str_xoffsets/str_ysort kernels + fps_bucket_kernel (stage-0 farthest point sampling: Sort-Tile-Recursive packing, then the sampling rounds)",
                          "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK / 1e9), 6), "traffic": pmc_traffic_bytes(F),

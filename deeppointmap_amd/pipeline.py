@@ -58,6 +58,13 @@ class HotPath:
         self._side = None      # side HIP streams for the software pipeline (submit / flush)
         self._pending = None
         self._rings = {}
+        # Bytes handed to torch's caching allocator as ONE segment before the first pipelined batch.  Four batches are in flight
+        # on four streams; a block freed on one stream while another still reads it cannot be reused yet, so the allocator
+        # keeps meeting requests nothing cached fits and goes to hipMalloc -- 5-12 ms of host time each, 28 of them over the
+        # first 150 steps until ~6.3 GB were reserved (scripts/debug/step_hiccup.py), and a 20-step measurement that catches a
+        # burst of them reads 5.3 instead of 4.35 ms per step.  Blocks of one big cached segment are split instead.  The chip
+        # has 288 GB; 0 switches it off.
+        self.reserve_bytes = 16 << 30
 
     @torch.no_grad()
     def extract(self, points: torch.Tensor, padding: torch.Tensor, presampled=None) -> torch.Tensor:
@@ -195,6 +202,16 @@ class HotPath:
                               reg=torch.cuda.Stream(device=dev),
                               feat=[torch.cuda.Stream(device=dev) for _ in range(self.feature_streams)]
                               if self.feature_streams > 1 else [])
+            if self.reserve_bytes:
+                # the allocator's cache is per stream: every stream of the pipeline gets its share
+                streams = [torch.cuda.current_stream(dev)] + self._side["geo"] + [self._side["reg"]] + self._side["feat"]
+                free = torch.cuda.mem_get_info(dev)[0]
+                n = min(int(self.reserve_bytes), free // 2) // len(streams)
+                if n >= (1 << 29):
+                    for st in streams:
+                        with torch.cuda.stream(st):
+                            del_me = torch.empty(n, dtype=torch.uint8, device=dev)  # one segment; back into the cache at once
+                            del del_me
             self._pending = dict(geo=[], reg=None, n=0, nf=0, hold=[])
         self._pending["hold"].append((points, padding, pcd_m))
         if len(self._pending["hold"]) >= max(1, self.geometry_group):
