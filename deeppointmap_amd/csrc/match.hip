@@ -27,6 +27,17 @@ constexpr int MT_SMEM2 = MT_ROWS * MT_PLD + 2 * MT_KCAP;       // second kernel:
 constexpr int MT_MCAP = MT_ROWS * MT_PLD / 2;                  // candidates (value, index) the dead P tile holds for the merge: 8 320
 static_assert(MT_SMEM2 >= MT_SMEM && MT_SMEM >= 2 * MT_COLS, "the P tile and the column statistics reuse the operand tiles");
 
+#ifdef DPM_EXPERIMENT
+__device__ long long dpm_match_trace_buf[64];   // cycle stamps of pair 0 (scripts/debug/match_trace.py): slots 0-15 of the strip
+                                                // that merges, 16-31 of match_stats_kernel's strip 0
+#define DPM_MT_STAMP(slot)                                                                                        \
+    do {                                                                                                          \
+        if (blockIdx.y == 0 && threadIdx.x == 0) dpm_match_trace_buf[slot] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define DPM_MT_STAMP(slot) do { } while (0)
+#endif
+
 struct MatchWs {
     float *rmax, *rsum;      // (batch, M)
     float *pmax, *psum;      // (batch, strips, N)
@@ -106,7 +117,9 @@ __global__ __launch_bounds__(MT_T) void match_stats_kernel(const float *__restri
     const int row0 = strip * MT_ROWS;
     if (strip == 0 && t == 0) ws.ticket[pair] = 0;   // the next launch counts the pair's finished strips from zero
     f32x4 acc[4][4];
+    if (strip == 0) DPM_MT_STAMP(16);
     match_strip_gemm(A + ((size_t)pair * M + row0) * C, M - row0, B + (size_t)pair * N * C, N, C, smem, acc);
+    if (strip == 0) DPM_MT_STAMP(17);
     const float NEG = -__builtin_inff();
     // x = S / tau, invalid entries -inf (they fall out of every maximum and add exp(-inf) = 0 to every sum)
 #pragma unroll
@@ -164,6 +177,7 @@ __global__ __launch_bounds__(MT_T) void match_stats_kernel(const float *__restri
             const int c = w * 64 + j * 16 + (lane >> 4) * 4 + q;
             if ((lane & 15) == 0 && c < N) pm_out[c] = m, ps_out[c] = s;
         }
+    if (strip == 0) DPM_MT_STAMP(18);
 }
 
 // ---- block-wide exact top-k over items a thread enumerates itself (registers or memory) -------------------------------
@@ -197,6 +211,72 @@ __device__ __forceinline__ void pick_bin(const unsigned *hist, unsigned *sc /* [
         sc[2] = rem, sc[0] |= (unsigned)b << shift, sc[1] |= 255u << shift;
         sc[3] = hist[b];   // population of the chosen bin (after the last pass: keys equal to the selected one)
     }
+}
+
+// Bitonic sort of np2 = 256 EPT (value, index) pairs in sv / si into (value descending, index ascending), EPT consecutive
+// elements per thread in registers: compare-exchange steps at distances below EPT stay inside a thread, below 64 EPT inside a
+// wave (lane exchanges), and only the last ones (partner in another wave) go through LDS with barriers -- 3 of the 55 steps at
+// 1024 elements.  (All steps through LDS with a barrier each: 15 of the merge's 26 us.)
+template <int EPT>
+__device__ __forceinline__ void block_sort_regs(float *sv, int *si) {
+    const int t = threadIdx.x;
+    constexpr int NP2 = EPT * MT_T;
+    float v[EPT];
+    int ix[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) v[i] = sv[t * EPT + i], ix[i] = si[t * EPT + i];
+    // own (a, ia) against partner (b, ib); take_first: this slot keeps the pair that sorts first
+    auto keep = [](float a, int ia, float b, int ib, bool take_first, float &o, int &oi) {
+        const bool a_first = a > b || (a == b && ia < ib);
+        const bool own = a_first == take_first;
+        o = own ? a : b, oi = own ? ia : ib;
+    };
+    for (int size = 2; size <= NP2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= EPT * 64) {          // partner in another wave
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) sv[t * EPT + i] = v[i], si[t * EPT + i] = ix[i];
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int e = t * EPT + i, pe = e ^ stride;
+                    const bool take_first = ((e & stride) == 0) == ((e & size) == 0);
+                    keep(v[i], ix[i], sv[pe], si[pe], take_first, v[i], ix[i]);
+                }
+            } else if (stride >= EPT) {        // partner lane of the same wave
+                const int m = stride / EPT;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int e = t * EPT + i;
+                    const float b = __shfl_xor(v[i], m, 64);
+                    const int ib = __shfl_xor(ix[i], m, 64);
+                    const bool take_first = ((e & stride) == 0) == ((e & size) == 0);
+                    keep(v[i], ix[i], b, ib, take_first, v[i], ix[i]);
+                }
+            } else {                           // both elements in this thread: static register pairs
+#pragma unroll
+                for (int sd = 1; sd < EPT; sd <<= 1) {
+                    if (sd != stride) continue;
+#pragma unroll
+                    for (int i = 0; i < EPT; ++i) {
+                        if (i & sd) continue;
+                        const int j = i | sd;
+                        const bool desc = ((t * EPT + i) & size) == 0;   // this block sorts "first" to the low slot
+                        const bool a_first = v[i] > v[j] || (v[i] == v[j] && ix[i] < ix[j]);
+                        if (a_first != desc) {
+                            const float tv = v[i];
+                            const int ti = ix[i];
+                            v[i] = v[j], ix[i] = ix[j], v[j] = tv, ix[j] = ti;
+                        }
+                    }
+                }
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) sv[t * EPT + i] = v[i], si[t * EPT + i] = ix[i];
+    __syncthreads();
 }
 
 // items(f): calls f(value bits, flat index) for each of the thread's valid items (values >= 0: their bit patterns order
@@ -239,6 +319,7 @@ __device__ __forceinline__ void block_topk(Items &&items, int k, float *sv, int 
     select([](unsigned u, int) { return u; }, [](unsigned, int) { return true; }, true, (unsigned)k);
     const unsigned thr = sc[0], take_eq = sc[2], c_eq = sc[3];
     __syncthreads();
+    if (sorted) DPM_MT_STAMP(8);
     unsigned ithr = 0x7fffffffu;
     if (take_eq < c_eq) {   // not every element equal to the k-th value fits: the take_eq smallest flat indices do
         select([](unsigned, int idx) { return (unsigned)idx; }, [thr](unsigned u, int) { return u == thr; }, false, take_eq);
@@ -264,7 +345,10 @@ __device__ __forceinline__ void block_topk(Items &&items, int k, float *sv, int 
         sv[p] = __uint_as_float(u), si[p] = idx;
     });
     __syncthreads();
+    if (sorted) DPM_MT_STAMP(9);
     if (!sorted) return;
+    if (np2 == 4 * MT_T) return block_sort_regs<4>(sv, si);
+    if (np2 == 8 * MT_T) return block_sort_regs<8>(sv, si);
     for (int size = 2; size <= np2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int e = t; e < np2 / 2; e += MT_T) {
@@ -289,7 +373,9 @@ __global__ __launch_bounds__(MT_T) void match_topk_kernel(const float *__restric
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int row0 = strip * MT_ROWS;
     f32x4 acc[4][4];
+    if (strip == 0) DPM_MT_STAMP(0);
     match_strip_gemm(A + ((size_t)pair * M + row0) * C, M - row0, B + (size_t)pair * N * C, N, C, smem, acc);
+    if (strip == 0) DPM_MT_STAMP(1);
     // column statistics over ALL rows: fold the strips' partial (max, sum) pairs, in strip order
     float *cm = smem, *cs = smem + MT_COLS;   // the operand tiles are dead
     float *pt = smem, *sv = smem + MT_ROWS * MT_PLD;
@@ -328,11 +414,22 @@ __global__ __launch_bounds__(MT_T) void match_topk_kernel(const float *__restric
     const int rows_here = min(MT_ROWS, M - row0);
     const int kl = min(k, rows_here * N);   // the strip's contribution: its k largest (all of them when it has fewer)
     // thread t walks column t of the tile (conflict-free LDS reads); the selection passes run over LDS, not over 64 registers
+    // (sixteen LDS reads in flight per step: one read per item, waited for before it is looked at, made every walk of the
+    // selection a chain of 64 LDS round trips -- 27 of the kernel's 73 us, scripts/debug/match_trace.py)
     auto tile_items = [&](auto &&f) {
         if (t < N)
-            for (int r = 0; r < rows_here; ++r) f(__float_as_uint(pt[r * MT_PLD + t]), (row0 + r) * N + t);
+            for (int r0 = 0; r0 < rows_here; r0 += 16) {
+                unsigned u[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) u[q] = __float_as_uint(pt[min(r0 + q, rows_here - 1) * MT_PLD + t]);
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (r0 + q < rows_here) f(u[q], (row0 + r0 + q) * N + t);
+            }
     };
+    if (strip == 0) DPM_MT_STAMP(2);
     block_topk(tile_items, kl, sv, si, hist, sc, strips == 1);
+    if (strip == 0) DPM_MT_STAMP(3);
     if (strips == 1) {
         for (int e = t; e < k; e += MT_T) out_v[(size_t)pair * k + e] = sv[e], out_i[(size_t)pair * k + e] = si[e];
         return;
@@ -350,6 +447,7 @@ __global__ __launch_bounds__(MT_T) void match_topk_kernel(const float *__restric
     }
     __syncthreads();
     if ((int)sc[5] != strips - 1) return;
+    DPM_MT_STAMP(4);
     if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     const float *av = ws.cand_v + (size_t)pair * strips * kcap;
@@ -377,11 +475,25 @@ __global__ __launch_bounds__(MT_T) void match_topk_kernel(const float *__restric
             }
         }
         __syncthreads();
+        DPM_MT_STAMP(5);
         auto lds_items = [&](auto &&f) {
-            for (int e = t; e < total; e += MT_T) f(__float_as_uint(mv[e]), mi[e]);
+            for (int e0 = t; e0 < total; e0 += 8 * MT_T) {
+                unsigned u[8];
+                int ix[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = min(e0 + q * MT_T, total - 1);
+                    u[q] = __float_as_uint(mv[e]), ix[q] = mi[e];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (e0 + q * MT_T < total) f(u[q], ix[q]);
+            }
         };
         block_topk(lds_items, k, sv, si, hist, sc, true);
+        DPM_MT_STAMP(6);
         for (int e = t; e < k; e += MT_T) out_v[(size_t)pair * k + e] = sv[e], out_i[(size_t)pair * k + e] = si[e];
+        DPM_MT_STAMP(7);
         return;
     }
     auto mem_items = [&](auto &&f) {
@@ -418,6 +530,12 @@ MatchWs carve(void *workspace, int batch, int M, int N, int k) {
 }
 
 }  // namespace
+
+#ifdef DPM_EXPERIMENT
+extern "C" int dpm_debug_match_trace(long long *host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dpm_match_trace_buf), sizeof(long long) * (size_t)std::min(n, 64));
+}
+#endif
 
 extern "C" size_t dpm_match_workspace_bytes(int batch, int M, int N, int k) {
     if (batch < 1 || M < 1 || N < 1 || k < 1) return 0;
