@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--geometry-group", type=int, default=None, help="batches per first-level sampling launch (pipeline tuning)")
     ap.add_argument("--geometry-knn", type=int, default=None, help="1: neighbour queries run in the geometry stage, 0: in the feature stage")
     ap.add_argument("--feature-streams", type=int, default=None, help="feature-stage streams (pipeline tuning)")
+    ap.add_argument("--feature-split", type=int, default=None, help="downsampling level at which the feature stage moves to its second stream (pipeline tuning; 0 = one stage)")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time breakdown to stderr")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend for --gpus > 1; gloo (ranks folded onto the visible GPUs) exists only to dry-run "
@@ -157,6 +158,8 @@ def main():
         hot.encoder.presample_neighbours = bool(args.geometry_knn)
     if args.feature_streams is not None:
         hot.feature_streams = args.feature_streams
+    if args.feature_split is not None:
+        hot.feature_split = args.feature_split
     hot.chain = world > 1  # block-boundary edges come from the neighbour rank's last frame (shard.exchange_halo)
     F, N = args.frames, args.points
     pts, pad = synthetic.frames(F, N, start=rank * F)  # every rank owns its own block of the sequence

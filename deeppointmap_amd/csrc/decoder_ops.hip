@@ -39,6 +39,9 @@ __global__ __launch_bounds__(256) void posemb_kernel(const float *__restrict__ x
 // ------------------------------------------------------------------------------------------
 constexpr int HD = 32;
 constexpr float LOG2E = 1.44269504088896340736f;
+#ifndef DPM_ATT_WIDE_MIN
+#define DPM_ATT_WIDE_MIN 1024   // workgroups of 128 queries a launch must have for the 32-queries-per-wave form
+#endif
 constexpr int RES_HDR = 20;  // floats before the inlier-confidence list in a Kabsch `result`
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -1317,7 +1320,7 @@ static int attention_launch(const float *Q, int ldq, long long sq, const float *
                      ldo % 4 == 0 && so % 4 == 0 && ((uintptr_t)out & 15) == 0;  // 16-byte K / V loads and output stores
     const float scale = (float)(1.0 / sqrt((double)head_dim));
     // 32 queries per wave when the query count fills such blocks and there are enough of them for the chip
-    const bool wide = M % 128 == 0 && (long long)(M / 128) * heads * B >= 1024;
+    const bool wide = M % 128 == 0 && (long long)(M / 128) * heads * B >= DPM_ATT_WIDE_MIN;
 #define DPM_ATT(V, QT)                                                                                                  \
     hipLaunchKernelGGL((attention_kernel<V, QT>), dim3(dpm_cdiv(M, 64 * QT), heads, B), dim3(256), (size_t)dpm_knob("DPM_ATT_LDS_PAD", 0), (hipStream_t)stream, \
                        Q, ldq, sq, K, ldk, sk, V_, ldv, sv, out, ldo, so, M, N, scale, kv_shift, nullptr, 1, nullptr,     \

@@ -44,6 +44,7 @@ class Encoder(ParamTree):
         # presample() also answers the neighbour queries (coordinates only): a pipeline knob -- where they run moves
         # work between the geometry and the feature stage, the results are the same tensors either way
         self.presample_neighbours = False
+        self._price_tail = 0   # measurement only (scripts/price_tail.py): extra evaluations of levels 3+ and the upsamplers
         self.eval()
 
     # -- helpers -------------------------------------------------------------------------------
@@ -166,16 +167,22 @@ class Encoder(ParamTree):
 
     @torch.no_grad()
     def forward(self, points: torch.Tensor, points_padding: torch.Tensor, trace: Optional[dict] = None,
-                presampled: Optional[dict] = None, descriptor_scale: float = 0.0, spare_frames: int = 0) -> List[torch.Tensor]:
+                presampled: Optional[dict] = None, descriptor_scale: float = 0.0, spare_frames: int = 0,
+                stop_level: Optional[int] = None, resume: Optional[dict] = None) -> List[torch.Tensor]:
         """-> [coor (B,3,S), fea (B,out_channel,S), padding (B,S)] (encoder.py:51-69).  descriptor_scale > 0 (not in the
         reference signature; used by the batched hot path): return instead the unified descriptor (B,out_channel+3,S) =
-        [fea ; coor * descriptor_scale] that ExtractionThread.process builds from the triple (odometry.py:47-49)."""
+        [fea ; coor * descriptor_scale] that ExtractionThread.process builds from the triple (odometry.py:47-49).
+        stop_level = i: run the downsampling levels below i and return the state (a dict) instead; resume = that state: run
+        the rest (same kernels in the same order: the two halves may sit on different HIP streams, pipeline.py)."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("deeppointmap_amd.Encoder runs on the GPU only: call .to('cuda') first "
                                "(there is no CPU fallback)")
         enc = self.encoder_cfg
-        samp = presampled if presampled is not None else self.presample(points, points_padding)
+        if resume is not None:
+            samp = resume["samp"]
+        else:
+            samp = presampled if presampled is not None else self.presample(points, points_padding)
         with torch.cuda.device(dev):
             pts, xyz, lengths = samp["pts"], samp["xyz"], samp["lengths"]
             # level-0 features = point_mlp0(points).  With xyz-only input (every shipped config) they are only ever
@@ -183,19 +190,23 @@ class Encoder(ParamTree):
             w0 = self.p("point_mlp0.weight")
             fuse0 = (self.in_channel == 3 and w0.shape[0] % 4 == 0 and 2 * w0.shape[0] in (32, 64, 128)
                      and enc.nsample_list[0][0] in (16, 32))
-            if fuse0:
+            if resume is not None or fuse0:
                 fea = None
             elif self.in_channel == 3:
                 fea = ops.linear(xyz, w0, self.p("point_mlp0.bias"))
             else:  # extra input channels: point-major copy of the first in_channel rows
                 fea = ops.linear(pts[:, :self.in_channel].transpose(1, 2).contiguous(), w0, self.p("point_mlp0.bias"))
-            levels = [(xyz, fea, lengths)]
+            levels = [(xyz, fea, lengths)] if resume is None else resume["levels"]
             # Neighbour queries repeat: a SetAbstraction asks, for the FPS-picked subset of a level's points, exactly
             # what the preceding LocalAggregation answered for ALL of them when radius and K coincide (they do in every
             # shipped config), and consecutive LocalAggregations of a stage may share (radius, K) too.  `self_q`
             # remembers the self-queries of the current level: (radius, K) -> idx (B,N,K).
-            self_q = {}
+            self_q = {} if resume is None else resume["self_q"]
             for i, npoint in enumerate(enc.npoint):
+                if resume is not None and i < resume["next"]:
+                    continue
+                if stop_level is not None and i >= stop_level:
+                    return dict(samp=samp, levels=levels, self_q=self_q, next=i)
                 xyz, fea, lengths = levels[-1]
                 radii, ks = enc.radius_list[i], enc.nsample_list[i]
                 pre = f"downsampler.{i}"
@@ -203,45 +214,49 @@ class Encoder(ParamTree):
                     fidx, new_xyz, new_len = samp[f"fidx{i}"], samp[f"xyz{i}"], samp[f"len{i}"]
                 else:  # levels the geometry pass left to this stream
                     fidx, new_xyz, new_len = self._sample_level(i, xyz, lengths)
-                prev = self_q.get((float(radii[0]), int(ks[0])))
-                grids, knn = samp.get("grids", {}), samp.get("knn", {})
-                gidx = knn.get(("sa", i))
-                if gidx is None:
-                    gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0], reuse_idx=prev,
-                                          center_src=fidx if prev is not None else None,
-                                          grid=grids.get(("sa", i)) if prev is None else None)
-                self_q = {}  # from here on the level is the sampled one
-                if fea is None:
-                    m = pre + ".sa.mlp"
-                    new_fea = ops.group_mlp_max_from_xyz(xyz, w0, self.p("point_mlp0.bias"), new_xyz, gidx,
-                                                         self.p(m + ".0.weight"), self.p(m + ".0.bias"),
-                                                         self.p(m + ".1.ln.weight"), self.p(m + ".1.ln.bias"), radii[0])
-                else:
-                    new_fea = self._group(pre + ".sa.mlp", radii[0], xyz, fea, new_xyz, gidx)
-                if trace is not None:
-                    trace[pre + ".fps.idx"], trace[pre + ".fps.new"] = fidx, new_xyz
-                    trace[pre + ".sa.idx"], trace[pre + ".sa.out"] = gidx, new_fea
-                for j in range(1, len(radii)):
-                    q = f"{pre}.irm.{j - 1}"
-                    key = (float(radii[j]), int(ks[j]))
-                    if key not in self_q:
-                        self_q[key] = knn[("la", i, key)] if ("la", i, key) in knn else ops.knn_hybrid(
-                            new_xyz, new_len, new_xyz, ks[j], radii[j], grid=grids.get(("la", i, key)))
-                    lidx = self_q[key]
-                    t = self._group(q + ".la.mlp", radii[j], new_xyz, new_fea, new_xyz, lidx)
-                    u = self._mlp_ln(t, q + ".pw_conv.0", q + ".pw_conv.1.ln", ops.ACT_RELU)
-                    new_fea = self._mlp_ln(u, q + ".pw_conv.3", q + ".pw_conv.4.ln", ops.ACT_RELU, post=new_fea)
+                # (self._price_tail > 0: levels 3+ and the upsamplers are computed that many extra times, results identical --
+                # scripts/price_tail.py measures what the launch-bound tail of the encoder costs a pipelined step)
+                for _rep in range(1 + (self._price_tail if i >= 3 else 0)):
+                    prev = self_q.get((float(radii[0]), int(ks[0])))
+                    grids, knn = samp.get("grids", {}), samp.get("knn", {})
+                    gidx = knn.get(("sa", i))
+                    if gidx is None:
+                        gidx = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0], reuse_idx=prev,
+                                              center_src=fidx if prev is not None else None,
+                                              grid=grids.get(("sa", i)) if prev is None else None)
+                    self_q = {}  # from here on the level is the sampled one
+                    if fea is None:
+                        m = pre + ".sa.mlp"
+                        new_fea = ops.group_mlp_max_from_xyz(xyz, w0, self.p("point_mlp0.bias"), new_xyz, gidx,
+                                                             self.p(m + ".0.weight"), self.p(m + ".0.bias"),
+                                                             self.p(m + ".1.ln.weight"), self.p(m + ".1.ln.bias"), radii[0])
+                    else:
+                        new_fea = self._group(pre + ".sa.mlp", radii[0], xyz, fea, new_xyz, gidx)
                     if trace is not None:
-                        trace[q + ".la.idx"], trace[q + ".la.out"], trace[q + ".out"] = lidx, t, new_fea
+                        trace[pre + ".fps.idx"], trace[pre + ".fps.new"] = fidx, new_xyz
+                        trace[pre + ".sa.idx"], trace[pre + ".sa.out"] = gidx, new_fea
+                    for j in range(1, len(radii)):
+                        q = f"{pre}.irm.{j - 1}"
+                        key = (float(radii[j]), int(ks[j]))
+                        if key not in self_q:
+                            self_q[key] = knn[("la", i, key)] if ("la", i, key) in knn else ops.knn_hybrid(
+                                new_xyz, new_len, new_xyz, ks[j], radii[j], grid=grids.get(("la", i, key)))
+                        lidx = self_q[key]
+                        t = self._group(q + ".la.mlp", radii[j], new_xyz, new_fea, new_xyz, lidx)
+                        u = self._mlp_ln(t, q + ".pw_conv.0", q + ".pw_conv.1.ln", ops.ACT_RELU)
+                        new_fea = self._mlp_ln(u, q + ".pw_conv.3", q + ".pw_conv.4.ln", ops.ACT_RELU, post=new_fea)
+                        if trace is not None:
+                            trace[q + ".la.idx"], trace[q + ".la.out"], trace[q + ".out"] = lidx, t, new_fea
                 levels.append((new_xyz, new_fea, new_len))
             L = self.downsample_layers
             for i in range(self.upsample_layers):
                 xyz1, fea1, len1 = levels[L - i - 1]
                 xyz2, fea2, len2 = levels[-1]
                 q = f"upsampler.{i}"
-                x = ops.three_interp_cat(xyz1, xyz2, len2, fea1, fea2)
-                x = self._mlp_ln(x, q + ".mlp.0", q + ".mlp.1.ln", ops.ACT_RELU)
-                x = self._mlp_ln(x, q + ".mlp.3", q + ".mlp.4.ln", ops.ACT_RELU)
+                for _rep in range(1 + self._price_tail):
+                    x = ops.three_interp_cat(xyz1, xyz2, len2, fea1, fea2)
+                    x = self._mlp_ln(x, q + ".mlp.0", q + ".mlp.1.ln", ops.ACT_RELU)
+                    x = self._mlp_ln(x, q + ".mlp.3", q + ".mlp.4.ln", ops.ACT_RELU)
                 if trace is not None:
                     trace[q + ".out"] = x
                 levels.append((xyz1, x, len1))

@@ -21,12 +21,15 @@ EDGE_FLOATS = 56  # per edge: 20-float registration header (R, T, rmse, n_corr, 
 
 
 def _tensors(d):
-    """every tensor of a (possibly nested) dict"""
-    for v in d.values():
-        if isinstance(v, dict):
+    """every tensor of a (possibly nested) dict / list / tuple"""
+    if isinstance(d, torch.Tensor):
+        yield d
+    elif isinstance(d, dict):
+        for v in d.values():
             yield from _tensors(v)
-        elif isinstance(v, torch.Tensor):
-            yield v
+    elif isinstance(d, (list, tuple)):
+        for v in d:
+            yield from _tensors(v)
 
 
 @dataclass
@@ -49,6 +52,14 @@ class HotPath:
         self.geometry_depth = 2      # geometry launches in flight ahead of the feature stage (one HIP stream each)
         self.geometry_group = 1      # batches whose first-level sampling shares ONE launch
         self.feature_streams = 1     # >1: consecutive batches' feature stages alternate between side streams
+        # > 0: the feature stage as TWO pipeline stages -- the downsampling levels below `feature_split` on the caller's stream,
+        # the rest (lower levels, upsamplers, descriptors) on a stream of its own, so that the next batch's first level does
+        # not wait for this batch's launch-bound tail.  Built because every extra evaluation of levels 3+ costs the pipelined
+        # step its whole 0.44 ms (scripts/price_tail.py); bit-identical results -- and SLOWER at every cut (4.88 / 4.58 / 4.39 /
+        # 4.89 ms per step at levels 1 / 2 / 3 / 4 against 4.18, with 8 hardware queues; worse with the default 4, where a fifth
+        # stream shares a queue with a sampling launch): one more kernel stream on the chip costs more than the shorter chain
+        # returns.  Off.
+        self.feature_split = 0
         # chain = True: frame 0 of a batch is registered against the frame BEFORE the batch (the previous batch's last
         # frame, or -- several ranks -- the last frame of the rank that owns the preceding block, shard.exchange_halo)
         # instead of the batch's own last frame (the single-GPU ring, which costs the same and needs no hand-over)
@@ -201,10 +212,12 @@ class HotPath:
             self._side = dict(geo=[torch.cuda.Stream(device=dev) for _ in range(max(1, self.geometry_depth))],
                               reg=torch.cuda.Stream(device=dev),
                               feat=[torch.cuda.Stream(device=dev) for _ in range(self.feature_streams)]
-                              if self.feature_streams > 1 else [])
+                              if self.feature_streams > 1 else [],
+                              featb=torch.cuda.Stream(device=dev) if self.feature_split else None)
             if self.reserve_bytes:
                 # the allocator's cache is per stream: every stream of the pipeline gets its share
-                streams = [torch.cuda.current_stream(dev)] + self._side["geo"] + [self._side["reg"]] + self._side["feat"]
+                streams = [torch.cuda.current_stream(dev)] + self._side["geo"] + [self._side["reg"]] + self._side["feat"] + \
+                    ([self._side["featb"]] if self._side["featb"] is not None else [])
                 free = torch.cuda.mem_get_info(dev)[0]
                 n = min(int(self.reserve_bytes), free // 2) // len(streams)
                 if n >= (1 << 29):
@@ -276,6 +289,19 @@ class HotPath:
                 desc = self.extract(points, padding, presampled=pre)
                 desc_ready = sf.record_event()
             desc.record_stream(main)  # handed to the caller (gather, host copies) on its stream
+        elif self._side["featb"] is not None and 0 < self.feature_split < self.encoder.downsample_layers:
+            fb = self._side["featb"]
+            main.wait_event(ready)
+            state = self.encoder(points, padding, presampled=pre, stop_level=self.feature_split)
+            half = main.record_event()
+            for t in _tensors(state):
+                t.record_stream(fb)       # made (or handed over) on the caller's stream, read on the second feature stream
+            with torch.cuda.stream(fb):
+                fb.wait_event(half)
+                desc = self.encoder(points, padding, resume=state, descriptor_scale=self.coor_scale,
+                                    spare_frames=1 if self.chain else 0)
+                desc_ready = fb.record_event()
+            desc.record_stream(main)      # handed to the caller (gather, host copies) on its stream
         else:
             main.wait_event(ready)
             desc = self.extract(points, padding, presampled=pre)

@@ -65,8 +65,13 @@ def test_size_independent_properties(hot):
     assert float(edges[0].T.cpu().abs().max()) < 1e-3
 
 
-def test_streaming_pipeline_equals_plain_steps(hot):
-    # submit/flush (side-stream presampling overlapped with the previous batch) must give bit-identical results
+@pytest.mark.parametrize("feature_split", [0, 1, 3])
+def test_streaming_pipeline_equals_plain_steps(hot, feature_split):
+    # submit/flush (side-stream presampling overlapped with the previous batch) must give bit-identical results -- also with the
+    # feature stage cut in two pipeline stages on two streams (Encoder.forward's stop_level / resume)
+    from deeppointmap_amd.pipeline import HotPath
+    hot = HotPath(hot.encoder, hot.decoder)
+    hot.feature_split = feature_split
     batches = []
     for i in range(5):
         pts, pad = synthetic.frames(2, 16384, start=2 * i)
