@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--geometry-group", type=int, default=None, help="batches per first-level sampling launch (pipeline tuning)")
     ap.add_argument("--geometry-knn", type=int, default=None, help="1: neighbour queries run in the geometry stage, 0: in the feature stage")
     ap.add_argument("--feature-streams", type=int, default=None, help="feature-stage streams (pipeline tuning)")
+    ap.add_argument("--geometry-knn-from", type=int, default=None, help="first downsampling level whose neighbour queries run in the geometry stage (pipeline tuning; -1 = none)")
     ap.add_argument("--feature-split", type=int, default=None, help="downsampling level at which the feature stage moves to its second stream (pipeline tuning; 0 = one stage)")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time breakdown to stderr")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
@@ -156,6 +157,8 @@ def main():
         hot.geometry_group = args.geometry_group
     if args.geometry_knn is not None:
         hot.encoder.presample_neighbours = bool(args.geometry_knn)
+    if args.geometry_knn_from is not None:
+        hot.encoder.presample_neighbours_from = args.geometry_knn_from if args.geometry_knn_from >= 0 else None
     if args.feature_streams is not None:
         hot.feature_streams = args.feature_streams
     if args.feature_split is not None:

@@ -47,13 +47,21 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restri
 #ifndef DPM_B3_WIDE
 #define DPM_B3_WIDE 1024
 #endif
+#ifndef DPM_B3_DEEP
+#define DPM_B3_DEEP 256    // launches of at most this many workgroups (one per CU) keep four K-tiles in flight
+#endif
 constexpr int B3_KT = 32, B3_LD = B3_KT;       // K-tile; LDS rows of 64 bytes, chunks swizzled (b3_col, dpm_common.h)
 
 // BM x BN = 64 x 128 (wave tile 32 x 64) for the large problems, 64 x 64 (wave tile 32 x 32 = 2 x 2 blocks), or 32 x 32 (one block
 // per wave) for problems too small to fill the chip with 64 x 64 tiles; an output element sees the same instructions in the same order either way (same bits).
 // XVEC: the rows of X are 16-byte aligned (false: four scalar loads per group -- a token matrix with rows of 131 floats must
 // take the same kernel as one with rows of 132, or a layer's bits would depend on how its input happens to be laid out)
-template <int BM, int BN, bool XVEC>
+// PF: K-tiles in flight (a ring of PF register sets for both operands, the loop unrolled PF times so that the ring index is
+// static).  1 for launches that fill the chip several times over -- there other workgroups cover a tile's load latency and the
+// registers of a deeper ring cost occupancy (measured: 97 -> 99.9 / 99.4 / 106.5 us at 2 / 3 / 4 on 32 768 x 256 -> 768) --,
+// 4 for small launches (at most a few workgroups per CU: the registration of ONE pair, the encoder's lower levels), where every
+// trip of the K loop otherwise waits out a whole L2 / HBM round trip.  Same instructions per output element: same bits.
+template <int BM, int BN, bool XVEC, int PF = 1>
 __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ Wp, int ldw,
                                                       long long plane, const float *__restrict__ bias,
                                                       const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo,
@@ -83,14 +91,18 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
         if (XVEC) return *reinterpret_cast<const f32x4 *>(p);
         return f32x4{p[0], p[1], p[2], p[3]};
     };
-    f32x4 xv[PX];
+    f32x4 xv[PF][PX];
+    u32x4 wv[PF][PW][3];
 #pragma unroll
-    for (int p = 0; p < PX; ++p) xv[p] = load_x(xp[p]);
-    u32x4 wv[PW][3];
+    for (int d = 0; d < PF; ++d) {
+        const int kd = min(d * B3_KT, Cin - B3_KT);
 #pragma unroll
-    for (int p = 0; p < PW; ++p)
+        for (int p = 0; p < PX; ++p) xv[d][p] = load_x(xp[p] + kd);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) wv[p][pl] = *reinterpret_cast<const u32x4 *>(wp[p] + pl * plane);
+        for (int p = 0; p < PW; ++p)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wv[d][p][pl] = *reinterpret_cast<const u32x4 *>(wp[p] + pl * plane + kd);
+    }
     f32x4 acc[MB][NB];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -104,25 +116,29 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
         *reinterpret_cast<u32x2 *>(&Xs[1][r][b3_col(r, xk)]) = u32x2{pack2(m0, m1), pack2(m2, m3)};
         *reinterpret_cast<u32x2 *>(&Xs[2][r][b3_col(r, xk)]) = u32x2{pack2(l0, l1), pack2(l2, l3)};
     };
-    for (int k0 = 0; k0 < Cin; k0 += B3_KT) {
+    for (int kb = 0; kb < Cin; kb += B3_KT * PF)
 #pragma unroll
-        for (int p = 0; p < PX; ++p) stage_x(xv[p], p * 32 + xr_);
+    for (int d = 0; d < PF; ++d) {
+        const int k0 = kb + d * B3_KT;
+        if (PF > 1 && k0 >= Cin) break;   // uniform
+#pragma unroll
+        for (int p = 0; p < PX; ++p) stage_x(xv[d][p], p * 32 + xr_);
         if (WT >= 256 || t < WT) {
 #pragma unroll
             for (int p = 0; p < PW; ++p)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(&Ws[pl][p * 64 + wr_][b3_col(wr_, wk)]) = wv[p][pl];
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(&Ws[pl][p * 64 + wr_][b3_col(wr_, wk)]) = wv[d][p][pl];
         }
         __syncthreads();
         {   // the next K-tile is requested while this one feeds the MFMAs -- unconditionally (the last trip re-reads its own
             // tile): behind a branch the prefetch group is serialised behind a full wait (gemm.hip, load4)
-            const int kn = min(k0 + B3_KT, Cin - B3_KT);
+            const int kn = min(k0 + PF * B3_KT, Cin - B3_KT);
 #pragma unroll
-            for (int p = 0; p < PX; ++p) xv[p] = load_x(xp[p] + kn);
+            for (int p = 0; p < PX; ++p) xv[d][p] = load_x(xp[p] + kn);
 #pragma unroll
             for (int p = 0; p < PW; ++p)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wv[p][pl] = *reinterpret_cast<const u32x4 *>(wp[p] + pl * plane + kn);
+                for (int pl = 0; pl < 3; ++pl) wv[d][p][pl] = *reinterpret_cast<const u32x4 *>(wp[p] + pl * plane + kn);
         }
         // (the scheduler sinks these loads below the matrix instructions to save 20 registers; pinning them up here with
         // sched_barrier(0) was measured -- 116 us alone either way, 4.47 against 4.48 ms per pipelined step -- and not kept)
@@ -353,17 +369,23 @@ extern "C" int dpm_linear_bf16x3(const float *x, int ldx, const void *w_planes, 
     const bool xvec = ldx % 4 == 0 && al(x);
     // tile choice as in dpm_linear: 64 x 64 from 192 such tiles on (or tall problems), 32 x 32 below -- the bits do not depend on it
     const long long big = (long long)dpm_cdiv(R, 64) * dpm_cdiv(Cout, 64);
-#define DPM_B3_LAUNCH(TM, TN, V)                                                                                              \
-    hipLaunchKernelGGL((gemm_b3_kernel<TM, TN, V>), dim3(dpm_cdiv(Cout, TN), dpm_cdiv(R, TM)), dim3(256), 0, (hipStream_t)stream, x, ldx, \
+#define DPM_B3_LAUNCH(TM, TN, V, PF)                                                                                          \
+    hipLaunchKernelGGL((gemm_b3_kernel<TM, TN, V, PF>), dim3(dpm_cdiv(Cout, TN), dpm_cdiv(R, TM)), dim3(256), 0, (hipStream_t)stream, x, ldx, \
                        (const uint16_t *)w_planes, ldw, plane_stride, bias, residual, ldr, out, ldo, R, Cin, Cout, act)
     if (DPM_B3_WIDE && xvec && Cout % 128 == 0 && (long long)dpm_cdiv(R, 64) * (Cout / 128) >= DPM_B3_WIDE) {
-        DPM_B3_LAUNCH(64, 128, true);
+        DPM_B3_LAUNCH(64, 128, true, 1);
     } else if (big >= 192 || (R > 1024 && Cout > 32)) {
-        if (xvec) DPM_B3_LAUNCH(64, 64, true);
-        else DPM_B3_LAUNCH(64, 64, false);
+        const bool small = big <= DPM_B3_DEEP;   // few workgroups per CU: K-tiles four ahead
+        if (xvec && small) DPM_B3_LAUNCH(64, 64, true, 4);
+        else if (xvec) DPM_B3_LAUNCH(64, 64, true, 1);
+        else if (small) DPM_B3_LAUNCH(64, 64, false, 4);
+        else DPM_B3_LAUNCH(64, 64, false, 1);
     } else {
-        if (xvec) DPM_B3_LAUNCH(32, 32, true);
-        else DPM_B3_LAUNCH(32, 32, false);
+        const bool small = (long long)dpm_cdiv(R, 32) * dpm_cdiv(Cout, 32) <= 2 * DPM_B3_DEEP;
+        if (xvec && small) DPM_B3_LAUNCH(32, 32, true, 4);
+        else if (xvec) DPM_B3_LAUNCH(32, 32, true, 1);
+        else if (small) DPM_B3_LAUNCH(32, 32, false, 4);
+        else DPM_B3_LAUNCH(32, 32, false, 1);
     }
 #undef DPM_B3_LAUNCH
     return dpm_launch_status();

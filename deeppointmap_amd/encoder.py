@@ -44,6 +44,9 @@ class Encoder(ParamTree):
         # presample() also answers the neighbour queries (coordinates only): a pipeline knob -- where they run moves
         # work between the geometry and the feature stage, the results are the same tensors either way
         self.presample_neighbours = False
+        # ... or only the queries of the downsampling levels from this one on (None: none): the lower levels' searches are
+        # microseconds of work each but launches of the feature stream's dependent chain, and the geometry streams have slack
+        self.presample_neighbours_from = None
         self._price_tail = 0   # measurement only (scripts/price_tail.py): extra evaluations of levels 3+ and the upsamplers
         self.eval()
 
@@ -140,18 +143,25 @@ class Encoder(ParamTree):
                         grids[("la", i, key)] = ops.knn_grid(pts_i, len_i, radii[j])
                     answered.add(key)
             out["grids"] = grids
-            if self.presample_neighbours and n_levels == len(self.encoder_cfg.npoint):
-                out["knn"] = self._neighbour_queries(out)
+            if n_levels == len(self.encoder_cfg.npoint):
+                if self.presample_neighbours:
+                    out["knn"] = self._neighbour_queries(out)
+                elif self.presample_neighbours_from is not None:
+                    out["knn"] = self._neighbour_queries(out, first_level=int(self.presample_neighbours_from))
         return out
 
-    def _neighbour_queries(self, samp: dict) -> dict:
-        """Every neighbour query of the encoder -- they depend on coordinates only, like the sampling.  Same reuse
-        rules as forward(): ("sa", i) / ("la", i, (radius, K)) -> idx."""
+    def _neighbour_queries(self, samp: dict, first_level: int = 0) -> dict:
+        """The neighbour queries of the downsampling levels from `first_level` on -- they depend on coordinates only, like the
+        sampling.  Same reuse rules as forward(): ("sa", i) / ("la", i, (radius, K)) -> idx (a reused answer is a copy of rows
+        of an identical query: the same tensors whether a level's first query finds a predecessor here or not)."""
         enc, grids, knn = self.encoder_cfg, samp.get("grids", {}), {}
         xyz, lengths, self_q = samp["xyz"], samp["lengths"], {}
         for i in range(len(enc.npoint)):
             radii, ks = enc.radius_list[i], enc.nsample_list[i]
             fidx, new_xyz, new_len = samp[f"fidx{i}"], samp[f"xyz{i}"], samp[f"len{i}"]
+            if i < first_level:
+                xyz, lengths, self_q = new_xyz, new_len, {}
+                continue
             prev = self_q.get((float(radii[0]), int(ks[0])))
             knn[("sa", i)] = ops.knn_hybrid(xyz, lengths, new_xyz, ks[0], radii[0], reuse_idx=prev,
                                             center_src=fidx if prev is not None else None,

@@ -32,3 +32,20 @@ for rep in range(2):
     for extra in (0, 1, 2, 0):
         hot.encoder._price_tail = extra
         print(f"tail evaluated {1 + extra} x per batch: {run(60):.3f} ms per step", flush=True)
+
+# ... and the same question for PURE latency on the feature stream (a one-thread spin kernel in front of the descriptor emission:
+# no chip work, no memory traffic): does the step follow the feature stream's chain length?
+from deeppointmap_amd import ops
+hot.encoder._price_tail = 0
+orig = ops.emit_descriptors
+for us in (0, 200, 400, 0):
+    def emit(*a, _us=us, **k):
+        if _us:
+            torch.cuda._sleep(int(_us * 1000))   # the spin kernel counts ~1 cycle per ns on this part (checked below)
+        return orig(*a, **k)
+    ops.emit_descriptors = emit
+    import deeppointmap_amd.encoder as enc_mod
+    enc_mod.ops.emit_descriptors = emit
+    print(f"spin of {us} us on the feature stream: {run(60):.3f} ms per step", flush=True)
+torch.cuda.synchronize(); t0 = time.perf_counter(); torch.cuda._sleep(400 * 1000); torch.cuda.synchronize()
+print(f"(a 400 us spin alone takes {(time.perf_counter() - t0) * 1e3:.3f} ms)")
