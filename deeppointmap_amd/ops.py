@@ -520,7 +520,8 @@ def linear_layernorm(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tens
             and x.dtype == torch.float32):
         wp = _weight_planes(W)
         if wp is not None and (bias is None or bias.data_ptr() % 16 == 0):
-            if Cout in FUSED_LN_WIDTHS and x2.shape[0] >= FUSED_LN_MIN_ROWS and x2.is_contiguous() and knobs.FUSED_LN:
+            if (Cout in FUSED_LN_WIDTHS and (x2.shape[0] >= FUSED_LN_MIN_ROWS or x2.shape[0] <= knobs.FUSED_LN_SMALL_ROWS)
+                    and x2.is_contiguous() and knobs.FUSED_LN):
                 planes, off, n = wp
                 out = torch.empty(*x.shape[:-1], Cout, device=x.device, dtype=torch.float32)
                 for nm, t in (("pre", pre), ("post", post)):

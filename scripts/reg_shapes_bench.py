@@ -2,6 +2,8 @@
 threads make it) at the three shapes of a SLAM step: eager launches against the captured HIP graph, results compared."""
 import sys, time, torch
 sys.path.insert(0, '.')
+from deeppointmap_amd import knobs
+knobs.apply_env()
 from deeppointmap_amd.config import default_args
 from deeppointmap_amd.decoder import Decoder
 from deeppointmap_amd.weights import init_procedural
