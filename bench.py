@@ -472,7 +472,7 @@ def main():
                 # term products per fp32 product.  `achieved` counts the EXECUTED bf16 flops against the dense bf16 peak;
                 # `fp32_equivalent` is the fp32 product it delivers against the fp32 matrix peak it would otherwise run at.
                 PEAK, mult = 2500.0, 6
-                kern = ("gemm_b3_kernel<64,64> (csrc/gemm_b3.hip: fp32 GEMM as an exact three-way bf16 split, 6 products, fp32 "
+                kern = ("gemm_b3_kernel<64,128> (csrc/gemm_b3.hip: fp32 GEMM as an exact three-way bf16 split, 6 products, fp32 "
                         f"accumulate) on the decoder's 256->768 attention projections ({rows} token rows per launch)")
                 note = ("v_mfma_f32_16x16x32_bf16, dense bf16 peak ~2500 TFLOP/s; achieved = 6 x the fp32 product's flops; timed "
                         "with HIP events on its launch stream while the other pipeline stages share the chip")
