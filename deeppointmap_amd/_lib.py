@@ -56,6 +56,7 @@ SIGNATURES = {
     "dpm_split_bf16x3": (I, [P, LL, P, P]),
     "dpm_linear_bf16x3": (I, [P, I, P, I, LL, P, P, I, P, I, I, I, I, I, P]),
     "dpm_linear_layernorm_bf16x3": (I, [P, I, P, I, LL, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "dpm_pwconv_pair_bf16x3": (I, [P, I, P, LL, P, P, P, P, LL, P, P, P, P, P, I, I, I, P]),
     "dpm_layernorm": (I, [P, I, P, P, P, P, P, I, I, I, I, P]),
     "dpm_linear_layernorm": (I, [P, I, P, I, P, P, P, P, P, P, I, I, I, I, I, P]),
     "dpm_three_interp_cat": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),

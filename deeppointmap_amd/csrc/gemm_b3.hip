@@ -349,6 +349,183 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_ln_b3_kernel(const float 
     }
 }
 
+
+// InvResMLP's point-wise pair (network/encoder/pointnext.py:118-138: pw_conv = Conv1d(C, 4C) -> LayerNorm -> ReLU -> Conv1d(4C, C)
+// -> LayerNorm, then + residual and ReLU) as ONE kernel for C = 32 (the first level: 262 144 rows per 64-frame batch, where the
+// two fused GEMM + LayerNorm kernels move 369 MB through HBM for 100 MB of input and output -- the 4C-wide intermediate is
+// written and read back).  A wave owns 16 rows at a time and keeps the intermediate in REGISTERS:
+//   h = relu(LN(x W1^T + b1)): x fragments straight from global memory (a row is 128 bytes, split in registers), W1 planes in
+//       LDS (whole: 24 KB); the accumulators hold h[row = lane & 15][column 16 j + 4 g + q] (g = lane >> 4), whole rows per wave,
+//       so the LayerNorm sums are two lane swaps;
+//   y = LN(h W2^T + b2) + post, relu: the accumulator registers of column blocks 2 s, 2 s + 1 ARE the B operand of K-step s under
+//       a permutation of k (slot 8 g + e <-> column 16 (2 s + (e >> 2)) + 4 g + (e & 3)), which the caller applies to W2's columns
+//       once when it makes the planes (w2_planes_kperm): h is split in registers and never leaves them.
+// Both products are bf16x3 (same arithmetic as gemm_b3_kernel; the row statistics are summed in another association than the
+// two-kernel form's, so the results agree to rounding, not bit for bit).  The workgroup walks `tiles_per_wave` row tiles per wave
+// with the weights resident in LDS.
+#ifndef DPM_PW_GRID
+#define DPM_PW_GRID 768
+#endif
+constexpr int PW_C = 32, PW_H = 128;
+__device__ __forceinline__ float pw_rows4_sum(float v) {   // over the four lanes l, l+16, l+32, l+48 (decoder_ops.hip, rows4_sum)
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__global__ __launch_bounds__(256) void pwconv_pair_b3_kernel(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ W1p,
+                                                            long long plane1, const float *__restrict__ b1,
+                                                            const float *__restrict__ g1, const float *__restrict__ be1,
+                                                            const uint16_t *__restrict__ W2p, long long plane2,
+                                                            const float *__restrict__ b2, const float *__restrict__ g2,
+                                                            const float *__restrict__ be2, const float *__restrict__ post,
+                                                            float *__restrict__ out, int R, int tiles_per_wave) {
+    __shared__ __attribute__((aligned(16))) uint16_t W1s[3][PW_H][PW_C];        // 24 KB, rows swizzled (b3_col)
+    __shared__ __attribute__((aligned(16))) uint16_t W2s[3][PW_H / 32][PW_C][32];  // 24 KB: [plane][K-step][output column][slot]
+    __shared__ __attribute__((aligned(16))) float vec1[3][PW_H];                 // b1 | gamma1 | beta1
+    __shared__ __attribute__((aligned(16))) float vec2[3][PW_C];                 // b2 | gamma2 | beta2
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, fr = lane & 15;
+    // weights -> LDS: 16-byte pieces; W1 rows are [column][32 k], W2 rows (already K-permuted) [column][128 slots]
+    for (int e = t; e < 3 * PW_H * 4; e += 256) {
+        const int pl = e / (PW_H * 4), r = (e / 4) % PW_H, c = (e & 3) * 8;
+        *reinterpret_cast<u32x4 *>(&W1s[pl][r][b3_col(r, c)]) = *reinterpret_cast<const u32x4 *>(W1p + pl * plane1 + r * PW_C + c);
+    }
+    for (int e = t; e < 3 * PW_C * 16; e += 256) {
+        const int pl = e / (PW_C * 16), r = (e / 16) % PW_C, c = (e & 15) * 8;   // c: slot offset inside the row of 128
+        *reinterpret_cast<u32x4 *>(&W2s[pl][c >> 5][r][b3_col(r, c & 31)]) =
+            *reinterpret_cast<const u32x4 *>(W2p + pl * plane2 + r * PW_H + c);
+    }
+    if (t < PW_H) vec1[0][t] = b1 ? b1[t] : 0.f, vec1[1][t] = g1[t], vec1[2][t] = be1[t];
+    if (t < PW_C) vec2[0][t] = b2 ? b2[t] : 0.f, vec2[1][t] = g2[t], vec2[2][t] = be2[t];
+    __syncthreads();
+    const long long tile0 = ((long long)blockIdx.x * 4 + w) * tiles_per_wave;
+    // x fragment: this lane's 8 consecutive k of its row; the next tile's rows are requested while this one is computed
+    f32x4 nx0, nx1, np0, np1;
+    auto request = [&](long long r0) {
+        const int r = (int)min(r0 + fr, (long long)R - 1);
+        const float *xp = X + (size_t)r * ldx + 8 * g;
+        nx0 = *reinterpret_cast<const f32x4 *>(xp), nx1 = *reinterpret_cast<const f32x4 *>(xp + 4);
+        np0 = post ? *reinterpret_cast<const f32x4 *>(post + (size_t)r * PW_C + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        np1 = post ? *reinterpret_cast<const f32x4 *>(post + (size_t)r * PW_C + 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    request(min(tile0 * 16, (long long)R - 1));
+    for (int it = 0; it < tiles_per_wave; ++it) {
+        const long long row0 = (tile0 + it) * 16;
+        if (row0 >= R) break;
+        const int row = (int)min(row0 + fr, (long long)R - 1);
+        const f32x4 x0 = nx0, x1 = nx1, p0 = np0, p1 = np1;
+        request(min(row0 + 16, (long long)R - 1));   // (clamped: the last trip re-reads a valid row)
+        bf16x8 xb[3];
+        {
+            unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3(x0[e], hh[e], mm[e], ll[e]), split3(x1[e], hh[4 + e], mm[4 + e], ll[4 + e]);
+            xb[0] = __builtin_bit_cast(bf16x8, u32x4{pack2(hh[0], hh[1]), pack2(hh[2], hh[3]), pack2(hh[4], hh[5]), pack2(hh[6], hh[7])});
+            xb[1] = __builtin_bit_cast(bf16x8, u32x4{pack2(mm[0], mm[1]), pack2(mm[2], mm[3]), pack2(mm[4], mm[5]), pack2(mm[6], mm[7])});
+            xb[2] = __builtin_bit_cast(bf16x8, u32x4{pack2(ll[0], ll[1]), pack2(ll[2], ll[3]), pack2(ll[4], ll[5]), pack2(ll[6], ll[7])});
+        }
+        // ---- h = x W1^T: 8 column blocks of 16, K = 32 = one instruction deep; two blocks at a time
+        f32x4 h[PW_H / 16];
+#pragma unroll
+        for (int j = 0; j < PW_H / 16; j += 2) {
+            bf16x8 a[2][3];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[jj][pl] = *reinterpret_cast<const bf16x8 *>(&W1s[pl][(j + jj) * 16 + fr][b3_col(fr, 8 * g)]);
+            h[j] = h[j + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define DPM_PW1(PWQ, PXQ)                                                                             \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                  \
+        h[j + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj][PWQ], xb[PXQ], h[j + jj], 0, 0, 0)
+            DPM_PW1(1, 1);
+            DPM_PW1(2, 0);
+            DPM_PW1(0, 2);
+            DPM_PW1(1, 0);
+            DPM_PW1(0, 1);
+            DPM_PW1(0, 0);
+#undef DPM_PW1
+        }
+        // + bias, LayerNorm over the row's 128 columns (32 here, the rest in the lanes 16 / 32 / 48 away), ReLU
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < PW_H / 16; ++j) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(&vec1[0][16 * j + 4 * g]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h[j][q] += bv[q], sum += h[j][q];
+        }
+        const float mu = pw_rows4_sum(sum) * (1.f / PW_H);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < PW_H / 16; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h[j][q] -= mu, sq = fmaf(h[j][q], h[j][q], sq);
+        const float rs = rsqrtf(pw_rows4_sum(sq) * (1.f / PW_H) + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < PW_H / 16; ++j) {
+            const f32x4 gv = *reinterpret_cast<const f32x4 *>(&vec1[1][16 * j + 4 * g]);
+            const f32x4 ev = *reinterpret_cast<const f32x4 *>(&vec1[2][16 * j + 4 * g]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h[j][q] = fmaxf(fmaf(h[j][q] * rs, gv[q], ev[q]), 0.f);
+        }
+        // ---- y = h W2^T: 2 column blocks, 4 K-steps; the B operand of K-step s = this lane's h values of blocks 2 s, 2 s + 1
+        f32x4 y[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s4 = 0; s4 < PW_H / 32; ++s4) {
+            unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split3(h[2 * s4 + (e >> 2)][e & 3], hh[e], mm[e], ll[e]);
+            bf16x8 hb[3];
+            hb[0] = __builtin_bit_cast(bf16x8, u32x4{pack2(hh[0], hh[1]), pack2(hh[2], hh[3]), pack2(hh[4], hh[5]), pack2(hh[6], hh[7])});
+            hb[1] = __builtin_bit_cast(bf16x8, u32x4{pack2(mm[0], mm[1]), pack2(mm[2], mm[3]), pack2(mm[4], mm[5]), pack2(mm[6], mm[7])});
+            hb[2] = __builtin_bit_cast(bf16x8, u32x4{pack2(ll[0], ll[1]), pack2(ll[2], ll[3]), pack2(ll[4], ll[5]), pack2(ll[6], ll[7])});
+            bf16x8 a[2][3];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[jj][pl] = *reinterpret_cast<const bf16x8 *>(&W2s[pl][s4][jj * 16 + fr][b3_col(fr, 8 * g)]);
+#define DPM_PW2(PWQ, PXQ)                                                                             \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                  \
+        y[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj][PWQ], hb[PXQ], y[jj], 0, 0, 0)
+            DPM_PW2(1, 1);
+            DPM_PW2(2, 0);
+            DPM_PW2(0, 2);
+            DPM_PW2(1, 0);
+            DPM_PW2(0, 1);
+            DPM_PW2(0, 0);
+#undef DPM_PW2
+        }
+        // + bias, LayerNorm over 32 columns, + residual, ReLU; the lane owns columns 16 jj + 4 g .. + 3 of its row
+        float s2 = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(&vec2[0][16 * jj + 4 * g]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[jj][q] += bv[q], s2 += y[jj][q];
+        }
+        const float mu2 = pw_rows4_sum(s2) * (1.f / PW_C);
+        float q2 = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[jj][q] -= mu2, q2 = fmaf(y[jj][q], y[jj][q], q2);
+        const float rs2 = rsqrtf(pw_rows4_sum(q2) * (1.f / PW_C) + 1e-5f);
+        if (row0 + fr < R) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const f32x4 gv = *reinterpret_cast<const f32x4 *>(&vec2[1][16 * jj + 4 * g]);
+                const f32x4 ev = *reinterpret_cast<const f32x4 *>(&vec2[2][16 * jj + 4 * g]);
+                const f32x4 pv = jj ? p1 : p0;
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = fmaxf(fmaf(y[jj][q] * rs2, gv[q], ev[q]) + pv[q], 0.f);
+                *reinterpret_cast<f32x4 *>(out + (size_t)row * PW_C + 16 * jj + 4 * g) = o;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int dpm_split_bf16x3(const float *W, long long n, void *planes, dpm_stream_t stream) {
@@ -421,5 +598,28 @@ extern "C" int dpm_linear_layernorm_bf16x3(const float *x, int ldx, const void *
     else if (Cout == 32) DPM_GLN3(64, 32, 2, 2, 1);
     else return DPM_EUNSUPPORTED;
 #undef DPM_GLN3
+    return dpm_launch_status();
+}
+
+// InvResMLP's pw_conv pair in one kernel (pwconv_pair_b3_kernel): out = relu(LN2(relu(LN1(x W1^T + b1)) W2^T + b2) + post),
+// x (R, 32) with row stride ldx, W1 (128, 32) and W2 (32, 128) as bf16x3 planes (dpm_split_bf16x3), W2's columns PERMUTED
+// before the split: stored column 32 s + 8 g + e holds original column 16 (2 s + (e >> 2)) + 4 g + (e & 3).  post / out packed
+// (R, 32).  DPM_EUNSUPPORTED for other widths or unaligned operands.
+extern "C" int dpm_pwconv_pair_bf16x3(const float *x, int ldx, const void *w1_planes, long long plane1, const float *b1,
+                                      const float *g1, const float *be1, const void *w2_planes_kperm, long long plane2,
+                                      const float *b2, const float *g2, const float *be2, const float *post, float *out, int R,
+                                      int C, int H, dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && w1_planes && w2_planes_kperm && g1 && be1 && g2 && be2 && out && R >= 1 && ldx >= C);
+    auto al = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+    if (C != PW_C || H != PW_H || ldx % 4 != 0 || plane1 % 8 != 0 || plane2 % 8 != 0 || !al(x) || !al(w1_planes) ||
+        !al(w2_planes_kperm) || !al(post) || !al(out))
+        return DPM_EUNSUPPORTED;
+    const long long tiles = ((long long)R + 15) / 16;
+    // the weights (48 KB) are staged once per workgroup: enough row tiles per wave to pay for it, enough workgroups to fill the chip
+    // (one round of three resident workgroups per CU when there are rows enough; never fewer than 2 tiles per wave's worth)
+    const int tpw = (int)std::max<long long>(1, (tiles + 4LL * DPM_PW_GRID - 1) / (4LL * DPM_PW_GRID));
+    const unsigned grid = (unsigned)((tiles + 4LL * tpw - 1) / (4LL * tpw));
+    hipLaunchKernelGGL(pwconv_pair_b3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (const uint16_t *)w1_planes,
+                       plane1, b1, g1, be1, (const uint16_t *)w2_planes_kperm, plane2, b2, g2, be2, post, out, R, tpw);
     return dpm_launch_status();
 }

@@ -253,8 +253,15 @@ class Encoder(ParamTree):
                                 new_xyz, new_len, new_xyz, ks[j], radii[j], grid=grids.get(("la", i, key)))
                         lidx = self_q[key]
                         t = self._group(q + ".la.mlp", radii[j], new_xyz, new_fea, new_xyz, lidx)
-                        u = self._mlp_ln(t, q + ".pw_conv.0", q + ".pw_conv.1.ln", ops.ACT_RELU)
-                        new_fea = self._mlp_ln(u, q + ".pw_conv.3", q + ".pw_conv.4.ln", ops.ACT_RELU, post=new_fea)
+                        pair = ops.pwconv_pair(t, self.p(q + ".pw_conv.0.weight"), self.p(q + ".pw_conv.0.bias"),
+                                               self.p(q + ".pw_conv.1.ln.weight"), self.p(q + ".pw_conv.1.ln.bias"),
+                                               self.p(q + ".pw_conv.3.weight"), self.p(q + ".pw_conv.3.bias"),
+                                               self.p(q + ".pw_conv.4.ln.weight"), self.p(q + ".pw_conv.4.ln.bias"), post=new_fea)
+                        if pair is not None:     # the first level: both layers in one kernel, the 4C-wide intermediate in registers
+                            new_fea = pair
+                        else:
+                            u = self._mlp_ln(t, q + ".pw_conv.0", q + ".pw_conv.1.ln", ops.ACT_RELU)
+                            new_fea = self._mlp_ln(u, q + ".pw_conv.3", q + ".pw_conv.4.ln", ops.ACT_RELU, post=new_fea)
                         if trace is not None:
                             trace[q + ".la.idx"], trace[q + ".la.out"], trace[q + ".out"] = lidx, t, new_fea
                 levels.append((new_xyz, new_fea, new_len))

@@ -561,6 +561,44 @@ def linear_layernorm(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tens
     return layernorm(y, gamma, beta, act=act, post=post)
 
 
+def _pwconv_kperm() -> torch.Tensor:
+    """stored column -> original column of W2 for dpm_pwconv_pair_bf16x3 (include/dpm_hip.h): 32 s + 8 g + e <- 16 (2 s + (e >> 2)) + 4 g + (e & 3)"""
+    return torch.tensor([16 * (2 * s + (e >> 2)) + 4 * g + (e & 3) for s in range(4) for g in range(4) for e in range(8)], dtype=torch.long)
+
+
+def pwconv_pair(x: torch.Tensor, W1, b1, g1, be1, W2, b2, g2, be2, post: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """relu(LN2(relu(LN1(x W1^T + b1)) W2^T + b2) + post) in one kernel (InvResMLP's pw_conv pair, C = 32 only: csrc/gemm_b3.hip,
+    pwconv_pair_b3_kernel).  None when the layer / layout is not covered: the caller runs two linear_layernorm calls -- for EVERY
+    call of that layer (the decision depends on the layer's shape and the tensors' layout class, never on the row count)."""
+    C, H = W1.shape[1], W1.shape[0]
+    if not (knobs.FUSED_PWCONV and knobs.GEMM_BF16X3 and C == 32 and H == 128 and tuple(W2.shape[:2]) == (C, H) and x.is_cuda
+            and x.dtype == torch.float32 and x.is_contiguous() and W1.numel() == C * H and W2.numel() == C * H):
+        return None
+    wp1 = _weight_planes(W1)
+    if wp1 is None or (post is not None and (not post.is_contiguous() or post.numel() != x.numel())):
+        return None
+    for n, t_ in (("gamma1", g1), ("beta1", be1), ("gamma2", g2), ("beta2", be2)):
+        _chk(t_, torch.float32, n)
+
+    def make():
+        Wp = W2.reshape(C, H)[:, _pwconv_kperm().to(W2.device)].contiguous()
+        planes = torch.empty(3, C * H, device=W2.device, dtype=torch.int16)
+        _lib.check(_lib.load().dpm_split_bf16x3(_ptr(Wp), C * H, _ptr(planes), _stream(W2)), "dpm_split_bf16x3")
+        planes._dpm_keep = Wp   # (the split kernel reads it asynchronously)
+        return planes
+    planes2 = _derived("bf16x3-planes-kperm", (W2,), make)
+    planes1, off1, n1 = wp1
+    x2 = x.reshape(-1, C)
+    out = torch.empty_like(x)
+    st = _lib.load().dpm_pwconv_pair_bf16x3(_ptr(x2), C, planes1.data_ptr() + 2 * off1, n1, _ptr(b1), _ptr(g1), _ptr(be1),
+                                            planes2.data_ptr(), C * H, _ptr(b2), _ptr(g2), _ptr(be2), _ptr(post), _ptr(out),
+                                            x2.shape[0], C, H, _stream(x))
+    if st == -2:
+        return None
+    _lib.check(st, "dpm_pwconv_pair_bf16x3")
+    return out
+
+
 def three_interp_cat(xyz1, xyz2, lengths2, fea1, fea2) -> torch.Tensor:
     """fine xyz1 (B,N,3)/fea1 (B,N,D1), coarse xyz2 (B,S,3)/fea2 (B,S,D2) -> (B,N,D1+D2)."""
     for n, t in (("xyz1", xyz1), ("xyz2", xyz2), ("fea1", fea1), ("fea2", fea2)):

@@ -322,6 +322,19 @@ int dpm_linear_layernorm_bf16x3(const float *x, int ldx, const void *w_planes, i
                                 const float *bias, const float *pre, const float *gamma, const float *beta, const float *post,
                                 float *out, int ldo, int R, int Cin, int Cout, int act, dpm_stream_t stream);
 
+/* InvResMLP's point-wise pair (network/encoder/pointnext.py:118-138: pw_conv = Conv1d(C, 4C, 1) -> LayerNorm1d -> ReLU ->
+ * Conv1d(4C, C, 1) -> LayerNorm1d, then the residual and ReLU) as ONE kernel for C = 32, H = 4C = 128 (the first level, whose
+ * 4C-wide intermediate is otherwise written to and read back from HBM): out = relu(LN2(relu(LN1(x W1^T + b1)) W2^T + b2) + post).
+ * x (R,32) rows ldx floats apart; post / out packed (R,32); W1 (128,32) and W2 (32,128) as bf16x3 planes of dpm_split_bf16x3
+ * (plane p of element i at planes[p * plane_stride + i]), W2's COLUMNS permuted before the split: stored column 32 s + 8 g + e
+ * holds original column 16 (2 s + (e >> 2)) + 4 g + (e & 3), s < 4, g < 4, e < 8 (the order in which the kernel's accumulator
+ * registers hold the intermediate).  Same bf16x3 arithmetic as dpm_linear_layernorm_bf16x3 twice; the row statistics are summed
+ * in another association (results agree to rounding).  DPM_EUNSUPPORTED for other widths or unaligned operands. */
+int dpm_pwconv_pair_bf16x3(const float *x, int ldx, const void *w1_planes, long long plane_stride1, const float *b1,
+                           const float *gamma1, const float *beta1, const void *w2_planes_kperm, long long plane_stride2,
+                           const float *b2, const float *gamma2, const float *beta2, const float *post, float *out, int R,
+                           int C, int H, dpm_stream_t stream);
+
 /* F.normalize(x, p=2, dim=-1) (decoder.py:185): x / max(||x||, 1e-12), rows (R,C). */
 int dpm_l2_normalize(const float *x, int R, int C, float *out, dpm_stream_t stream);
 

@@ -636,3 +636,33 @@ def test_c_abi_from_a_program_without_torch():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert "c abi gpu ok" in out.stdout
+
+
+def test_pwconv_pair_kernel_vs_two_fused_layers_and_fp64(ops):
+    """InvResMLP's pw_conv pair of the first level as one kernel (dpm_pwconv_pair_bf16x3: the 128-wide intermediate stays in
+    registers) against the two Linear + LayerNorm calls it replaces and against an fp64 evaluation; ragged row counts, with
+    and without the residual, values over many binades."""
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    C, H = 32, 128
+    W1 = torch.randn(H, C, 1, device=DEV, generator=gen) / C ** 0.5
+    W2 = torch.randn(C, H, 1, device=DEV, generator=gen) / H ** 0.5
+    b1, g1, be1 = (torch.randn(H, device=DEV, generator=gen) for _ in range(3))
+    b2, g2, be2 = (torch.randn(C, device=DEV, generator=gen) for _ in range(3))
+    for R, with_post in [(262144, True), (1000, True), (17, False), (16 * 4 * 4 * 3 + 5, True)]:
+        x = torch.randn(R, C, device=DEV, generator=gen) * torch.exp2(torch.randint(-6, 6, (R, 1), device=DEV, generator=gen).float())
+        post = torch.randn(R, C, device=DEV, generator=gen) if with_post else None
+        got = ops.pwconv_pair(x, W1, b1, g1, be1, W2, b2, g2, be2, post)
+        assert got is not None and got.shape == x.shape
+        u = ops.linear_layernorm(x, W1, b1, g1, be1, act=ops.ACT_RELU)
+        two = ops.linear_layernorm(u, W2, b2, g2, be2, act=ops.ACT_RELU, post=post)
+        n = min(R, 4096)
+        xd = x[:n].double()
+        h = torch.relu(torch.nn.functional.layer_norm(xd @ W1[:, :, 0].double().t() + b1.double(), (H,), g1.double(), be1.double(), 1e-5))
+        y = torch.nn.functional.layer_norm(h @ W2[:, :, 0].double().t() + b2.double(), (C,), g2.double(), be2.double(), 1e-5)
+        want = torch.relu(y + (post[:n].double() if with_post else 0.0))
+        e_one, e_two = (got[:n].double() - want).abs().max(), (two[:n].double() - want).abs().max()
+        assert float(e_one) < 2e-5 and float(e_one) < 2.0 * float(e_two) + 2e-6, (R, float(e_one), float(e_two))
+        torch.testing.assert_close(got, two, rtol=2e-5, atol=2e-5)
+    # a row's result does not depend on the rows it travels with
+    a = ops.pwconv_pair(x[:37].contiguous(), W1, b1, g1, be1, W2, b2, g2, be2, post[:37].contiguous())
+    assert torch.equal(a, got[:37])
