@@ -21,6 +21,7 @@ BF16X3_MAX_K = 512     # layers up to this reduction length take the bf16x3 kern
 # rows).  Pipelined step 4.27 -> 4.19 ms against the fp32 fused kernel's 4.33 (csrc/gemm_b3.hip, dpm_linear_layernorm_bf16x3,
 # has the history of its tile shapes).
 GEMM_LN_BF16X3 = True
+BF16X3_LN_MIN_K = 128  # shortest reduction a Linear + LayerNorm layer needs to take the bf16x3 kernels (below: the fp32 fused kernel)
 # bf16x3 Linear + LayerNorm layers of at most this many rows take the fused kernel as well (identical rows).  Measured for the one-pair
 # registration (512 rows): 9 launches fewer, eager call 1.00 -> 0.86 ms, but the replayed graph 0.48 -> 0.61 ms (8 workgroups walking
 # K instead of 96): off.
@@ -30,7 +31,7 @@ FUSED_MATCH = True     # similarity -> dual softmax -> top-k as one operator (cs
 DEDUP_FRAMES = True    # False: per-frame decoder work once per pair side instead of once per frame (new Decoder objects)
 
 _ENV = {"DPM_FPS_ALGO": ("FPS_ALGO", int), "DPM_NO_FUSED_LN": ("FUSED_LN", lambda v: v != "1"),
-        "DPM_DEDUP_FRAMES": ("DEDUP_FRAMES", lambda v: v != "0"), "DPM_GEMM_BF16X3": ("GEMM_BF16X3", lambda v: v == "1"), "DPM_BF16X3_MAX_K": ("BF16X3_MAX_K", int), "DPM_FUSED_LN_SMALL_ROWS": ("FUSED_LN_SMALL_ROWS", int), "DPM_GEMM_LN_BF16X3": ("GEMM_LN_BF16X3", lambda v: v == "1"),
+        "DPM_DEDUP_FRAMES": ("DEDUP_FRAMES", lambda v: v != "0"), "DPM_GEMM_BF16X3": ("GEMM_BF16X3", lambda v: v == "1"), "DPM_BF16X3_MAX_K": ("BF16X3_MAX_K", int), "DPM_BF16X3_LN_MIN_K": ("BF16X3_LN_MIN_K", int), "DPM_FUSED_LN_SMALL_ROWS": ("FUSED_LN_SMALL_ROWS", int), "DPM_GEMM_LN_BF16X3": ("GEMM_LN_BF16X3", lambda v: v == "1"),
         "DPM_FUSED_MATCH": ("FUSED_MATCH", lambda v: v != "0"), "DPM_FUSED_PWCONV": ("FUSED_PWCONV", lambda v: v != "0")}
 
 

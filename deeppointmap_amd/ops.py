@@ -376,7 +376,6 @@ def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radi
     return out
 
 
-BF16X3_LN_MIN_K = 128
 
 
 def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
@@ -516,7 +515,7 @@ def linear_layernorm(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tens
     # Layers the bf16x3 kernel covers (a property of the layer: K <= 512 in whole K-tiles, whole weight rows) take it in BOTH forms
     # -- fused from FUSED_LN_MIN_ROWS rows on, GEMM + LayerNorm below -- with identical rows either way
     # (from K = 128 on: with shorter reductions the kernels are bound by their epilogues and the fp32 form's smaller row tiles win)
-    if (knobs.GEMM_BF16X3 and knobs.GEMM_LN_BF16X3 and Cin % 32 == 0 and BF16X3_LN_MIN_K <= Cin <= knobs.BF16X3_MAX_K and Cout % 4 == 0 and W.numel() == Cout * Cin
+    if (knobs.GEMM_BF16X3 and knobs.GEMM_LN_BF16X3 and Cin % 32 == 0 and knobs.BF16X3_LN_MIN_K <= Cin <= knobs.BF16X3_MAX_K and Cout % 4 == 0 and W.numel() == Cout * Cin
             and x.dtype == torch.float32):
         wp = _weight_planes(W)
         if wp is not None and (bias is None or bias.data_ptr() % 16 == 0):
