@@ -13,17 +13,21 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "libdpm_hip.so")
 ARCH = "gfx950"
-# -packed-fp32-ops off: no v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 anywhere.  Round 4: with the packed forms compiled in
-# (hipcc 7.2 packs adjacent fp32 multiply-adds on its own; the encoder's first-level gather kernel held 52 of them) that kernel
-# returned a few wrong maxima in a few rows in up to 40 % of its launches WHILE ANOTHER WAVE ON THE CHIP EXECUTED bf16 MATRIX
-# INSTRUCTIONS -- the bf16x3 GEMM on another stream, in another process on the same GPU, even a register-only MFMA
-# micro-benchmark in another process -- and never otherwise (fp32 MFMA neighbours: 0 of 2 400 passes).  Same source without
-# the packed forms: 0 of 1 800 passes, 0 of 15 runs of the three-process test that had failed one time in five
-# (scripts/debug/enc_stress.py, enc_stress_streams.py, sa0_forensics.py).  NOT understood further: a register-only
-# v_pk_fma_f32 loop next to MFMA waves computes correctly (scripts/micro/pk_vs_mfma.hip), longer wait states in front of the
-# kernel's hand-written DPP steps change nothing -- it is the compiled sequence around the packed forms, not the instruction
-# alone.  They buy 1.15-1.2x on the multiply-adds they cover (scripts/micro/pk_fma_rate.hip) and nothing in the pipelined bench
-# (4.74 ms per step without them, 4.79 with, fp32 GEMMs both times).
+# -packed-fp32-ops off: no v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 anywhere (csrc/isa_lint.py checks the linked library).
+# hipcc 7.2 packs adjacent fp32 multiply-adds on its own, and on MI355X a v_pk_fma_f32 whose op_sel routes the HIGH dword of a
+# 64-bit source to the LOW lane (`op_sel:[0,1,0]`: the compiler's broadcast of the second of two adjacent registers) returns wrong
+# results while other waves of the SAME compute unit execute bf16 matrix instructions.  Round 4 met it as a few wrong maxima of the
+# encoder's first-level gather in up to 40 % of its launches next to the bf16x3 GEMM; round 5 bisected it (profiles/r05_pk_opsel.md):
+#   * compiler-generated code only -- a build of that kernel without any inline asm fails the same way; wait states around the
+#     packed instructions (s_nop 3 / 15 before or after each) and full s_waitcnt everywhere change nothing;
+#   * of the kernel's 26 packed instructions the four `op_sel:[0,1,0]` ones are the cause: replaced by scalar pairs 0 of 1000
+#     launches differ, with them (everything else scalar or not) ~900 of 1000 (both streams confined to the same compute units;
+#     on disjoint compute units 0 of 3000; fp32 MFMA neighbours: 0);
+#   * scripts/micro/pk_opsel_vs_mfma.hip shows the event in isolation (v_pk_mul_f32 op_sel:[0,1]: sixteen lanes of a wave read the
+#     routed operand as 0), scripts/debug/pk_isa_variants.py + pk_isa_run.py are the ISA bisection, tests/test_gpu_corun_stress.py
+#     is the regression guard (the shipped library must be bit-stable next to the bf16x3 GEMM; a packed build fails it).
+# The packed forms bought 1.15-1.2x on the multiply-adds they cover (scripts/micro/pk_fma_rate.hip) and nothing in the pipelined
+# bench (4.74 ms per step without them, 4.79 with, fp32 GEMMs both times).
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 SOURCES = {
@@ -50,9 +54,10 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, flags=(), out=None):
+def build(force=False, verbose=False, flags=(), out=None, only=None):
     """flags / out: an experimental build with extra compiler flags into a library of its own (objects under build/<name>/;
-    `DPM_LIB=<out>` selects it at run time: A/B measurements of one tree in one GPU session)."""
+    `DPM_LIB=<out>` selects it at run time: A/B measurements of one tree in one GPU session).  only: the sources the extra
+    flags apply to (the rest of that library is compiled like the shipped one)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build") if out is None else os.path.join(HERE, "build", os.path.basename(out) + ".d")
     OUT = globals()["OUT"] if out is None else out
@@ -64,7 +69,7 @@ def build(force=False, verbose=False, flags=(), out=None):
         s = os.path.join(HERE, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *COMMON, *extra, *flags, "-c", s, "-o", o])
+            jobs.append([hipcc, *COMMON, *extra, *(flags if only is None or src in only else ()), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -76,6 +81,12 @@ def build(force=False, verbose=False, flags=(), out=None):
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(OUT, objs):
         run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT, *objs])
+        sys.path.insert(0, HERE)
+        import isa_lint
+        if out is None:
+            isa_lint.check(OUT)    # the shipped library: no packed fp32 instructions (see COMMON)
+        elif verbose:
+            print("packed fp32 instructions:", isa_lint.packed_fp32(OUT))
     return OUT
 
 
@@ -99,9 +110,13 @@ def build_abi_smoke(verbose=False):
 
 
 if __name__ == "__main__":
-    if "--out" in sys.argv:   # python build.py --out <lib.so> [extra compiler flags ...]
+    if "--out" in sys.argv:   # python build.py --out <lib.so> [--only a.hip,b.hip] [extra compiler flags ...]
         i = sys.argv.index("--out")
-        print(build(verbose=True, flags=tuple(a for a in sys.argv[i + 2:]), out=os.path.abspath(sys.argv[i + 1])))
+        rest, only = sys.argv[i + 2:], None
+        if rest[:1] == ["--only"]:
+            only, rest = set(rest[1].split(",")), rest[2:]
+            assert only <= set(SOURCES), only
+        print(build(verbose=True, flags=tuple(rest), out=os.path.abspath(sys.argv[i + 1]), only=only))
         sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_abi_smoke(verbose=True))

@@ -119,6 +119,24 @@ __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp
     "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                    \
     "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                  \
     "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
+#ifdef DPM_DPP_BUILTIN   // experimental builds (csrc/build.py --out): the same steps through update_dpp, hazards padded by the compiler
+template <typename F>
+__device__ __forceinline__ int wave_reduce_builtin(int v, F op) {
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    return __int_as_float(wave_reduce_builtin(__float_as_int(v), [](int a, int b) { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); }));
+}
+__device__ __forceinline__ int wave_min_dpp(int v) {
+    return wave_reduce_builtin(v, [](int a, int b) { return min(a, b); });
+}
+#else
 __device__ __forceinline__ float wave_max_dpp(float v) {
     asm(DPM_WAVE_REDUCE("v_max_f32_dpp") : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
@@ -127,4 +145,5 @@ __device__ __forceinline__ int wave_min_dpp(int v) {
     asm(DPM_WAVE_REDUCE("v_min_i32_dpp") : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
+#endif
 #undef DPM_WAVE_REDUCE

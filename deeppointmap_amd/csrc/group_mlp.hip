@@ -428,6 +428,18 @@ namespace {
 // wave pass, LayerNorm sums are DPP / shuffle reductions inside the lane group.
 // The in-row steps are written as v_add_f32 with a DPP operand (one instruction + the two wait states a DPP read
 // needs after the write of its register); from update_dpp the compiler builds copy + s_nop + mov_dpp + add.
+#ifdef DPM_DPP_BUILTIN   // experimental builds: update_dpp + add (the compiler pads the hazards of what it builds from them)
+template <int G>
+__device__ __forceinline__ float lane_group_sum(float v) {
+    if (G >= 2) v += __int_as_float(dpp_i<0xB1, 0xF>(__float_as_int(v)));
+    if (G >= 4) v += __int_as_float(dpp_i<0x4E, 0xF>(__float_as_int(v)));
+    if (G >= 8) v += __int_as_float(dpp_i<0x141, 0xF>(__float_as_int(v)));
+    if (G >= 16) v += __int_as_float(dpp_i<0x140, 0xF>(__float_as_int(v)));
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+#else
 #define DPM_ADD_DPP(ctrl) "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
 template <int G>
 __device__ __forceinline__ float lane_group_sum(float v) {
@@ -442,8 +454,12 @@ __device__ __forceinline__ float lane_group_sum(float v) {
     return v;
 }
 #undef DPM_ADD_DPP
+#endif
 // max without the NaN canonicalisation fmaxf drags in (the operands are LayerNorm outputs of finite inputs)
 __device__ __forceinline__ float vmax_raw(float a, float b) {
+#ifdef DPM_VMAX_BUILTIN
+    return fmaxf(a, b);
+#endif
     float r;
     asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;

@@ -1,0 +1,63 @@
+"""ISA lint of the built library: no packed fp32 vector instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32
+are what hipcc forms from adjacent fp32 operations unless told not to).
+
+Why (profiles/r05_pk_opsel.md): on MI355X a v_pk_fma_f32 whose op_sel routes the HIGH dword of a 64-bit
+source to the LOW lane (`op_sel:[0,1,0]`: how the compiler broadcasts the second of two adjacent registers) returns wrong results
+while other waves of the same compute unit execute bf16 matrix instructions -- compiler-generated code, no inline asm involved, no
+wait state helps; found by ISA bisection of the encoder's first-level gather kernel.  The library is therefore compiled with
+`-target-feature -packed-fp32-ops` (csrc/build.py) and this check keeps it that way: csrc/build.py runs it after linking, and
+tests/test_isa_lint.py on the CPU.
+"""
+from __future__ import annotations
+
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+PACKED = re.compile(r"\b(v_pk_(?:fma|mul|add)_f32)\b(.*)")
+
+
+def device_disassembly(lib_path: str):
+    """yields the disassembly lines of every gfx950 code object bundled in the shared library"""
+    tmp = tempfile.mkdtemp(prefix="dpm_isa_")
+    try:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(lib_path, local)
+        subprocess.run([OBJDUMP, "--offloading", local], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        objs = sorted(f for f in os.listdir(tmp) if "hipv4-amdgcn" in f)
+        if not objs:
+            raise RuntimeError(f"{lib_path}: no gfx950 code object found")
+        for f in objs:
+            out = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            yield from out.splitlines()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def packed_fp32(lib_path: str) -> dict:
+    """-> {'v_pk_fma_f32': n, ..., 'op_sel high-to-low': n}: packed fp32 arithmetic in the library's device code"""
+    counts = {}
+    for line in device_disassembly(lib_path):
+        m = PACKED.search(line)
+        if not m:
+            continue
+        counts[m.group(1)] = counts.get(m.group(1), 0) + 1
+        sel = re.search(r"op_sel:\[([\d,]+)\]", m.group(2))
+        if sel and "1" in sel.group(1):
+            counts["op_sel high-to-low"] = counts.get("op_sel high-to-low", 0) + 1
+    return counts
+
+
+def check(lib_path: str) -> None:
+    found = packed_fp32(lib_path)
+    if found:
+        raise RuntimeError(f"{lib_path} contains packed fp32 instructions {found}: they return wrong results next to bf16 matrix "
+                           "instructions on MI355X (csrc/isa_lint.py); compile with -Xclang -target-feature -Xclang -packed-fp32-ops")
+
+
+if __name__ == "__main__":
+    import sys
+    print(packed_fp32(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libdpm_hip.so")))

@@ -1,0 +1,180 @@
+"""Co-residency stress of the kernels with hand-written DPP steps (tests/test_gpu_corun_stress.py runs it; so does
+`python tests/corun_stress.py [iters] [noise]` with DPM_LIB pointing at an experimental build of the library).
+
+Round 4 met silent corruption here: the encoder's first-level gather (csrc/group_mlp.hip, group_gather_ln_max_kernel
+<32,1,true>) returned a few wrong maxima in up to 40 % of its launches WHILE ANOTHER WAVE ON THE CHIP EXECUTED bf16 MATRIX
+INSTRUCTIONS, when the library was compiled with packed fp32 instructions.  Every parity claim of the repository rests on the
+kernels being deterministic, so the situation is part of the suite: each victim runs `iters` times on one stream while a second
+stream of the same process keeps the bf16x3 GEMM (csrc/gemm_b3.hip: v_mfma_f32_16x16x32_bf16) on the chip, and every result must
+equal the victim's result on an idle chip bit for bit.
+
+Semantics of the victims: SetAbstraction / LocalAggregation body, reference network/encoder/pointnext.py:52-61; farthest point
+sampling, network/encoder/utils.py:232-262; hybrid query, utils.py:76-89.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def _victims(dev):
+    """name -> zero-argument callable returning the tensor to compare.  Inputs are made once; every call allocates only
+    its output."""
+    from deeppointmap_amd import _lib, ops, synthetic
+    from deeppointmap_amd.config import default_args
+    from deeppointmap_amd.encoder import Encoder
+    from deeppointmap_amd.weights import init_procedural
+
+    enc = init_procedural(Encoder(default_args())).to(dev)
+    lib = _lib.load()
+    B, N, S = 4, 16384, 2048
+    pts, pad = synthetic.frames(B, N, start=40)
+    xyz, lengths = ops.prepare_points(pts.to(dev).contiguous(), pad.to(dev).contiguous())
+    _, cen, clen = ops.fps(xyz, lengths, S)
+    idx0 = ops.knn_hybrid(xyz, lengths, cen, 32, 0.05)
+    m = "downsampler.0.sa.mlp"
+    sa = [enc.p("point_mlp0.weight"), enc.p("point_mlp0.bias"), cen, idx0, enc.p(m + ".0.weight"), enc.p(m + ".0.bias"),
+          enc.p(m + ".1.ln.weight"), enc.p(m + ".1.ln.bias")]
+
+    def plain_gather(C, K, radius, seed):
+        """group_gather_ln_max_kernel<C, V, false> alone: P (the projected point features) is an input"""
+        g = torch.Generator().manual_seed(seed)
+        P = torch.randn(B, S, C, generator=g).to(dev)
+        Wr = (torch.randn(C, 3, generator=g) / 3).to(dev)
+        gm, bt = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+        idx = ops.knn_hybrid(cen, clen, cen, K, radius)
+
+        def call():
+            out = torch.empty(B, S, C, device=dev)
+            _lib.check(lib.dpm_group_gather_ln_max(P.data_ptr(), cen.data_ptr(), cen.data_ptr(), idx.data_ptr(), Wr.data_ptr(), 3,
+                                                   gm.data_ptr(), bt.data_ptr(), B, S, S, K, C, float(radius), out.data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream), "dpm_group_gather_ln_max")
+            return out
+        return call
+
+    small_xyz, small_len = xyz[:1, :8192].contiguous(), torch.full((1,), 8192, device=dev, dtype=torch.int32)
+    return {
+        "gather affine <32> (stage-0 SetAbstraction)": lambda: ops.group_mlp_max_from_xyz(xyz, *sa, 0.05),
+        "gather <32> (LocalAggregation)": plain_gather(32, 32, 0.1, 1),
+        "gather <64>": plain_gather(64, 32, 0.1, 2),
+        "gather <128>": plain_gather(128, 32, 0.2, 3),
+        "gather <256>, 16 neighbours": plain_gather(256, 16, 0.2, 4),
+        "gather <512>": plain_gather(512, 16, 0.4, 5),
+        # slot order inside a row is not part of the operator's contract (the grid search appends in arrival order): rows compared as sets
+        "neighbour search (DPP min / max selection)": lambda: torch.sort(ops.knn_hybrid(xyz, lengths, cen, 32, 0.05), dim=-1).values,
+        "farthest point sampling (DPP bounds)": lambda: ops.fps(small_xyz, small_len, 256)[0],
+    }
+
+
+def _noise(dev, kind):
+    """zero-argument callable enqueueing one noise kernel on the current stream"""
+    from deeppointmap_amd import ops
+    x = torch.randn(8192, 256, device=dev)
+    W = torch.randn(768, 256, device=dev) / 16
+    b = torch.randn(768, device=dev)
+    out = torch.empty(8192, 768, device=dev)
+    if kind == "bf16x3":
+        if ops.linear_bf16x3(x, W, b, out=out) is None:
+            raise RuntimeError("the bf16x3 GEMM refused the noise shape")
+        return lambda: ops.linear_bf16x3(x, W, b, out=out)
+    if kind == "fp32":
+        return lambda: ops.linear(x, W, b, out=out, exact=True)
+    if kind == "none":
+        return None
+    raise ValueError(kind)
+
+
+def hip_runtime_path():
+    """the HIP runtime this process already runs on (torch's), not a second copy found by name"""
+    torch.cuda.init()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                return line.split()[-1]
+    return "libamdhip64.so"
+
+
+def _masked_stream(dev, words):
+    """a HIP stream restricted to the compute units whose bits are set in `words` (hipExtStreamCreateWithCUMask), as a torch
+    stream.  Used to tell a chip-wide effect of the neighbour (clock, power) from one inside a compute unit."""
+    import ctypes
+    hip = ctypes.CDLL(hip_runtime_path())
+    st = ctypes.c_void_p()
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    err = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(words), arr)
+    if err:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask: {err}")
+    return torch.cuda.ExternalStream(st.value, device=dev)
+
+
+def run(iters: int = 300, noise: str = "bf16x3", only=None, cu_split: str = "") -> dict:
+    """-> {victim name: number of calls (of iters) whose result differed from the idle-chip result}, plus '_noise_launches'.
+    cu_split: '' = both streams anywhere; 'halves' = victims on the compute units of mask bits 0-127, noise on bits 128-255
+    (disjoint compute units); 'same' = both confined to bits 0-127."""
+    torch.set_grad_enabled(False)
+    dev = torch.device("cuda:0")
+    lo, hi = [0xFFFFFFFF] * 4 + [0] * 4, [0] * 4 + [0xFFFFFFFF] * 4
+    vstream = _masked_stream(dev, lo) if cu_split else torch.cuda.current_stream(dev)
+    nstream = _masked_stream(dev, hi if cu_split == "halves" else lo) if cu_split else torch.cuda.Stream(device=dev)
+    victims = _victims(dev)
+    if only:
+        victims = {k: v for k, v in victims.items() if any(o in k for o in only)}
+    ref = {k: fn().clone() for k, fn in victims.items()}
+    for k, fn in victims.items():   # a victim that is not deterministic on an idle chip would make the test meaningless
+        for _ in range(5):
+            if not torch.equal(fn(), ref[k]):
+                raise AssertionError(f"{k}: differs from its own previous result on an idle chip")
+    torch.cuda.synchronize()
+    nfn = _noise(dev, noise)
+    stop, launches = threading.Event(), [0]
+
+    def noise_loop():
+        s = nstream
+        with torch.cuda.stream(s):
+            while not stop.is_set():
+                for _ in range(30):
+                    nfn()
+                launches[0] += 30
+                s.synchronize()
+
+    th = None
+    if nfn is not None:
+        th = threading.Thread(target=noise_loop)
+        th.start()
+        time.sleep(0.05)
+    bad = {}
+    try:
+        with torch.cuda.stream(vstream):
+            for k, fn in victims.items():
+                n = 0
+                for _ in range(iters):
+                    if not torch.equal(fn(), ref[k]):
+                        n += 1
+                bad[k] = n
+    finally:
+        stop.set()
+        if th is not None:
+            th.join()
+    torch.cuda.synchronize()
+    bad["_noise_launches"] = launches[0]
+    return bad
+
+
+if __name__ == "__main__":
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    noise = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
+    only = sys.argv[3:] or None
+    t0 = time.time()
+    res = run(iters, noise, only, os.environ.get("STRESS_CU_SPLIT", ""))
+    from deeppointmap_amd import _lib
+    print(json.dumps({"lib": os.path.basename(_lib.LIB_PATH), "iters": iters, "noise": noise, "seconds": round(time.time() - t0, 1), "cu_split": os.environ.get("STRESS_CU_SPLIT", ""),
+                      "differing_calls": res}))

@@ -1,0 +1,25 @@
+"""The built library holds no packed fp32 vector instructions (csrc/isa_lint.py says why: v_pk_fma_f32 with a high-to-low op_sel
+returns wrong results next to bf16 matrix instructions on MI355X).  Runs on the CPU: it only disassembles the library."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deeppointmap_amd", "csrc"))
+LIB = os.path.join(ROOT, "deeppointmap_amd", "libdpm_hip.so")
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="library not built")
+def test_library_has_no_packed_fp32_instructions():
+    import isa_lint
+    if not os.path.exists(isa_lint.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    assert isa_lint.packed_fp32(LIB) == {}
+
+
+def test_lint_recognises_the_failing_form():
+    import isa_lint
+    line = "\tv_pk_fma_f32 v[84:85], v[60:61], v[46:47], v[84:85] op_sel:[0,1,0]"
+    m = isa_lint.PACKED.search(line)
+    assert m and m.group(1) == "v_pk_fma_f32"
