@@ -55,6 +55,49 @@ def pmc_traffic_bytes(frames_per_launch: int):
         return None
 
 
+def parity_gate(desc: torch.Tensor, table: torch.Tensor, n_points: int) -> dict:
+    """What the timed steps computed, held against the reference's own results for this workload (a parity
+    gate with every number).  `desc` (>= 6, 131, 256) / `table` (>= 6, 56) are the rows the LAST timed step gathered on rank 0;
+    row f of the table is the edge (f - 1, f).  Checked against fixtures made by importing the reference
+    (tests/golden/make_golden.py; reference network/decoder/decoder.py:91-127, network/encoder/encoder.py:57-67,
+    network/encoder/utils.py:232-262):
+      * edges 0->1 ... 4->5 vs poses_full.npz: translation < 1e-4 m, rotation < 1e-4 rad, inlier count equal, |rmse| < 1e-3;
+      * frame 0's 256 key points bit-equal to the first 256 picks of the reference's farthest point sampling (fps.npz) and to the
+        reference encoder's coordinates (encoder_full.npz); descriptors of frames 0, 1 within 3e-4 of the reference's;
+      * every information matrix of the step finite and symmetric.
+    The fixtures exist for the 65 536-point synthetic sequence only; another workload reports `checked: false`."""
+    import numpy as np
+    gold = os.path.join(ROOT, "tests", "golden")
+    if n_points != 65536 or desc is None or desc.shape[0] < 6 or table.shape[0] < 6:
+        return {"checked": False, "why": "fixtures cover the 65 536-point synthetic sequence, frames 0-5"}
+    poses, fps, enc = (np.load(os.path.join(gold, f)) for f in ("poses_full.npz", "fps.npz", "encoder_full.npz"))
+    d, t = desc[:6].detach().float().cpu(), table.detach().double().cpu()
+    max_dt = max_dr = max_drmse = 0.0
+    n_conf_equal = True
+    for f in range(1, 6):
+        k = f"pair{f - 1}_{f}"
+        R, T = t[f, 0:9].view(3, 3), t[f, 9:12].view(3, 1)
+        max_dt = max(max_dt, float((T - torch.from_numpy(poses[k + ".T"]).double()).norm()))
+        M = R.T @ torch.from_numpy(poses[k + ".R"]).double()
+        max_dr = max(max_dr, float(np.arctan2(float(torch.linalg.norm(M - M.T)) / (2 * 2 ** 0.5), float((torch.trace(M) - 1) / 2))))
+        max_drmse = max(max_drmse, abs(float(t[f, 12]) - float(poses[k + ".rmse"])))
+        n_conf_equal &= int(t[f, 14]) == int(poses[k + ".n_conf"])
+    key_xyz = d[0, 128:131, :]                                                         # metres: coordinates x 60 (fp32)
+    fps_prefix_equal = bool(torch.equal(key_xyz, (torch.from_numpy(fps["synthetic0_k4096.new"][:256]) * 60.0).t().contiguous()))
+    coor_equal = bool(torch.equal(key_xyz, torch.from_numpy(enc["synthetic0.coor"]) * 60.0))
+    desc_err = max(float((d[f, :128] - torch.from_numpy(enc[f"synthetic{f}.fea"])).abs().max()) for f in (0, 1))
+    info = t[:, 20:56].view(-1, 6, 6)
+    info_ok = bool(torch.isfinite(info).all()) and bool(((info - info.transpose(1, 2)).abs() <= 1e-5 * info.abs().amax(dim=(1, 2), keepdim=True) + 1e-12).all())
+    ok = (max_dt < 1e-4 and max_dr < 1e-4 and max_drmse < 1e-3 and n_conf_equal and fps_prefix_equal and coor_equal
+          and desc_err < 3e-4 and info_ok)
+    return {"checked": True, "ok": bool(ok), "pairs": 5, "max_dT_m": float(f"{max_dt:.3g}"), "max_dR_rad": float(f"{max_dr:.3g}"),
+            "max_drmse": float(f"{max_drmse:.3g}"), "n_conf_equal": bool(n_conf_equal), "fps_prefix_equal": fps_prefix_equal,
+            "keypoints_equal_reference": coor_equal, "descriptor_max_err": float(f"{desc_err:.3g}"),
+            "information_matrices": int(info.shape[0]), "information_finite_symmetric": info_ok,
+            "against": "tests/golden/{poses_full,fps,encoder_full}.npz (made by importing the reference)",
+            "tolerance": "1e-4 m / 1e-4 rad (north_star); rmse 1e-3; descriptors 3e-4; key points and inlier counts exact"}
+
+
 def cpu_baseline(n_frames: int, n_points: int, threads: int):
     """The oracle (CPU restatement, oracle/dpm_oracle.py) on a bounded sample of the same workload."""
     from oracle import dpm_oracle as O
@@ -80,6 +123,58 @@ def cpu_baseline(n_frames: int, n_points: int, threads: int):
     return n_frames / (t2 - t0), (t1 - t0) / n_frames, (t2 - t1) / n_frames
 
 
+class Guard:
+    """Makes a run unable to hang or to die silently (the first N > 1 run on hardware happens under the driver, unobserved):
+      * every phase leaves a rank-tagged breadcrumb on stderr and has a deadline; a watchdog thread that finds the deadline passed
+        makes rank 0 print ONE JSON line carrying "error" (same metric / n_gpus keys as the result line) and ends the process;
+      * an exception anywhere does the same (`fail`); so does SIGTERM from the launcher (another rank died).
+    The process-group timeout (init_process_group(timeout=...)) is set to the same collective budget, so RCCL's own watchdog
+    raises in the rank that waits instead of blocking for its default ten minutes."""
+
+    def __init__(self, rank: int, world: int, args):
+        import signal
+        import threading
+        self.rank, self.world, self.args = rank, world, args
+        self.t0 = time.time()
+        self.phase_name, self.deadline = "start", time.time() + 300
+        self._done = False
+        self._lock = threading.Lock()
+        threading.Thread(target=self._watch, daemon=True).start()
+        try:
+            signal.signal(signal.SIGTERM, lambda *_: self.fail("SIGTERM from the launcher (another rank failed or the run was cancelled)", 143))
+        except ValueError:   # not the main thread
+            pass
+
+    def phase(self, name: str, budget_s: float) -> None:
+        self.phase_name, self.deadline = name, time.time() + budget_s
+        print(f"[bench rank {self.rank}/{self.world} +{time.time() - self.t0:6.1f}s] {name} (budget {budget_s:.0f} s)", file=sys.stderr, flush=True)
+
+    def _watch(self) -> None:
+        while not self._done:
+            time.sleep(0.5)
+            if not self._done and time.time() > self.deadline:
+                self.fail(f"phase '{self.phase_name}' exceeded its budget: a collective or a kernel did not complete", 124)
+
+    def fail(self, why: str, code: int = 1) -> None:
+        with self._lock:
+            if self._done:
+                return
+            self._done = True
+        msg = f"{why} [rank {self.rank}/{self.world}, phase '{self.phase_name}', +{time.time() - self.t0:.1f} s]"
+        # raw writes: this may run inside a signal handler that interrupted a print, or next to a thread that holds a stream's lock
+        os.write(2, f"[bench rank {self.rank}/{self.world}] ERROR: {msg}\n".encode())
+        if self.rank == 0:
+            os.write(1, (json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": self.world, "steps": self.args.steps,
+                                     "warmup": self.args.warmup, "higher_is_better": True, "error": msg, "phase": self.phase_name}) + "\n").encode())
+        os._exit(code)    # not sys.exit: a thread blocked inside a collective would keep the process alive
+
+    def finish(self) -> None:
+        self._done = True
+
+
+METRIC = "LiDAR frames/s (encode+match+register), 65 536 pts/frame"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,8 +198,31 @@ def main():
     ap.add_argument("--allow-knobs", action="store_true",
                     help="run although DPM_* variables are set / an experimental library is loaded (A/B measurements); they are "
                          "recorded under config.knobs and the line is not a headline number")
+    ap.add_argument("--collective-timeout", type=float, default=120.0,
+                    help="seconds a collective (and the process-group rendezvous) may take before the run ends with an error line")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="--gpus 1 only: create a one-rank process group and issue the step's gather anyway (executes the RCCL call "
+                         "path on a single-GPU box; recorded in config.parallelism)")
+    ap.add_argument("--inject-failure", default="none", choices=("none", "hang-in-gather", "raise-in-step"),
+                    help="test hook for the guard: the named failure happens in the first timed step")
     args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    guard = Guard(rank, world, args)
+    try:
+        run(args, guard, rank, world)
+    except SystemExit as e:
+        if e.code not in (0, None):
+            guard.fail(str(e.code) if not isinstance(e.code, int) else f"exit code {e.code}", e.code if isinstance(e.code, int) else 1)
+        raise
+    except BaseException as e:  # noqa: BLE001 -- whatever it is, rank 0 says so in the record
+        import traceback
+        traceback.print_exc()
+        guard.fail(f"{type(e).__name__}: {e}")
+    guard.finish()
 
+
+def run(args, guard, rank, world):
     # Tamper evidence: the headline number comes from the shipped library and the shipped host settings or not at all.
     # DPM_LIB swaps the library, the other DPM_* names are what an experimental build (-DDPM_EXPERIMENT) or
     # deeppointmap_amd.knobs.apply_env() would read -- some of them skip work.
@@ -116,8 +234,6 @@ def main():
     if args.allow_knobs:
         knobs.apply_env()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -131,13 +247,32 @@ def main():
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    import datetime
     import torch.distributed as dist
-    if world > 1:
+    forced = args.force_collectives and world == 1   # one rank, collectives issued anyway
+    pg_timeout = datetime.timedelta(seconds=args.collective_timeout)
+    ranks_seen = None
+    if world > 1 or forced:
+        guard.phase("process-group rendezvous", args.collective_timeout + 30)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        kw = dict(rank=0, world_size=1) if forced else {}
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=pg_timeout, **kw)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=pg_timeout, **kw)
+        # who is here: the record must show N ranks on N distinct devices (a launcher that folded two ranks onto one GPU, or
+        # a communicator that saw fewer ranks than --gpus, would otherwise produce a plausible line)
+        guard.phase("rank census (first collective)", args.collective_timeout + 30)
+        props = torch.cuda.get_device_properties(dev)
+        me = {"rank": rank, "local_rank": local, "device": torch.cuda.current_device(),
+              "pci": f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}", "uuid": str(getattr(props, "uuid", ""))}
+        ranks_seen = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks_seen, me)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        if backend == "nccl" and len({r["pci"] for r in ranks_seen}) != len(ranks_seen):
+            raise SystemExit(f"ranks share devices: {ranks_seen}")
 
     from deeppointmap_amd import _lib, ops, synthetic
     if _lib.experimental() and not args.allow_knobs:
@@ -210,7 +345,11 @@ def main():
 
     last_gathered = [None]
 
+    timed = [False]
+
     def step():
+        if inject[0] == "raise-in-step" and timed[0]:
+            raise RuntimeError("injected failure (--inject-failure raise-in-step)")
         # Streaming mode (HotPath.submit): this batch's input staging + first-level FPS start on a side HIP
         # stream and overlap with the previous batch's remaining stages on the main stream.  Edges stay on the
         # device in `table` (header | information per frame); no host sync inside a step.
@@ -222,7 +361,8 @@ def main():
         if done is not None:
             gather(done)
 
-    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm = torch.cuda.Stream(device=dev) if (world > 1 or forced) else None
+    inject = [args.inject_failure]
 
     def gather(done):
         # the step's one collective runs on a stream of its own: the caller's stream carries the next batch's feature stage,
@@ -230,11 +370,13 @@ def main():
         if comm is None:
             last_gathered[0] = gather_step_results(done[0].contiguous(), done[1])
             return
+        if inject[0] == "hang-in-gather" and timed[0]:
+            time.sleep(10 ** 6)          # a collective that never completes, as the guard sees it
         comm.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(comm):
             for t in done:
                 t.record_stream(comm)
-            last_gathered[0] = gather_step_results(done[0].contiguous(), done[1])
+            last_gathered[0] = gather_step_results(done[0].contiguous(), done[1], force=forced)
 
     def drain():  # the batches still in the pipe are finished INSIDE the timed region
         for done in hot.flush():
@@ -249,6 +391,7 @@ def main():
     # One-time initialisation that is not a benchmark step: a two-frame, 20 000-point pass makes the HIP runtime load
     # the kernels' code objects and fills the weight-derived caches (a first launch of each kernel costs milliseconds),
     # so that a run with --warmup 0 measures the path and not the loader.  Nothing of the timed workload is computed.
+    guard.phase("one-time initialisation (code objects, weight-derived caches)", 300)
     init_pts, init_pad = synthetic.frames(2, 20000, start=10_000)
     hot.step(init_pts.to(dev), init_pad.to(dev), (init_pts * synthetic.COOR_SCALE).contiguous().to(dev), materialize=False)
     torch.cuda.synchronize()
@@ -257,22 +400,32 @@ def main():
     fps_events.clear()
     gemm_events.clear()
 
+    guard.phase(f"warm-up ({args.warmup} steps)", args.collective_timeout + 60 + 1.0 * args.warmup)
     for _ in range(args.warmup):
         step()
     drain()
     fps_events.clear()
     gemm_events.clear()
     fence()
+    guard.phase(f"timed region ({args.steps} steps)", args.collective_timeout + 1.0 * args.steps)
+    timed[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     drain()
     fence()
     dt = time.perf_counter() - t0
+    timed[0] = False
+    guard.phase("after the timed region (parity gate, extra measurements)", 600)
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
+    # the rows the last timed step gathered, held against the reference's results before anything else touches the pipeline's buffers
+    gate = None
+    if rank == 0:
+        gd, gt = last_gathered[0] if last_gathered[0] is not None else (None, None)
+        gate = parity_gate(gd, gt, N) if gd is not None else {"checked": False, "why": "nothing gathered"}
     fps_ms = sum(a.elapsed_time(b) for a, b in fps_events) / max(len(fps_events), 1)
     gemm_ms = sum(a.elapsed_time(b) for a, b in gemm_events) / max(len(gemm_events), 1)
 
@@ -422,7 +575,7 @@ def main():
         alg = fps0_algorithmic_bytes(N, cfg.encoder.npoint[0]) * F  # one launch handles the rank's F frames
         achieved = alg / (fps_ms * 1e-3) / 1e9 if fps_ms > 0 else 0.0
         line = {
-            "metric": "LiDAR frames/s (encode+match+register), 65 536 pts/frame",
+            "metric": METRIC,
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
@@ -434,7 +587,8 @@ def main():
                                    "registration_forward (256x256) + information matrix per frame",
                        "frames_per_gpu_per_step": F, "points_per_frame": N,
                        "parallelism": f"frame-sharded x{world}, one RCCL gather of descriptors+edges per step" +
-                                      ("" if backend == "nccl" or world == 1 else f" (DRY RUN over {backend}, ranks folded onto the visible GPUs)"),
+                                      ("" if backend == "nccl" or world == 1 else f" (DRY RUN over {backend}, ranks folded onto the visible GPUs)") +
+                                      (" (ONE rank, collectives forced: --force-collectives)" if forced else ""),
                        "pipeline": "none" if args.no_pipeline else "HIP-stream pipeline: geometry (staging+FPS chain) of batches i, i-1 on two alternating streams | features of batch i-2 | registration+information matrices of batch i-3",
                        "weights": "procedural (deeppointmap_amd/weights.py)",
                        "allocator_reserve_gib": 0 if args.no_pipeline else hot.reserve_bytes >> 30},
@@ -454,6 +608,10 @@ def main():
                                  "reference's loop re-reads the WHOLE frame every round (4095 x 65536 x 16 B = 4.3 GB "
                                  "per frame, 275 GB per launch), the bucket pruning cuts that ~85x; see DESIGN.md"},
         }
+        if ranks_seen is not None:    # N ranks on N distinct devices, as the process group itself reported them
+            line["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "collective_timeout_s": args.collective_timeout,
+                             "members": ranks_seen}
+        line["parity_gate"] = gate   # what the timed steps computed against the reference's results for this workload
         if "fps_ms" in alone:   # the same kernel pair with the chip to itself (outside the timed region)
             line["roofline"]["alone"] = {"launch_ms": round(alone["fps_ms"], 4),
                                          "us_per_round": round(alone["fps_ms"] * 1e3 / (cfg.encoder.npoint[0] - 1), 3),
@@ -495,6 +653,7 @@ def main():
                 if mult > 1:
                     line["roofline_mfma"]["alone"]["fp32_equivalent_frac"] = round(ta / 157.3, 4)
         if world == 1 and args.cpu_frames > 0:
+            guard.phase("cpu_baseline (oracle on the host cores)", 1200)
             # torch's intra-op pool stops scaling (and then collapses) well below the box's core count on
             # these small ops: 16 threads measured fastest on the 256-core GPU host (8: 0.83, 16: 0.63,
             # 32: 0.75, 64: 1.09 s/frame encode); `cores` reports the threads actually used
@@ -505,8 +664,17 @@ def main():
                                     "sample": f"{min(args.cpu_frames, F)} frames x {N} pts: oracle encode {enc_s:.2f} s/frame "
                                               f"(C farthest-point sampling), register+information matrix {reg_s:.2f} s/frame"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+        gate_failed = line["parity_gate"].get("checked") and not line["parity_gate"]["ok"]
+    else:
+        gate_failed = False
+    if world > 1 or forced:
+        guard.phase("process-group teardown", args.collective_timeout)
         dist.destroy_process_group()
+    if gate_failed:   # the line above already carries parity_gate.ok = false: no second line, a non-zero exit
+        print("bench.py: PARITY GATE FAILED -- the timed steps did not reproduce the reference's results: " +
+              json.dumps(line["parity_gate"]), file=sys.stderr, flush=True)
+        guard.finish()
+        sys.exit(1)
 
 
 if __name__ == "__main__":

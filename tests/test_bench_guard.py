@@ -1,0 +1,78 @@
+"""bench.py's Guard: a phase that outlives its budget, an exception and a SIGTERM each end the process with ONE JSON line on rank 0
+that carries "error" -- the first multi-GPU run happens under the driver, unobserved, and must not hang or die silently.
+CPU only: the Guard is exercised without the workload (tests/test_gpu_rccl.py drives the real bench.py through it on a GPU)."""
+import json
+import os
+import signal
+import subprocess
+import sys
+import time
+
+from conftest import ROOT
+
+CHILD = r"""
+import argparse, os, sys, time
+sys.path.insert(0, os.environ["DPMTEST_ROOT"])
+import bench
+args = argparse.Namespace(steps=7, warmup=1)
+g = bench.Guard(int(os.environ["RANK"]), 2, args)
+mode = sys.argv[1]
+if mode == "hang":
+    g.phase("a collective that never completes", 0.7)
+    time.sleep(60)
+elif mode == "raise":
+    g.phase("a step that raises", 30)
+    try:
+        raise RuntimeError("boom")
+    except RuntimeError as e:
+        g.fail(f"{type(e).__name__}: {e}")
+elif mode == "term":
+    g.phase("waiting for the launcher's SIGTERM", 30)
+    print("READY", file=sys.stderr, flush=True)
+    time.sleep(60)
+elif mode == "ok":
+    g.phase("a phase that completes", 5)
+    g.finish()
+    time.sleep(1.5)
+    print("DONE")
+"""
+
+
+def _run(mode, rank=0, sigterm=False):
+    env = dict(os.environ, DPMTEST_ROOT=ROOT, RANK=str(rank))
+    p = subprocess.Popen([sys.executable, "-c", CHILD, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+    if sigterm:
+        assert "READY" in p.stderr.readline() + p.stderr.readline()
+        p.send_signal(signal.SIGTERM)
+    t0 = time.time()
+    out, err = p.communicate(timeout=120)
+    return p.returncode, out, err, time.time() - t0
+
+
+def test_overrun_phase_ends_the_run_with_an_error_line():
+    rc, out, err, secs = _run("hang")
+    line = json.loads(out.strip().splitlines()[-1])
+    assert rc == 124 and secs < 30
+    assert line["value"] is None and line["n_gpus"] == 2 and line["steps"] == 7 and "exceeded its budget" in line["error"]
+    assert line["phase"] == "a collective that never completes" and "[bench rank 0/2" in err
+
+
+def test_exception_ends_the_run_with_an_error_line():
+    rc, out, err, _ = _run("raise")
+    line = json.loads(out.strip().splitlines()[-1])
+    assert rc == 1 and "RuntimeError: boom" in line["error"] and line["metric"].startswith("LiDAR frames/s")
+
+
+def test_other_ranks_report_on_stderr_only():
+    rc, out, err, _ = _run("hang", rank=1)
+    assert rc == 124 and out.strip() == "" and "[bench rank 1/2] ERROR" in err
+
+
+def test_sigterm_from_the_launcher_leaves_a_record():
+    rc, out, err, _ = _run("term", sigterm=True)
+    assert rc == 143 and "SIGTERM" in json.loads(out.strip().splitlines()[-1])["error"]
+
+
+def test_finished_guard_stays_quiet():
+    rc, out, err, _ = _run("ok")
+    assert rc == 0 and out.strip() == "DONE"

@@ -90,3 +90,43 @@ def test_rccl_call_paths_execute_on_one_gpu():
     env.pop("RANK", None), env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
     assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+
+
+def _bench(*extra, timeout=600):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DPM_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + os.getpid() % 200), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--force-collectives", "--frames", "8",
+           "--points", "16384", "--steps", "3", "--warmup", "1", "--no-extras", "--cpu-frames", "0", *extra]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_over_a_one_rank_rccl_group_records_its_ranks():
+    """bench.py's N > 1 code path (process group with a timeout, rank census, the step's gather on the communication stream) on the
+    one GPU there is: the line must say which ranks on which devices the process group saw."""
+    import json
+    out = _bench()
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["ranks"]["world_size"] == 1 and line["ranks"]["backend"] == "nccl" and len(line["ranks"]["members"]) == 1
+    assert line["ranks"]["members"][0]["pci"] and "forced" in line["config"]["parallelism"]
+    assert line["value"] > 0 and line["parity_gate"]["checked"] is False     # fixtures cover the 65 536-point workload only
+    assert "timed region" in out.stderr and "[bench rank 0/1" in out.stderr  # breadcrumbs
+
+
+def test_bench_ends_with_an_error_line_when_a_collective_never_completes():
+    import json
+    import time
+    t0 = time.time()
+    out = _bench("--inject-failure", "hang-in-gather", "--collective-timeout", "5")
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert out.returncode == 124 and time.time() - t0 < 300
+    assert line["value"] is None and line["n_gpus"] == 1 and "exceeded its budget" in line["error"] and "timed region" in line["phase"]
+
+
+def test_bench_ends_with_an_error_line_when_a_step_raises():
+    import json
+    out = _bench("--inject-failure", "raise-in-step")
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert out.returncode != 0 and line["value"] is None and "injected failure" in line["error"]
