@@ -663,6 +663,10 @@ def run(args, guard, rank, world):
             line["cpu_baseline"] = {"value": round(v, 4), "unit": "frames/s", "cores": cores, "kind": "port",
                                     "sample": f"{min(args.cpu_frames, F)} frames x {N} pts: oracle encode {enc_s:.2f} s/frame "
                                               f"(C farthest-point sampling), register+information matrix {reg_s:.2f} s/frame"}
+        # RCCL writes its version banner through C stdio (fully buffered on a pipe: it would surface at exit, AFTER this line);
+        # flushed first, the JSON line is the last thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
         gate_failed = line["parity_gate"].get("checked") and not line["parity_gate"]["ok"]
     else:
