@@ -302,8 +302,16 @@ def _derived(tag: str, sources, make):
         if hit is not None:
             _RETIRED.append(hit[2])
         if len(_DERIVED) >= 512:
-            _RETIRED.extend(v[2] for v in _DERIVED.values())
-            _DERIVED.clear()
+            # entries of weights that no longer exist go first (models re-created, ad-hoc weights); nothing can still read them
+            # through a captured graph, whose owner holds its weights.  If live entries have to go as well, captured graphs
+            # that replay kernels reading them are stale: the generation they were stamped with ends here (decoder.py).
+            dead = [k for k, v in _DERIVED.items() if any(r() is None for r in v[0])]
+            for k in dead:
+                _RETIRED.append(_DERIVED.pop(k)[2])
+            if len(_DERIVED) >= 512:
+                _RETIRED.extend(v[2] for v in _DERIVED.values())
+                _DERIVED.clear()
+                _GENERATION[0] += 1
         value = make()
         _DERIVED[key] = (tuple(weakref.ref(t) for t in sources), stamp, value, cur.record_event())
         return value

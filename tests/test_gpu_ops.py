@@ -507,6 +507,27 @@ def test_weight_derived_tensors_follow_the_weights(ops):
         both(W)
 
 
+def test_derived_cache_overflow_evicts_dead_weights_first_and_ends_the_generation_otherwise(ops):
+    """A long-lived process that re-creates models reaches the cache's 512 entries: entries of freed weights go silently;
+    when LIVE entries have to go, the generation captured decoder graphs are stamped with must change (they replay kernels that
+    read those tensors)."""
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(64, 32, generator=gen).to(DEV)
+    g0 = ops.derived_generation()
+    for _ in range(600):                       # ad-hoc weights, each freed at once: only dead entries pile up
+        W = (torch.randn(32, 32, generator=gen) / 6).to(DEV)
+        ops.linear_bf16x3(x, W)
+        del W
+    assert ops.derived_generation() == g0 and len(ops._DERIVED) < 512
+    keep = [(torch.randn(32, 32, generator=gen) / 6).to(DEV) for _ in range(520)]   # live weights beyond the bound
+    want = ops.linear_bf16x3(x, keep[0]).clone()
+    for W in keep:
+        ops.linear_bf16x3(x, W)
+    assert ops.derived_generation() > g0
+    assert torch.equal(ops.linear_bf16x3(x, keep[0]), want)      # re-derived after the clear, same result
+    torch.cuda.synchronize()
+
+
 def test_prepare_and_channel_first(ops):
     gen = torch.Generator().manual_seed(5)
     pts = torch.randn(3, 4, 1000, generator=gen)
