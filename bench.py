@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 B_ALG_FRAME = 66_497_536  # algorithmic bytes per frame of the whole encoder
 HBM_PEAK = 8.0e12         # B/s, MI355X spec (MI355X_MICROARCH.md)
+RESERVE_BYTES = 16 << 30  # HotPath.reserve_bytes of the bench (measured working set of the four batches in flight: ~6.3 GB)
 
 
 def fps0_algorithmic_bytes(n_points: int, k: int) -> int:
@@ -298,6 +299,7 @@ def run(args, guard, rank, world):
         hot.feature_streams = args.feature_streams
     if args.feature_split is not None:
         hot.feature_split = args.feature_split
+    hot.reserve_bytes = RESERVE_BYTES   # a dedicated streaming deployment: one allocator segment per pipeline stream up front (pipeline.py)
     hot.chain = world > 1  # block-boundary edges come from the neighbour rank's last frame (shard.exchange_halo)
     F, N = args.frames, args.points
     pts, pad = synthetic.frames(F, N, start=rank * F)  # every rank owns its own block of the sequence

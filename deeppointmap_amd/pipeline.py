@@ -73,9 +73,11 @@ class HotPath:
         # on four streams; a block freed on one stream while another still reads it cannot be reused yet, so the allocator
         # keeps meeting requests nothing cached fits and goes to hipMalloc -- 5-12 ms of host time each, 28 of them over the
         # first 150 steps until ~6.3 GB were reserved (scripts/debug/step_hiccup.py), and a 20-step measurement that catches a
-        # burst of them reads 5.3 instead of 4.35 ms per step.  Blocks of one big cached segment are split instead.  The chip
-        # has 288 GB; 0 switches it off.
-        self.reserve_bytes = 16 << 30
+        # burst of them reads 5.3 instead of 4.35 ms per step.  Blocks of one big cached segment are split instead.
+        # 0 (the default): nothing is reserved -- a caller that shares the GPU (the SLAM host's map storage, other processes)
+        # keeps its memory.  A dedicated streaming deployment opts in (bench.py: RESERVE_BYTES = 16 GiB of the chip's 288;
+        # INTEGRATION.md); the amount is capped at half of what is free.
+        self.reserve_bytes = 0
 
     @torch.no_grad()
     def extract(self, points: torch.Tensor, padding: torch.Tensor, presampled=None) -> torch.Tensor:

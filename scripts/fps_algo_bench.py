@@ -8,7 +8,7 @@ pts, _ = synthetic.frames(B, 65536)
 xyz = pts.transpose(1, 2).contiguous().cuda()
 lens = torch.full((B,), 65536, dtype=torch.int32, device="cuda")
 ref = None
-for algo in (2, 5):
+for algo in ([int(a) for a in sys.argv[2:]] or (2, 5)):
     for _ in range(2):
         out = ops.fps(xyz, lens, 4096, algo=algo)
     torch.cuda.synchronize()
