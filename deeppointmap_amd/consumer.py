@@ -36,6 +36,7 @@ This is the Amdahl term of the multi-GPU path: bench.py reports i
 from __future__ import annotations
 
 import time
+from collections import OrderedDict
 from math import sqrt
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -82,6 +83,69 @@ def default_slam_args() -> dict:
                 loop_detection_confidence_acpt_threshold=0.6, enable_global_optimization=True, global_optimization_gap=0)
 
 
+class ScanCloudStore:
+    """token -> full cloud (3,N) in metres, for the information matrices of the edges (utils.py:60-113).  The reference keeps every
+    ScanPack.full_pcd on the host for the whole run (pose_graph.py:43-69); here the clouds the odometry / mapping / loop steps
+    are about to pair stay on the DEVICE, and their total is bounded: beyond `max_device_bytes` the least recently used clouds
+    move to host memory and come back (same bits) when an edge asks for them -- a loop closure against a key-frame of an hour
+    ago pays one upload, a long drive does not grow the GPU footprint without bound."""
+
+    def __init__(self, device, max_device_bytes: int = 4 << 30):
+        self.device, self.max_device_bytes = torch.device(device), int(max_device_bytes)
+        self._dev: "OrderedDict[int, torch.Tensor]" = OrderedDict()   # least recently used first
+        self._host: Dict[int, torch.Tensor] = {}
+        self._bytes = 0
+        self.stats = dict(evicted=0, restored=0)
+
+    def __contains__(self, tok) -> bool:
+        return tok in self._dev or tok in self._host
+
+    def __len__(self) -> int:
+        return len(self._dev) + len(self._host)
+
+    def device_bytes(self) -> int:
+        return self._bytes
+
+    def __setitem__(self, tok, pcd: torch.Tensor) -> None:
+        self.pop(tok, None)
+        pcd = pcd if pcd.device == self.device else pcd.to(self.device)
+        self._dev[tok] = pcd
+        self._bytes += pcd.numel() * pcd.element_size()
+        self._shrink(keep=tok)
+
+    def _shrink(self, keep) -> None:
+        while self._bytes > self.max_device_bytes and len(self._dev) > 1:
+            tok = next(iter(self._dev))
+            if tok == keep:
+                self._dev.move_to_end(tok)
+                continue
+            t = self._dev.pop(tok)
+            self._bytes -= t.numel() * t.element_size()
+            self._host[tok] = t.cpu()           # synchronous copy: the device block is free for reuse when it returns
+            self.stats["evicted"] += 1
+
+    def __getitem__(self, tok) -> torch.Tensor:
+        if tok in self._dev:
+            self._dev.move_to_end(tok)
+            return self._dev[tok]
+        t = self._host.pop(tok).to(self.device)
+        self.stats["restored"] += 1
+        self._dev[tok] = t
+        self._bytes += t.numel() * t.element_size()
+        self._shrink(keep=tok)
+        return t
+
+    def get(self, tok, default=None):
+        return self[tok] if tok in self else default
+
+    def pop(self, tok, default=None):
+        if tok in self._dev:
+            t = self._dev.pop(tok)
+            self._bytes -= t.numel() * t.element_size()
+            return t
+        return self._host.pop(tok, default)
+
+
 class Rank0Consumer:
     def __init__(self, decoder, device, slam_args: Optional[dict] = None, optimize_every: int = 0,
                  exact_odometry: bool = False, agent_id: int = 0, loop_targets: str = "self",
@@ -103,7 +167,8 @@ class Rank0Consumer:
         self._searches: Dict[tuple, List[int]] = {}    # graph_search results since the last new edge of their kinds
         self._near: Dict[int, tuple] = {}              # key-frame neighbourhood of a scan + its positions (see _neighbourhood)
         self.desc: Dict[int, torch.Tensor] = {}        # key-frames and the scan at hand: descriptors on the device
-        self.pcd: Dict[int, torch.Tensor] = {}         # full clouds (3,N) in metres on the device, when the caller has them
+        # full clouds (3,N) in metres, when the caller has them: on the device up to a budget, the rest on the host
+        self.pcd = ScanCloudStore(self.device, int(self.args.get("scan_cloud_device_bytes", 4 << 30)))
         self.coor: Dict[int, int] = {}                 # token -> coordinate system (multi-agent: one per agent until loops merge them)
         self.coor_sys = agent_id                       # SlamSystem.coor_sys (core.py:44)
         self.last_known_keyframe: Optional[int] = None

@@ -16,7 +16,10 @@ FUSED_LN = True        # False: Linear + LayerNorm as two kernels at every size 
 # alone, +2.7 % frames/s in the pipelined bench, error against fp64 at the fp32 kernel's level.  False: the fp32-MFMA kernel
 # everywhere.  (The library is compiled without packed fp32 instructions because of this kernel: csrc/build.py says why.)
 GEMM_BF16X3 = True
-BF16X3_MAX_K = 512     # layers up to this reduction length take the bf16x3 kernel (longer ones are the encoder's few-row tails)
+# layers up to this reduction length take the bf16x3 kernel.  Round 5: 512 -> 2048 (every layer of both networks; the longer ones are
+# the encoder's few-row tails 768 -> 256, 1024 -> 256, 2048 -> 512, until then on the fp32-MFMA kernel): pipelined step 4.19 / 4.20 ->
+# 4.12 / 4.15 ms (A/B, 60 steps, two alternating repetitions; 1024: 4.14 / 4.12)
+BF16X3_MAX_K = 2048
 # ... and the Linear + LayerNorm layers with 128 <= K <= 512 (both forms: fused gemm_ln_b3_kernel / GEMM + LayerNorm, identical
 # rows).  Pipelined step 4.27 -> 4.19 ms against the fp32 fused kernel's 4.33 (csrc/gemm_b3.hip, dpm_linear_layernorm_bf16x3,
 # has the history of its tile shapes).

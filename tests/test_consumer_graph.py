@@ -89,3 +89,22 @@ def test_text_writers_equal_the_reference_s(tmp_path):
             assert open(tmp_path / str(i) / name).read() == text, (i, name)
             n += 1
     assert n == 20
+
+
+def test_scan_cloud_store_bounds_device_residency_and_returns_the_same_bits():
+    """consumer.ScanCloudStore (the consumer's full_pcd map): beyond its budget the least recently used clouds leave the device and
+    come back unchanged when an edge asks for them (logic exercised on the CPU device; the consumer tests drive it on the GPU)."""
+    from deeppointmap_amd.consumer import ScanCloudStore
+    gen = torch.Generator().manual_seed(3)
+    clouds = {t: torch.randn(3, 1000, generator=gen) for t in range(10)}
+    st = ScanCloudStore("cpu", max_device_bytes=3 * 12000 + 100)      # room for three clouds
+    for t, c in clouds.items():
+        st[t] = c
+        assert st.device_bytes() <= 3 * 12000 + 100
+    assert len(st) == 10 and st.stats["evicted"] == 7 and all(t in st for t in clouds)
+    assert torch.equal(st[0], clouds[0]) and st.stats["restored"] == 1            # back from the host, same bits
+    assert st.device_bytes() <= 3 * 12000 + 100
+    assert torch.equal(st.get(9), clouds[9]) and st.get(77) is None
+    assert torch.equal(st.pop(3), clouds[3]) and 3 not in st and st.pop(3, None) is None
+    st[0] = clouds[1]                                                             # overwrite keeps the accounting straight
+    assert torch.equal(st[0], clouds[1]) and st.device_bytes() <= 3 * 12000 + 100
