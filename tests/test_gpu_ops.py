@@ -366,14 +366,18 @@ def test_bf16x3_linear_vs_fp64_and_layout_independence(ops, monkeypatch):
     wide2 = torch.zeros(4096, 260, device=DEV)
     wide2[:, 4:] = x
     assert torch.equal(ops.linear(wide2[:, 4:], W, b), big)
-    # 64 x 128 tiles (launches of >= 1024 of them) with a ragged last row tile, against the 64 x 64 / 32 x 32 variants and the
-    # four-tiles-in-flight variants (small launches) on slices of the same rows
+    # 64 x 128 tiles (launches of >= 1024 of them; 768 and 384 columns) with a ragged last row tile, against the 64 x 64 /
+    # 32 x 32 variants and the four-tiles-in-flight variants (small launches) on slices of the same rows
     xb = torch.randn(32768 + 17, 256, device=DEV, generator=gen)
-    bigw = ops.linear(xb, W, b, act=ops.ACT_RELU)
-    for lo, hi in [(0, 200), (30000, 31000), (32768 - 40, 32768 + 17), (5000, 5000 + 4096)]:
-        assert torch.equal(ops.linear(xb[lo:hi].contiguous(), W, b, act=ops.ACT_RELU), bigw[lo:hi]), (lo, hi)
-    want = torch.relu(xb[-64:].double() @ W.double().t() + b.double())
-    torch.testing.assert_close(bigw[-64:].double(), want, rtol=1e-5, atol=2e-5)
+    for Wt, bt in ((W, b), (W[:384], b[:384])):
+        bigw = ops.linear(xb, Wt, bt, act=ops.ACT_RELU)
+        for lo, hi in [(0, 200), (30000, 31000), (32768 - 40, 32768 + 17), (5000, 5000 + 4096)]:
+            assert torch.equal(ops.linear(xb[lo:hi].contiguous(), Wt, bt, act=ops.ACT_RELU), bigw[lo:hi]), (Wt.shape[0], lo, hi)
+        want = torch.relu(xb[-64:].double() @ Wt.double().t() + bt.double())
+        torch.testing.assert_close(bigw[-64:].double(), want, rtol=1e-5, atol=2e-5)
+    res = torch.randn(32768 + 17, 768, device=DEV, generator=gen)                    # the wide tile's residual path
+    assert torch.equal(ops.linear(xb[100:612].contiguous(), W, b, residual=res[100:612].contiguous()),
+                       ops.linear(xb, W, b, residual=res)[100:612])
     # weights edited in place: the planes follow
     with torch.no_grad():
         W.mul_(0.5)
