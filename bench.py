@@ -72,7 +72,7 @@ def parity_gate(desc: torch.Tensor, table: torch.Tensor, n_points: int) -> dict:
     if n_points != 65536 or desc is None or desc.shape[0] < 6 or table.shape[0] < 6:
         return {"checked": False, "why": "fixtures cover the 65 536-point synthetic sequence, frames 0-5"}
     poses, fps, enc = (np.load(os.path.join(gold, f)) for f in ("poses_full.npz", "fps.npz", "encoder_full.npz"))
-    d, t = desc[:6].detach().float().cpu(), table.detach().double().cpu()
+    d, t = desc[:6].detach().cpu().float(), table.detach().cpu().double()   # copies only: no device arithmetic for the gate
     max_dt = max_dr = max_drmse = 0.0
     n_conf_equal = True
     for f in range(1, 6):

@@ -10,6 +10,10 @@ rows = db.execute(f"select name, start, end, {qcol or 0}, (grid_x/workgroup_x)*(
 starts = [i for i, r in enumerate(rows) if first in r[0]]
 lo = starts[-1]
 rows = rows[lo:]
+# what follows the step's last kernel (infomat_finalize_kernel) is bench.py's parity gate reading the results back: not the step
+ends = [i for i, r in enumerate(rows) if "infomat_finalize_kernel" in r[0]]
+if ends:
+    rows = rows[:ends[-1] + 1]
 t0 = rows[0][1]
 last_end = {}
 tot = gap_tot = 0
