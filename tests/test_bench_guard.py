@@ -76,3 +76,39 @@ def test_sigterm_from_the_launcher_leaves_a_record():
 def test_finished_guard_stays_quiet():
     rc, out, err, _ = _run("ok")
     assert rc == 0 and out.strip() == "DONE"
+
+
+def test_parity_gate_accepts_the_reference_rows_and_refuses_perturbed_ones():
+    """bench.py::parity_gate on rows built FROM the fixtures it checks against (the gate's own sensitivity, on the CPU): the
+    reference's values pass; a pose 2e-4 m off, a key point one ulp off, a changed inlier count, an asymmetric information matrix
+    each fail; another workload is reported as unchecked."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    gold = os.path.join(ROOT, "tests", "golden")
+    poses, fps, enc = (np.load(os.path.join(gold, f)) for f in ("poses_full.npz", "fps.npz", "encoder_full.npz"))
+    desc = torch.zeros(8, 131, 256)
+    desc[0, 128:131] = torch.from_numpy(enc["synthetic0.coor"]) * 60.0
+    for f in (0, 1):
+        desc[f, :128] = torch.from_numpy(enc[f"synthetic{f}.fea"])
+    table = torch.zeros(8, 56)
+    table[:, 20:56] = torch.eye(6).reshape(36)
+    for f in range(1, 6):
+        k = f"pair{f - 1}_{f}"
+        table[f, 0:9] = torch.from_numpy(poses[k + ".R"]).reshape(9)
+        table[f, 9:12] = torch.from_numpy(poses[k + ".T"]).reshape(3)
+        table[f, 12], table[f, 14] = float(poses[k + ".rmse"]), float(poses[k + ".n_conf"])
+    g = bench.parity_gate(desc, table, 65536)
+    assert g["checked"] and g["ok"] and g["pairs"] == 5 and g["fps_prefix_equal"] and g["max_dT_m"] == 0.0, g
+
+    def broken(edit):
+        d, t = desc.clone(), table.clone()
+        edit(d, t)
+        return bench.parity_gate(d, t, 65536)
+    assert not broken(lambda d, t: t[3, 9].add_(2e-4))["ok"]                                           # a pose off by 0.2 mm
+    assert not broken(lambda d, t: d[0, 128, 7].copy_(torch.nextafter(d[0, 128, 7], torch.tensor(9e9))))["ok"]   # a key point, one ulp
+    assert not broken(lambda d, t: t[2, 14].add_(1))["ok"]                                             # inlier count
+    assert not broken(lambda d, t: t[5, 21].add_(0.5))["ok"]                                           # information matrix asymmetric
+    assert not broken(lambda d, t: d[1, 5, 5].add_(1e-3))["ok"]                                        # a descriptor feature
+    assert bench.parity_gate(desc, table, 16384) == {"checked": False, "why": "fixtures cover the 65 536-point synthetic sequence, frames 0-5"}
