@@ -39,8 +39,11 @@ __global__ __launch_bounds__(256) void posemb_kernel(const float *__restrict__ x
 // ------------------------------------------------------------------------------------------
 constexpr int HD = 32;
 constexpr float LOG2E = 1.44269504088896340736f;
+// workgroups of 128 queries a launch must have for the 32-queries-per-wave form (QT = 2); 0 = never.  Round 5: with P V on the
+// bf16 pipe that form holds 204 registers (two waves per SIMD) against 128 at QT = 1; it is as fast alone (67.4 against 66.5 us at
+// 128 sequences) and costs the pipelined step what the P V change wins (4.16 / 4.18 against 4.10 / 4.10 ms): never.
 #ifndef DPM_ATT_WIDE_MIN
-#define DPM_ATT_WIDE_MIN 1024   // workgroups of 128 queries a launch must have for the 32-queries-per-wave form
+#define DPM_ATT_WIDE_MIN 0
 #endif
 constexpr int RES_HDR = 20;  // floats before the inlier-confidence list in a Kabsch `result`
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -81,9 +84,11 @@ __device__ __forceinline__ float rows4_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-// Flash-attention structure on fp32 MFMA with the TRANSPOSED score tile: S^T = K Q^T, so that the C-layout registers
+// Flash-attention structure on the matrix pipe with the TRANSPOSED score tile: S^T = K Q^T, so that the C-layout registers
 // of a score block (lane l: keys 4(l>>4)+q of the block, query l&15) are already the B operand of O^T = V^T P^T under
-// a k-remap (MFMA (block j, q) contracts the keys 16j + 4g + q, g = lane group, on both operands).  The
+// a k-remap (K-step h contracts, in slot 8 g + e of lane group g, the key 16 (2 h + (e >> 2)) + 4 g + (e & 3) on both operands).
+// Both products are exact bf16x3 products (gemm_b3.hip has the arithmetic; the scores since round 4, P V since round 5:
+// 128 sequences of 256 tokens 79.9 -> 67.4 us, 2 x 4096 x 4096 322 -> 269 us, error against fp64 4.2e-7 against 6.2e-7).  The
 // probabilities never leave the registers (no LDS round trip to re-shape P), a lane owns ONE query -- its running
 // max / sum are scalars, the max needs two lane swaps instead of a 16-lane reduction, the row sum meets once at the
 // end -- and it ends up with 2 x 4 consecutive output channels of that query: two 16-byte stores.
@@ -121,9 +126,14 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
     constexpr int KLD = HD;
     static_assert(HD == 32, "the score product is one v_mfma_f32_16x16x32_bf16 deep");
     __shared__ __attribute__((aligned(16))) uint16_t Ks3[3][TK][KLD];
-    // A operand of O^T: A[i=d][k=key] = Vs[key][d].  Row stride 36: 16-byte aligned rows, and the four lane groups of
-    // a fragment read (rows 4 apart) land 16 banks apart -- every bank serves exactly two lanes, the b32 minimum.
-    __shared__ __attribute__((aligned(16))) float Vs[TK][HD + 4];
+    // A operand of O^T = V^T P^T, which since round 5 runs as an exact bf16x3 product as well (the probabilities are split in
+    // registers, V while it is staged): three bf16 planes of the V tile TRANSPOSED, Vt3[plane][d][slot], 64 slots = the tile's
+    // keys in the order the score registers hold them: slot 32 h + 8 g + e <-> key 16 (2 h + (e >> 2)) + 4 g + (e & 3), so that
+    // a lane's eight consecutive slots (one 16-byte fragment read) are exactly the keys whose probabilities it holds for K-step h.
+    // Rows of 128 bytes, the eight 16-byte chunks of row d stored at chunk ^ ((d >> 1) & 7): the 16 lanes of every ds_read_b128
+    // group hit 16 different bank groups.
+    __shared__ __attribute__((aligned(16))) uint16_t Vt3[3][HD][TK];
+    auto vt_col = [](int d, int slot) { return ((((slot >> 3) ^ (d >> 1)) & 7) << 3) | (slot & 7); };
     // all query tiles and heads of one batch element on one XCD: its K / V rows are fetched into that L2 once
     const unsigned bid = xcd_chunked_id((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
                                         gridDim.x * gridDim.y * gridDim.z);
@@ -196,7 +206,16 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
             *reinterpret_cast<u32x2 *>(&Ks3[0][kr][b3_col(kr, c4)]) = u32x2{pack2(h0, h1), pack2(h2, h3)};
             *reinterpret_cast<u32x2 *>(&Ks3[1][kr][b3_col(kr, c4)]) = u32x2{pack2(m0, m1), pack2(m2, m3)};
             *reinterpret_cast<u32x2 *>(&Ks3[2][kr][b3_col(kr, c4)]) = u32x2{pack2(l0, l1), pack2(l2, l3)};
-            *reinterpret_cast<float4 *>(&Vs[kr][c4]) = vreg[p];     // row stride 144 B: 16-byte aligned
+            // V: split and scattered into the transposed planes (four 2-byte stores per plane)
+            const int vj = kr >> 4, slot = 32 * (vj >> 1) + 8 * ((kr >> 2) & 3) + 4 * (vj & 1) + (kr & 3);
+            const float vv[4] = {vreg[p].x, vreg[p].y, vreg[p].z, vreg[p].w};
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                unsigned vh, vm, vl;
+                split3(vv[dd], vh, vm, vl);
+                const int d = c4 + dd, col = vt_col(d, slot);
+                Vt3[0][d][col] = (uint16_t)(vh >> 16), Vt3[1][d][col] = (uint16_t)(vm >> 16), Vt3[2][d][col] = (uint16_t)(vl >> 16);
+            }
         }
         __syncthreads();
         if (n0 + TK < n_end) fetch(n0 + TK);
@@ -269,19 +288,41 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
 #pragma unroll
             for (int q = 0; q < 4; ++q) oacc[u][0][q] *= corr, oacc[u][1][q] *= corr;
         }
-        // O^T += V^T P^T: the score registers are the B operand as they are
+        // O^T += V^T P^T as two K-steps of 32 keys: the probabilities of key blocks 2 h, 2 h + 1 (this lane's eight registers)
+        // are split into three bf16 planes in place -- they ARE the B operand's slots 8 g .. 8 g + 7 -- and meet the V^T planes
+        // in six bf16 instructions per output block (smallest terms first; (plane of V, plane of P)); 2 QT independent
+        // accumulators lie between two instructions on the same one.  24 instructions of 16 cycles per 16 queries and key tile
+        // instead of 32 fp32 ones of 32.
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 pb[QT][3], va[2][3];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int u = 0; u < QT; ++u) {
+                unsigned hh[8], mm[8], ll[8];
 #pragma unroll
-                for (int jd = 0; jd < 2; ++jd) {
-                    const float av = Vs[j * 16 + g * 4 + q][jd * 16 + (lane & 15)];
-#pragma unroll
-                    for (int u = 0; u < QT; ++u)
-                        oacc[u][jd] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sacc[u][j][q], oacc[u][jd], 0, 0, 0), mfma_pace();
-                }
+                for (int e = 0; e < 8; ++e) split3(sacc[u][2 * h + (e >> 2)][e & 3], hh[e], mm[e], ll[e]);
+                pb[u][0] = __builtin_bit_cast(bf16x8, u32x4{pack2(hh[0], hh[1]), pack2(hh[2], hh[3]), pack2(hh[4], hh[5]), pack2(hh[6], hh[7])});
+                pb[u][1] = __builtin_bit_cast(bf16x8, u32x4{pack2(mm[0], mm[1]), pack2(mm[2], mm[3]), pack2(mm[4], mm[5]), pack2(mm[6], mm[7])});
+                pb[u][2] = __builtin_bit_cast(bf16x8, u32x4{pack2(ll[0], ll[1]), pack2(ll[2], ll[3]), pack2(ll[4], ll[5]), pack2(ll[6], ll[7])});
             }
+#pragma unroll
+            for (int jd = 0; jd < 2; ++jd)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const int d = jd * 16 + (lane & 15);
+                    va[jd][pl] = *reinterpret_cast<const bf16x8 *>(&Vt3[pl][d][vt_col(d, 32 * h + 8 * g)]);
+                }
+#define DPM_PV3(PVQ, PPQ)                                                                                           \
+    _Pragma("unroll") for (int jd = 0; jd < 2; ++jd) _Pragma("unroll") for (int u = 0; u < QT; ++u)                \
+        oacc[u][jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[jd][PVQ], pb[u][PPQ], oacc[u][jd], 0, 0, 0), mfma_pace()
+            DPM_PV3(1, 1);
+            DPM_PV3(2, 0);
+            DPM_PV3(0, 2);
+            DPM_PV3(1, 0);
+            DPM_PV3(0, 1);
+            DPM_PV3(0, 0);
+#undef DPM_PV3
+        }
     }
     // lane: queries q0 + 16 u + (lane&15), channels 16 jd + 4 g .. +3
     if (SPLIT) {
@@ -1320,7 +1361,7 @@ static int attention_launch(const float *Q, int ldq, long long sq, const float *
                      ldo % 4 == 0 && so % 4 == 0 && ((uintptr_t)out & 15) == 0;  // 16-byte K / V loads and output stores
     const float scale = (float)(1.0 / sqrt((double)head_dim));
     // 32 queries per wave when the query count fills such blocks and there are enough of them for the chip
-    const bool wide = M % 128 == 0 && (long long)(M / 128) * heads * B >= DPM_ATT_WIDE_MIN;
+    const bool wide = DPM_ATT_WIDE_MIN > 0 && M % 128 == 0 && (long long)(M / 128) * heads * B >= DPM_ATT_WIDE_MIN;
 #define DPM_ATT(V, QT)                                                                                                  \
     hipLaunchKernelGGL((attention_kernel<V, QT>), dim3(dpm_cdiv(M, 64 * QT), heads, B), dim3(256), (size_t)dpm_knob("DPM_ATT_LDS_PAD", 0), (hipStream_t)stream, \
                        Q, ldq, sq, K, ldk, sk, V_, ldv, sv, out, ldo, so, M, N, scale, kv_shift, nullptr, 1, nullptr,     \
