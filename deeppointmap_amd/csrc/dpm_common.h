@@ -76,6 +76,10 @@ __device__ __forceinline__ void mfma_pace() {
 // ---- exact three-way bf16 split of an fp32 value (csrc/gemm_b3.hip says what it is for): x = hi + mid + lo, each term a
 // truncation to the top 16 bits of a float, each remainder exact.  hi / mid come back masked, lo unmasked (its truncation
 // happens where the term is stored: pack2 / a 16-bit store of the upper half).
+// Finite values only: for x = +-Inf the first remainder is Inf - Inf = NaN, so a bf16x3 product turns an infinite operand into
+// NaN where the fp32 kernels propagate the infinity (NaN stays NaN).  Guarding it costs a class test and a select per value on
+// kernels that are bound by exactly these instructions; no layer of the path makes a non-finite activation from finite inputs
+// (LayerNorm follows every product), and tests/test_gpu_ops.py::test_bf16x3_non_finite_inputs_give_nan_not_garbage pins the behaviour.
 __device__ __forceinline__ void split3(float x, unsigned &hi, unsigned &mid, unsigned &lo) {
     hi = __float_as_uint(x) & 0xFFFF0000u;
     const float r1 = x - __uint_as_float(hi);

@@ -384,6 +384,26 @@ def test_bf16x3_linear_vs_fp64_and_layout_independence(ops, monkeypatch):
     torch.testing.assert_close(ops.linear(x, W, b), (big - b) * 0.5 + b, rtol=1e-5, atol=1e-5)
 
 
+def test_bf16x3_non_finite_inputs_give_nan_not_garbage(ops, monkeypatch):
+    """The exact three-way split is defined for finite values (csrc/dpm_common.h, split3): an infinite operand becomes NaN in the
+    rows it touches -- where the fp32 kernel would carry the infinity -- and every other row is untouched.  Pinned so that the
+    difference is a documented one."""
+    from deeppointmap_amd import knobs
+    monkeypatch.setattr(knobs, "GEMM_BF16X3", True)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(4096, 256, device=DEV, generator=gen)
+    W, b = torch.randn(256, 256, device=DEV, generator=gen) / 16, torch.randn(256, device=DEV, generator=gen)
+    clean = ops.linear(x, W, b)
+    x2 = x.clone()
+    x2[7, 3], x2[100, 200], x2[4000, 0] = float("inf"), float("-inf"), float("nan")
+    y = ops.linear(x2, W, b)
+    bad = torch.zeros(4096, dtype=torch.bool, device=DEV)
+    bad[[7, 100, 4000]] = True
+    assert torch.isnan(y[bad]).all() and torch.equal(y[~bad], clean[~bad])
+    y32 = ops.linear(x2, W, b, exact=True)                      # the fp32 kernel: infinities stay infinities, NaN stays NaN
+    assert torch.isinf(y32[7]).all() and torch.isinf(y32[100]).all() and torch.isnan(y32[4000]).all()
+
+
 def test_linear_large_tiles_vs_torch(ops):
     """The shapes that take the 128x128 persistent kernel (K >= 1024, >= 512 output tiles) and the 64x64 kernel's
     staged epilogue with ragged edges, against an fp64 product."""

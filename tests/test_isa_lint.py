@@ -16,6 +16,7 @@ def test_library_has_no_packed_fp32_instructions():
     if not os.path.exists(isa_lint.OBJDUMP):
         pytest.skip("llvm-objdump not found")
     assert isa_lint.packed_fp32(LIB) == {}
+    assert isa_lint.routed_operands(LIB) == {}      # no high-half op_sel outside the measured v_pk_mov_b32
 
 
 def test_lint_recognises_the_failing_form():
@@ -23,3 +24,6 @@ def test_lint_recognises_the_failing_form():
     line = "\tv_pk_fma_f32 v[84:85], v[60:61], v[46:47], v[84:85] op_sel:[0,1,0]"
     m = isa_lint.PACKED.search(line)
     assert m and m.group(1) == "v_pk_fma_f32"
+    r = isa_lint.ROUTED.search(line)
+    assert r and r.group(1) == "v_pk_fma_f32" and "1" in r.group(2)
+    assert isa_lint.ROUTED.search("\tv_pk_mov_b32 v[14:15], v[6:7], v[6:7] op_sel:[1,0]").group(1) in isa_lint.ROUTED_OK
