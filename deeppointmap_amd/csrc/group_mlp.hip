@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
             const int c = 4 * (gl + G * v) + e;
             gm[v][e] = gamma[c], bt[v][e] = beta[c];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) wr[v][e][d] = Wr[(size_t)c * ldwr + d];
+            for (int d = 0; d < 3; ++d) wr[v][e][d] = Wr[(size_t)c * ldwr + d] * inv_r;   // (p - centre) / r folded into the weight
             if (AFFINE) {
                 cv[v][e] = cvec[c];
 #pragma unroll
@@ -495,8 +495,12 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
     const int last = (int)min((long long)first + cpw, total);
     for (int cc = first; cc < last; ++cc) {
         const int b = cc / S;
-        const float *xyz = xyz_all + (size_t)b * N * 3;
-        const float *P = AFFINE ? nullptr : P_all + (size_t)b * N * COUT;
+        // the frame's coordinates, its projected rows and the centre's index row through buffer descriptors built from scalars:
+        // a gather's address is then ONE 32-bit offset per lane (no 64-bit vector address arithmetic per load)
+        const auto xyz_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xyz_all + (size_t)b * N * 3), 0, N * 12, 0x00020000);
+        const auto P_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(AFFINE ? xyz_all : P_all + (size_t)b * N * COUT), 0,
+                                                            AFFINE ? 0 : (int)((size_t)N * COUT * 4 < 0x7fffffffu ? (size_t)N * COUT * 4 : 0x7fffffffu), 0x00020000);
+        const auto idx_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(idx_all + (size_t)cc * K), 0, K * 4, 0x00020000);
         const float cx = ctr_all[(size_t)cc * 3], cy = ctr_all[(size_t)cc * 3 + 1], cz = ctr_all[(size_t)cc * 3 + 2];
         float mx[V][4];
 #pragma unroll
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
                 const int r = min(r0 + u * RPW + gr, K - 1);  // rows past K repeat the last one: a max does not mind
-                ng[u] = (unsigned)idx_all[(size_t)cc * K + r];
+                ng[u] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(idx_rs, r * 4, 0, 0);
             }
             float pxg[UG], pyg[UG], pzg[UG];
             float4 pg[UG][AFFINE ? 1 : V];
@@ -519,18 +523,22 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
             for (int u = 0; u < UG; ++u) {
                 // 32-bit element offsets from the (scalar) frame pointers: a frame is far below 2^32 bytes
                 ng[u] = (unsigned)min(max((int)ng[u], 0), N - 1);
-                const float *pn = xyz + ng[u] * 3u;  // one pointer, three adjacent floats: stays one 12-byte load
-                pxg[u] = pn[0], pyg[u] = pn[1], pzg[u] = pn[2];
+                using u32x3 = __attribute__((ext_vector_type(3))) unsigned;
+                using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+                const u32x3 pn = __builtin_amdgcn_raw_buffer_load_b96(xyz_rs, (int)__umul24(ng[u], 12u), 0, 0);   // one 12-byte load (N < 2^24: launch_gather)
+                pxg[u] = __uint_as_float(pn[0]), pyg[u] = __uint_as_float(pn[1]), pzg[u] = __uint_as_float(pn[2]);
                 if (!AFFINE) {
 #pragma unroll
-                    for (int v = 0; v < V; ++v)
-                        pg[u][v] = *reinterpret_cast<const float4 *>(P + (ng[u] * (unsigned)COUT + 4u * (unsigned)(gl + G * v)));
+                    for (int v = 0; v < V; ++v) {
+                        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(P_rs, (int)(ng[u] * (unsigned)(COUT * 4) + 16u * (unsigned)(gl + G * v)), 0, 0);
+                        pg[u][v] = make_float4(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
             const float px = pxg[u], py = pyg[u], pz = pzg[u];
-            const float rx = (px - cx) * inv_r, ry = (py - cy) * inv_r, rz = (pz - cz) * inv_r;
+            const float rx = px - cx, ry = py - cy, rz = pz - cz;   // 1 / r sits in the weights
             float y[V][4], sum = 0.f;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
@@ -590,7 +598,7 @@ int launch_gather(const float *P, const float *A, const float *cvec, const float
                   const int32_t *idx, const float *Wr, int ldwr, const float *gamma, const float *beta, int B, int N,
                   int S, int K, float inv_r, float *out, hipStream_t st) {
     const long long total = (long long)B * S;
-    if (total >= (1LL << 30)) return DPM_EUNSUPPORTED;
+    if (total >= (1LL << 30) || N >= (1 << 24) || (long long)N * COUT * 4 >= (1LL << 31)) return DPM_EUNSUPPORTED;   // 32-bit buffer offsets
     const int cpw = total >= (1 << 16) ? 8 : (total >= (1 << 13) ? 2 : 1);  // centres per wave
     hipLaunchKernelGGL((group_gather_ln_max_kernel<COUT, V, AFFINE>), dim3(dpm_cdiv(total, 4LL * cpw)), dim3(256), (size_t)dpm_knob("DPM_GATHER_LDS_PAD", 0), st, P,
                        A, cvec, xyz, centers, idx, Wr, ldwr, gamma, beta, N, S, K, total, cpw, inv_r, out);
