@@ -43,6 +43,8 @@ def test_gathers_sharing_compute_units_with_bf16_matrix_instructions_are_bit_sta
     packed build of the first-level gather differs in every second launch (profiles/r05_pk_opsel.md); on disjoint compute units
     it never does."""
     res = _run("bf16x3", 1000, {"STRESS_CU_SPLIT": "same"}, only=("gather",))
+    if "skipped" in res:
+        pytest.skip(res["skipped"])
     bad = {k: v for k, v in res["differing_calls"].items() if not k.startswith("_") and v}
     assert res["cu_split"] == "same" and res["differing_calls"]["_noise_launches"] >= 300, res
     assert not bad, f"results changed while bf16 MFMAs shared the compute units (of {res['iters']} calls each): {bad}"
