@@ -157,10 +157,12 @@ class Guard:
                 self.fail(f"phase '{self.phase_name}' exceeded its budget: a collective or a kernel did not complete", 124)
 
     def fail(self, why: str, code: int = 1) -> None:
-        with self._lock:
-            if self._done:
-                return
-            self._done = True
+        if not self._lock.acquire(blocking=False):   # somebody is failing already (a signal handler must not wait for its own thread)
+            return
+        if self._done:
+            self._lock.release()
+            return
+        self._done = True
         msg = f"{why} [rank {self.rank}/{self.world}, phase '{self.phase_name}', +{time.time() - self.t0:.1f} s]"
         # raw writes: this may run inside a signal handler that interrupted a print, or next to a thread that holds a stream's lock
         os.write(2, f"[bench rank {self.rank}/{self.world}] ERROR: {msg}\n".encode())
