@@ -50,11 +50,13 @@ SIGNATURES = {
     "dpm_group_mlp_max_generic": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, D, P, P]),
     "dpm_group_mlp_max_from_xyz": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, D, P, P]),
     "dpm_group_gather_ln_max": (I, [P, P, P, P, P, I, P, P, I, I, I, I, I, D, P, P]),
+    "dpm_group_gather_ln_max_folded": (I, [P, P, P, P, I, P, P, I, I, I, I, I, D, P, P]),
     "dpm_group_affine_ln_max": (I, [P, P, P, P, P, P, I, P, P, I, I, I, I, I, D, P, P]),
     "dpm_linear": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
     "dpm_linear_batched": (I, [P, I, LL, P, I, LL, P, P, I, LL, P, I, LL, I, I, I, I, I, P]),
     "dpm_split_bf16x3": (I, [P, LL, P, P]),
     "dpm_linear_bf16x3": (I, [P, I, P, I, LL, P, P, I, P, I, I, I, I, I, P]),
+    "dpm_linear_bf16x3_rank3": (I, [P, I, P, I, LL, P, P, I, P, I, I, I, I, I, P, P, I, D, P]),
     "dpm_linear_layernorm_bf16x3": (I, [P, I, P, I, LL, P, P, P, P, P, P, I, I, I, I, I, P]),
     "dpm_pwconv_pair_bf16x3": (I, [P, I, P, LL, P, P, P, P, LL, P, P, P, P, P, I, I, I, P]),
     "dpm_layernorm": (I, [P, I, P, P, P, P, P, I, I, I, I, P]),

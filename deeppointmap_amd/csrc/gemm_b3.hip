@@ -65,7 +65,10 @@ template <int BM, int BN, bool XVEC, int PF = 1>
 __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ Wp, int ldw,
                                                       long long plane, const float *__restrict__ bias,
                                                       const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo,
-                                                      int R, int Cin, int Cout, int act) {
+                                                      int R, int Cin, int Cout, int act, const float *__restrict__ r3x = nullptr,
+                                                      const float *__restrict__ r3w = nullptr, int ldr3 = 0, float r3s = 0.f) {
+    // r3x / r3w (round 5): a rank-3 term in the epilogue, out += r3s * (r3x[row, 0:3] . r3w[col, 0:3]) in fp32 -- the relative-
+    // coordinate columns of a grouping layer applied to the POINT's own coordinates (group_mlp.hip, "folded" gather)
     constexpr int LDC = BN + 4, MB = BM / 32, NB = BN / 32, PX = BM / 32, WT = BN * 4, PW = (WT + 255) / 256;   // WT: 16-byte pieces of a W plane tile
     constexpr int SM0 = 3 * (BM + BN) * B3_LD, SM1 = 2 * BM * LDC, SM = SM0 > SM1 ? SM0 : SM1;   // operand planes | staged output tile
     __shared__ __attribute__((aligned(16))) uint16_t smem[SM];   // 24 576 B at 64 x 64: X planes, then W planes
@@ -178,12 +181,26 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
     if (c < Cout) {   // Cout % 4 == 0 (dispatch): a thread's four columns exist together
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias) bv = *reinterpret_cast<const float4 *>(bias + c);
+        float w3[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        if (r3x) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) w3[q][d] = r3w[(size_t)(c + q) * ldr3 + d] * r3s;
+        }
 #pragma unroll
         for (int p = 0; p < BM / RPS; ++p) {
             const int r = row0 + p * RPS + cr;
             if (r >= R) continue;
             float4 v = *reinterpret_cast<const float4 *>(&ct[(p * RPS + cr) * LDC + cc]);
             v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+            if (r3x) {
+                const float x0 = r3x[3 * (size_t)r], x1 = r3x[3 * (size_t)r + 1], x2 = r3x[3 * (size_t)r + 2];
+                v.x = fmaf(x2, w3[0][2], fmaf(x1, w3[0][1], fmaf(x0, w3[0][0], v.x)));
+                v.y = fmaf(x2, w3[1][2], fmaf(x1, w3[1][1], fmaf(x0, w3[1][0], v.y)));
+                v.z = fmaf(x2, w3[2][2], fmaf(x1, w3[2][1], fmaf(x0, w3[2][0], v.z)));
+                v.w = fmaf(x2, w3[3][2], fmaf(x1, w3[3][1], fmaf(x0, w3[3][0], v.w)));
+            }
             if (res) {
                 const float4 rv = *reinterpret_cast<const float4 *>(res + (size_t)r * ldr + c);
                 v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
@@ -534,9 +551,26 @@ extern "C" int dpm_split_bf16x3(const float *W, long long n, void *planes, dpm_s
     return dpm_launch_status();
 }
 
+extern "C" int dpm_linear_bf16x3_rank3(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride,
+                                       const float *bias, const float *residual, int ldr, float *out, int ldo, int R, int Cin,
+                                       int Cout, int act, const float *x3, const float *w3, int ldw3, double scale,
+                                       dpm_stream_t stream);
+
 extern "C" int dpm_linear_bf16x3(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride, const float *bias,
                                  const float *residual, int ldr, float *out, int ldo, int R, int Cin, int Cout, int act,
                                  dpm_stream_t stream) {
+    return dpm_linear_bf16x3_rank3(x, ldx, w_planes, ldw, plane_stride, bias, residual, ldr, out, ldo, R, Cin, Cout, act, nullptr,
+                                   nullptr, 0, 0.0, stream);
+}
+
+// dpm_linear_bf16x3 plus a rank-3 term added in the epilogue: out[r, c] += scale * (x3[r, 0:3] . w3[c, 0:3]) (x3 (R,3) packed, w3
+// rows ldw3 floats apart; fp32 multiply-adds in k order, before residual and activation).  x3 NULL: dpm_linear_bf16x3.
+extern "C" int dpm_linear_bf16x3_rank3(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride,
+                                       const float *bias, const float *residual, int ldr, float *out, int ldo, int R, int Cin,
+                                       int Cout, int act, const float *x3, const float *w3, int ldw3, double scale,
+                                       dpm_stream_t stream) {
+    DPM_CHECK_ARG((x3 == nullptr) == (w3 == nullptr) && (!x3 || ldw3 >= 3));
+    const float r3s = (float)scale;
     DPM_CHECK_ARG(x && w_planes && out && R >= 1 && Cin >= 1 && Cout >= 1 && ldx >= Cin && ldw >= Cin && ldo >= Cout);
     DPM_CHECK_ARG(act >= DPM_ACT_NONE && act <= DPM_ACT_SIGMOID && (!residual || ldr >= Cout) && plane_stride >= (long long)Cout * ldw);
     auto al = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
@@ -548,7 +582,7 @@ extern "C" int dpm_linear_bf16x3(const float *x, int ldx, const void *w_planes, 
     const long long big = (long long)dpm_cdiv(R, 64) * dpm_cdiv(Cout, 64);
 #define DPM_B3_LAUNCH(TM, TN, V, PF)                                                                                          \
     hipLaunchKernelGGL((gemm_b3_kernel<TM, TN, V, PF>), dim3(dpm_cdiv(Cout, TN), dpm_cdiv(R, TM)), dim3(256), 0, (hipStream_t)stream, x, ldx, \
-                       (const uint16_t *)w_planes, ldw, plane_stride, bias, residual, ldr, out, ldo, R, Cin, Cout, act)
+                       (const uint16_t *)w_planes, ldw, plane_stride, bias, residual, ldr, out, ldo, R, Cin, Cout, act, x3, w3, ldw3, r3s)
     if (DPM_B3_WIDE && xvec && Cout % 128 == 0 && (long long)dpm_cdiv(R, 64) * (Cout / 128) >= DPM_B3_WIDE) {
         DPM_B3_LAUNCH(64, 128, true, 1);
     } else if (big >= 192 || (R > 1024 && Cout > 32)) {

@@ -465,7 +465,15 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {
     return r;
 }
 
-template <int COUT, int V, bool AFFINE>
+// FOLD (round 5): the relative-coordinate term is linear in the POINT and in the CENTRE separately,
+//   W_r (p_n - c) / r  =  W_r' p_n  -  W_r' c,      W_r' = W_r / r,
+// so its point half is folded into what is gathered -- the projection GEMM's epilogue adds W_r' p_n to the projected row
+// (dpm_linear_bf16x3_rank3), the affine first level merges it into its point map (A + W_r') -- and the centre half is ONE
+// vector per centre, subtracted per row: 4 subtractions instead of 3 + 12 operations per gathered row and lane, and the
+// projected path gathers no coordinates at all.  The price is cancellation: |W_r' p| is up to |p| / r (20 at the first level)
+// times the term it replaces, i.e. a rounding error of ~1e-6 relative instead of ~1e-7 on the pre-LayerNorm values; measured on
+// the oracle with this arithmetic: descriptors move by 3.3e-6, poses by 4-5e-6 m, inlier counts unchanged.
+template <int COUT, int V, bool AFFINE, bool FOLD = false>
 __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
     const float *__restrict__ P_all, const float *__restrict__ A, const float *__restrict__ cvec,
     const float *__restrict__ xyz_all, const float *__restrict__ ctr_all, const int32_t *__restrict__ idx_all,
@@ -491,6 +499,14 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
                 for (int d = 0; d < 3; ++d) am[v][e][d] = A[3 * c + d];
             }
         }
+    if (FOLD && AFFINE) {   // the point map takes the point half of the relative-coordinate term
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) am[v][e][d] += wr[v][e][d];
+    }
     const int first = (int)((xcd_chunked_id(blockIdx.x, gridDim.x) * 4 + w) * (unsigned)cpw);
     const int last = (int)min((long long)first + cpw, total);
     for (int cc = first; cc < last; ++cc) {
@@ -507,6 +523,16 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
         for (int v = 0; v < V; ++v)
 #pragma unroll
             for (int e = 0; e < 4; ++e) mx[v][e] = 0.f;  // ReLU floor
+        float kc[FOLD ? V : 1][4];   // FOLD: the centre half, W_r' c (AFFINE: minus the point map's constant, so that one add serves both)
+        if (FOLD) {
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float k = fmaf(wr[v][e][2], cz, fmaf(wr[v][e][1], cy, wr[v][e][0] * cx));
+                    kc[v][e] = AFFINE ? cv[v][e] - k : k;
+                }
+        }
         // UG row passes at a time: their UG index loads go out together, then the UG x (xyz, projected row) gathers,
         // and only then the arithmetic -- the chain index -> gather is paid once per group instead of once per pass
         constexpr int UG = V == 1 ? (RPW >= 8 ? 4 : 8) : 2;  // K >= 16 everywhere: never more passes than rows
@@ -525,8 +551,12 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
                 ng[u] = (unsigned)min(max((int)ng[u], 0), N - 1);
                 using u32x3 = __attribute__((ext_vector_type(3))) unsigned;
                 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-                const u32x3 pn = __builtin_amdgcn_raw_buffer_load_b96(xyz_rs, (int)__umul24(ng[u], 12u), 0, 0);   // one 12-byte load (N < 2^24: launch_gather)
-                pxg[u] = __uint_as_float(pn[0]), pyg[u] = __uint_as_float(pn[1]), pzg[u] = __uint_as_float(pn[2]);
+                if (AFFINE || !FOLD) {
+                    const u32x3 pn = __builtin_amdgcn_raw_buffer_load_b96(xyz_rs, (int)__umul24(ng[u], 12u), 0, 0);   // one 12-byte load (N < 2^24: launch_gather)
+                    pxg[u] = __uint_as_float(pn[0]), pyg[u] = __uint_as_float(pn[1]), pzg[u] = __uint_as_float(pn[2]);
+                } else {
+                    pxg[u] = pyg[u] = pzg[u] = 0.f;
+                }
                 if (!AFFINE) {
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
@@ -543,18 +573,23 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 float4 p4;
-                if (AFFINE) {
-                    p4.x = fmaf(am[v][0][2], pz, fmaf(am[v][0][1], py, fmaf(am[v][0][0], px, cv[v][0])));
-                    p4.y = fmaf(am[v][1][2], pz, fmaf(am[v][1][1], py, fmaf(am[v][1][0], px, cv[v][1])));
-                    p4.z = fmaf(am[v][2][2], pz, fmaf(am[v][2][1], py, fmaf(am[v][2][0], px, cv[v][2])));
-                    p4.w = fmaf(am[v][3][2], pz, fmaf(am[v][3][1], py, fmaf(am[v][3][0], px, cv[v][3])));
+                if (AFFINE) {   // FOLD: am = A + W_r', kc = c - W_r' centre
+                    p4.x = fmaf(am[v][0][2], pz, fmaf(am[v][0][1], py, fmaf(am[v][0][0], px, FOLD ? kc[v][0] : cv[v][0])));
+                    p4.y = fmaf(am[v][1][2], pz, fmaf(am[v][1][1], py, fmaf(am[v][1][0], px, FOLD ? kc[v][1] : cv[v][1])));
+                    p4.z = fmaf(am[v][2][2], pz, fmaf(am[v][2][1], py, fmaf(am[v][2][0], px, FOLD ? kc[v][2] : cv[v][2])));
+                    p4.w = fmaf(am[v][3][2], pz, fmaf(am[v][3][1], py, fmaf(am[v][3][0], px, FOLD ? kc[v][3] : cv[v][3])));
                 } else {
                     p4 = pg[u][v];
                 }
-                y[v][0] = fmaf(wr[v][0][2], rz, fmaf(wr[v][0][1], ry, fmaf(wr[v][0][0], rx, p4.x)));
-                y[v][1] = fmaf(wr[v][1][2], rz, fmaf(wr[v][1][1], ry, fmaf(wr[v][1][0], rx, p4.y)));
-                y[v][2] = fmaf(wr[v][2][2], rz, fmaf(wr[v][2][1], ry, fmaf(wr[v][2][0], rx, p4.z)));
-                y[v][3] = fmaf(wr[v][3][2], rz, fmaf(wr[v][3][1], ry, fmaf(wr[v][3][0], rx, p4.w)));
+                if (FOLD) {
+                    if (AFFINE) y[v][0] = p4.x, y[v][1] = p4.y, y[v][2] = p4.z, y[v][3] = p4.w;
+                    else y[v][0] = p4.x - kc[v][0], y[v][1] = p4.y - kc[v][1], y[v][2] = p4.z - kc[v][2], y[v][3] = p4.w - kc[v][3];
+                } else {
+                    y[v][0] = fmaf(wr[v][0][2], rz, fmaf(wr[v][0][1], ry, fmaf(wr[v][0][0], rx, p4.x)));
+                    y[v][1] = fmaf(wr[v][1][2], rz, fmaf(wr[v][1][1], ry, fmaf(wr[v][1][0], rx, p4.y)));
+                    y[v][2] = fmaf(wr[v][2][2], rz, fmaf(wr[v][2][1], ry, fmaf(wr[v][2][0], rx, p4.z)));
+                    y[v][3] = fmaf(wr[v][3][2], rz, fmaf(wr[v][3][1], ry, fmaf(wr[v][3][0], rx, p4.w)));
+                }
                 sum += (y[v][0] + y[v][1]) + (y[v][2] + y[v][3]);
             }
             const float mean = lane_group_sum<G>(sum) * (1.0f / (float)COUT);
@@ -593,14 +628,14 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
     }
 }
 
-template <int COUT, int V, bool AFFINE>
+template <int COUT, int V, bool AFFINE, bool FOLD = false>
 int launch_gather(const float *P, const float *A, const float *cvec, const float *xyz, const float *centers,
                   const int32_t *idx, const float *Wr, int ldwr, const float *gamma, const float *beta, int B, int N,
                   int S, int K, float inv_r, float *out, hipStream_t st) {
     const long long total = (long long)B * S;
     if (total >= (1LL << 30) || N >= (1 << 24) || (long long)N * COUT * 4 >= (1LL << 31)) return DPM_EUNSUPPORTED;   // 32-bit buffer offsets
     const int cpw = total >= (1 << 16) ? 8 : (total >= (1 << 13) ? 2 : 1);  // centres per wave
-    hipLaunchKernelGGL((group_gather_ln_max_kernel<COUT, V, AFFINE>), dim3(dpm_cdiv(total, 4LL * cpw)), dim3(256), (size_t)dpm_knob("DPM_GATHER_LDS_PAD", 0), st, P,
+    hipLaunchKernelGGL((group_gather_ln_max_kernel<COUT, V, AFFINE, FOLD>), dim3(dpm_cdiv(total, 4LL * cpw)), dim3(256), (size_t)dpm_knob("DPM_GATHER_LDS_PAD", 0), st, P,
                        A, cvec, xyz, centers, idx, Wr, ldwr, gamma, beta, N, S, K, total, cpw, inv_r, out);
     return dpm_launch_status();
 }
@@ -627,6 +662,29 @@ extern "C" int dpm_group_gather_ln_max(const float *P, const float *xyz, const f
 #undef DPM_GG
 }
 
+// dpm_group_gather_ln_max for rows P' that ALREADY carry the point half of the relative-coordinate term (P' = fea W_f^T + b +
+// xyz (W_rel / radius)^T: dpm_linear_bf16x3_rank3): the kernel subtracts the centre half, (W_rel / radius) centre, and gathers no
+// coordinates.  Same contract otherwise (xyz is not read).
+extern "C" int dpm_group_gather_ln_max_folded(const float *P, const float *centers, const int32_t *idx, const float *W_rel,
+                                              int ldw_rel, const float *gamma, const float *beta, int B, int N, int S, int K,
+                                              int Cout, double radius, float *out, dpm_stream_t stream) {
+    DPM_CHECK_ARG(P && centers && idx && W_rel && gamma && beta && out);
+    DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && ldw_rel >= 3 && radius > 0.0);
+    DPM_CHECK_ARG(((uintptr_t)P & 15) == 0 && ((uintptr_t)out & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_r = 1.0f / (float)radius;
+#define DPM_GF(C, V) return launch_gather<C, V, false, true>(P, nullptr, nullptr, centers, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, inv_r, out, st)
+    switch (Cout) {
+        case 32: DPM_GF(32, 1);
+        case 64: DPM_GF(64, 1);
+        case 128: DPM_GF(128, 1);
+        case 256: DPM_GF(256, 1);
+        case 512: DPM_GF(512, 2);
+        default: return DPM_EUNSUPPORTED;
+    }
+#undef DPM_GF
+}
+
 extern "C" int dpm_group_affine_ln_max(const float *A, const float *cvec, const float *xyz, const float *centers,
                                        const int32_t *idx, const float *W_rel, int ldw_rel, const float *gamma,
                                        const float *beta, int B, int N, int S, int K, int Cout, double radius,
@@ -635,7 +693,7 @@ extern "C" int dpm_group_affine_ln_max(const float *A, const float *cvec, const 
     DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && ldw_rel >= 3 && radius > 0.0 && ((uintptr_t)out & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
     const float inv_r = 1.0f / (float)radius;
-#define DPM_GA(C, V) return launch_gather<C, V, true>(nullptr, A, cvec, xyz, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, inv_r, out, st)
+#define DPM_GA(C, V) return launch_gather<C, V, true, true>(nullptr, A, cvec, xyz, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, inv_r, out, st)
     switch (Cout) {
         case 32: DPM_GA(32, 1);
         case 64: DPM_GA(64, 1);

@@ -29,13 +29,17 @@ BF16X3_LN_MIN_K = 128  # shortest reduction a Linear + LayerNorm layer needs to 
 # registration (512 rows): 9 launches fewer, eager call 1.00 -> 0.86 ms, but the replayed graph 0.48 -> 0.61 ms (8 workgroups walking
 # K instead of 96): off.
 FUSED_LN_SMALL_ROWS = 0
+# grouping layers in the folded form (csrc/group_mlp.hip, FOLD): W_r (p - c) / r = W_r' p - W_r' c, the point half added by the
+# projection GEMM's epilogue, the centre half one vector per centre.  False: the round-4 form (the relative coordinates formed per
+# gathered row).  Moves descriptors by ~3e-6 and poses by ~5e-6 m (cancellation).
+FOLD_GATHER = True
 FUSED_PWCONV = True    # InvResMLP's pw_conv pair of the first level (C = 32) as one kernel (csrc/gemm_b3.hip, pwconv_pair_b3_kernel); False: two fused GEMM + LayerNorm kernels
 FUSED_MATCH = True     # similarity -> dual softmax -> top-k as one operator (csrc/match.hip) where it applies; False: the five-launch form
 DEDUP_FRAMES = True    # False: per-frame decoder work once per pair side instead of once per frame (new Decoder objects)
 
 _ENV = {"DPM_FPS_ALGO": ("FPS_ALGO", int), "DPM_NO_FUSED_LN": ("FUSED_LN", lambda v: v != "1"),
         "DPM_DEDUP_FRAMES": ("DEDUP_FRAMES", lambda v: v != "0"), "DPM_GEMM_BF16X3": ("GEMM_BF16X3", lambda v: v == "1"), "DPM_BF16X3_MAX_K": ("BF16X3_MAX_K", int), "DPM_BF16X3_LN_MIN_K": ("BF16X3_LN_MIN_K", int), "DPM_FUSED_LN_SMALL_ROWS": ("FUSED_LN_SMALL_ROWS", int), "DPM_GEMM_LN_BF16X3": ("GEMM_LN_BF16X3", lambda v: v == "1"),
-        "DPM_FUSED_MATCH": ("FUSED_MATCH", lambda v: v != "0"), "DPM_FUSED_PWCONV": ("FUSED_PWCONV", lambda v: v != "0")}
+        "DPM_FUSED_MATCH": ("FUSED_MATCH", lambda v: v != "0"), "DPM_FUSED_PWCONV": ("FUSED_PWCONV", lambda v: v != "0"), "DPM_FOLD_GATHER": ("FOLD_GATHER", lambda v: v != "0")}
 
 
 def env_knobs() -> dict:

@@ -338,6 +338,17 @@ def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, g
         W2 = W.reshape(Cout, Cin + 3)
         # a packed copy of the feature columns (rows of the Conv2d weight are Cin+3 floats: not 16-byte aligned)
         Wf = _derived("feature-columns", (W,), lambda: W2[:, :Cin].contiguous())
+        if knobs.FOLD_GATHER and knobs.GEMM_BF16X3 and Cin % 32 == 0 and Cin <= knobs.BF16X3_MAX_K:
+            # folded form (csrc/group_mlp.hip, FOLD): the projection's epilogue adds the POINT half of the relative-coordinate
+            # term, the gather subtracts the centre half and reads no coordinates.  A property of the layer (its widths and the
+            # tensors' layout class), never of the row count.
+            P = linear_bf16x3(fea.reshape(B * N, Cin), Wf, bias,
+                              rank3=(xyz.reshape(B * N, 3), W2.data_ptr() + 4 * Cin, Cin + 3, 1.0 / float(radius)))
+            if P is not None:
+                _lib.check(lib.dpm_group_gather_ln_max_folded(_ptr(P), _ptr(centers), _ptr(idx), W2.data_ptr() + 4 * Cin, Cin + 3,
+                                                              _ptr(gamma), _ptr(beta), B, N, S, K, Cout, float(radius), _ptr(out),
+                                                              _stream(fea)), "dpm_group_gather_ln_max_folded")
+                return out
         P = linear(fea.reshape(B * N, Cin), Wf, bias)
         _lib.check(lib.dpm_group_gather_ln_max(_ptr(P), _ptr(xyz), _ptr(centers), _ptr(idx), W2.data_ptr() + 4 * Cin,
                                                Cin + 3, _ptr(gamma), _ptr(beta), B, N, S, K, Cout, float(radius),
@@ -449,7 +460,7 @@ def _weight_planes(W: torch.Tensor):
 
 
 def linear_bf16x3(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-                  residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                  residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, rank3=None) -> Optional[torch.Tensor]:
     """linear() on the bf16 matrix pipe: every fp32 operand split exactly into three bf16 terms, six term products
     accumulated in fp32 (csrc/gemm_b3.hip; fp32-accumulation accuracy, not the fp32 kernel's bits).  Returns None when the
     shape / layout is not covered (the caller runs linear())."""
@@ -472,9 +483,20 @@ def linear_bf16x3(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
     if residual is not None:
         r2 = residual.reshape(-1, Cout)
         _chk(r2, torch.float32, "residual")
-    st = _lib.load().dpm_linear_bf16x3(_ptr(x2), x2.stride(0), planes.data_ptr() + 2 * off, Cin, n, _ptr(bias), _ptr(r2),
-                                       Cout if r2 is not None else 0, _ptr(o2), o2.stride(0), x2.shape[0], Cin, Cout, act,
-                                       _stream(x))
+    if rank3 is not None:
+        # rank3 = (x3 (R,3) contiguous fp32, address of w3[0, 0], its row stride in floats, scale): out += scale * x3 w3^T in the
+        # epilogue (the point half of a grouping layer's relative-coordinate term: group_mlp_max)
+        x3, w3_ptr, ldw3, scale = rank3
+        _chk(x3, torch.float32, "x3")
+        if tuple(x3.shape) != (x2.shape[0], 3):
+            raise ValueError("rank3 rows must be (R, 3)")
+        st = _lib.load().dpm_linear_bf16x3_rank3(_ptr(x2), x2.stride(0), planes.data_ptr() + 2 * off, Cin, n, _ptr(bias), _ptr(r2),
+                                                 Cout if r2 is not None else 0, _ptr(o2), o2.stride(0), x2.shape[0], Cin, Cout, act,
+                                                 _ptr(x3), ctypes.c_void_p(w3_ptr), int(ldw3), float(scale), _stream(x))
+    else:
+        st = _lib.load().dpm_linear_bf16x3(_ptr(x2), x2.stride(0), planes.data_ptr() + 2 * off, Cin, n, _ptr(bias), _ptr(r2),
+                                           Cout if r2 is not None else 0, _ptr(o2), o2.stride(0), x2.shape[0], Cin, Cout, act,
+                                           _stream(x))
     if st == -2:
         return None
     _lib.check(st, "dpm_linear_bf16x3")

@@ -213,6 +213,16 @@ int dpm_group_affine_ln_max(const float *A, const float *cvec, const float *xyz,
                             const int32_t *idx, const float *W_rel, int ldw_rel, const float *gamma,
                             const float *beta, int B, int N, int S, int K, int Cout, double radius, float *out,
                             dpm_stream_t stream);
+/* The folded form of dpm_group_gather_ln_max (round 5): the relative-coordinate term W_rel (p - c) / radius is linear in the point
+ * and in the centre separately, so P' = P + xyz (W_rel / radius)^T is made once per point by the projection's epilogue
+ * (dpm_linear_bf16x3_rank3) and this kernel computes out[b,s,:] = max_k relu(LN(P'[idx[b,s,k]] - (W_rel / radius) center)):
+ * four subtractions instead of fifteen operations per gathered row and lane, no coordinates gathered.  Same shapes and alignment
+ * as dpm_group_gather_ln_max.  |W_rel p / radius| exceeds the term it replaces by up to |p| / radius, so the pre-LayerNorm values
+ * carry ~1e-6 relative rounding error instead of ~1e-7 (DESIGN.md section 4 has the measured effect on descriptors and poses).
+ * dpm_group_affine_ln_max folds the same way internally (A + W_rel / radius). */
+int dpm_group_gather_ln_max_folded(const float *P, const float *centers, const int32_t *idx, const float *W_rel, int ldw_rel,
+                                   const float *gamma, const float *beta, int B, int N, int S, int K, int Cout, double radius,
+                                   float *out, dpm_stream_t stream);
 
 /* 1x1 Conv1d / nn.Linear (build_mlp, network/encoder/utils.py:358-389; decoder heads):
  * out[r, :Cout] = act(x[r,:Cin] W^T + bias + residual[r]); W (Cout,Cin) row-major with leading
@@ -315,6 +325,13 @@ int dpm_split_bf16x3(const float *W, long long n, void *planes, dpm_stream_t str
 int dpm_linear_bf16x3(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride, const float *bias,
                       const float *residual, int ldr, float *out, int ldo, int R, int Cin, int Cout, int act,
                       dpm_stream_t stream);
+/* dpm_linear_bf16x3 plus a rank-3 term added in fp32 in the epilogue, before residual and activation:
+ * out[r, c] += scale * (x3[r, 0:3] . w3[c, 0:3]), x3 (R,3) packed, w3 rows ldw3 floats apart.  It is the POINT half of a grouping
+ * layer's relative-coordinate columns (network/encoder/pointnext.py:52-56: W [fea ; (p - c) / r] = W_f fea + W_r p / r - W_r c / r),
+ * with x3 = the points' coordinates, w3 = W_r, scale = 1 / r; dpm_group_gather_ln_max_folded subtracts the centre half. */
+int dpm_linear_bf16x3_rank3(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride, const float *bias,
+                            const float *residual, int ldr, float *out, int ldo, int R, int Cin, int Cout, int act,
+                            const float *x3, const float *w3, int ldw3, double scale, dpm_stream_t stream);
 /* dpm_linear_layernorm (Conv1d(k=1) / Linear + LayerNorm1d, network/encoder/utils.py:358-413, descriptor_attention.py:36-48)
  * on the bf16x3 product, weights as planes of dpm_split_bf16x3; rows identical to dpm_linear_bf16x3 followed by dpm_layernorm.
  * DPM_EUNSUPPORTED for Cout outside {32, 64, 128, 256}, Cin % 32 != 0 or unaligned operands. */

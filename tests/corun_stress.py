@@ -61,10 +61,29 @@ def _victims(dev):
             return out
         return call
 
+    def folded_gather(C, K, radius, seed):
+        """group_gather_ln_max_kernel<C, V, false, FOLD>: the form the encoder runs (rows that carry the point half of the
+        relative-coordinate term; the kernel subtracts the centre half)"""
+        g = torch.Generator().manual_seed(seed)
+        P = torch.randn(B, S, C, generator=g).to(dev)
+        Wr = (torch.randn(C, 3, generator=g) / 3).to(dev)
+        gm, bt = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+        idx = ops.knn_hybrid(cen, clen, cen, K, radius)
+
+        def call():
+            out = torch.empty(B, S, C, device=dev)
+            _lib.check(lib.dpm_group_gather_ln_max_folded(P.data_ptr(), cen.data_ptr(), idx.data_ptr(), Wr.data_ptr(), 3, gm.data_ptr(),
+                                                          bt.data_ptr(), B, S, S, K, C, float(radius), out.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream), "dpm_group_gather_ln_max_folded")
+            return out
+        return call
+
     small_xyz, small_len = xyz[:1, :8192].contiguous(), torch.full((1,), 8192, device=dev, dtype=torch.int32)
     return {
         "gather affine <32> (stage-0 SetAbstraction)": lambda: ops.group_mlp_max_from_xyz(xyz, *sa, 0.05),
         "gather <32> (LocalAggregation)": plain_gather(32, 32, 0.1, 1),
+        "gather folded <32>": folded_gather(32, 32, 0.1, 6),
+        "gather folded <128>": folded_gather(128, 32, 0.2, 7),
         "gather <64>": plain_gather(64, 32, 0.1, 2),
         "gather <128>": plain_gather(128, 32, 0.2, 3),
         "gather <256>, 16 neighbours": plain_gather(256, 16, 0.2, 4),

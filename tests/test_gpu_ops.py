@@ -498,6 +498,42 @@ def test_group_mlp_from_xyz_equals_materialised_features(ops):
         torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
+def test_folded_grouping_layers_against_the_unfolded_form(ops, monkeypatch):
+    """knobs.FOLD_GATHER (csrc/group_mlp.hip, FOLD): W_r (p - c) / r as W_r' p - W_r' c -- the point half in the projection
+    GEMM's epilogue (dpm_linear_bf16x3_rank3), the centre half one vector per centre -- against the form that builds the relative
+    coordinates per gathered row, at every width the encoder uses, first-level radius included (|p| / r = 20: the worst
+    cancellation), and against the plain-VALU kernel.  The two forms differ by rounding only."""
+    from deeppointmap_amd import knobs
+    gen = torch.Generator().manual_seed(41)
+    d = lambda t: t.to(DEV)
+    for Cin, Cout, K, radius in ((32, 32, 32, 0.05), (32, 64, 32, 0.1), (64, 128, 32, 0.2), (128, 256, 32, 0.4), (256, 512, 16, 0.8)):
+        B, N, S = 2, 3000, 400
+        xyz = d(torch.rand(B, N, 3, generator=gen) * 2 - 1)                      # coordinates in the unit box, as the encoder's
+        fea = d(torch.randn(B, N, Cin, generator=gen))
+        ctr = xyz[:, :S].contiguous()
+        idx = d(torch.randint(0, N, (B, S, K), generator=gen).int())
+        W = d(torch.randn(Cout, Cin + 3, 1, 1, generator=gen) / (Cin + 3) ** 0.5)
+        bias, gm, bt = d(0.1 * torch.randn(Cout, generator=gen)), d(1 + 0.1 * torch.randn(Cout, generator=gen)), d(0.1 * torch.randn(Cout, generator=gen))
+        monkeypatch.setattr(knobs, "FOLD_GATHER", True)
+        folded = ops.group_mlp_max(xyz, fea, ctr, idx, W, bias, gm, bt, radius)
+        monkeypatch.setattr(knobs, "FOLD_GATHER", False)
+        plain = ops.group_mlp_max(xyz, fea, ctr, idx, W, bias, gm, bt, radius)
+        generic = ops.group_mlp_max(xyz, fea, ctr, idx, W, bias, gm, bt, radius, generic=True)
+        assert not torch.equal(folded, plain)                                      # (two different kernels ran)
+        torch.testing.assert_close(folded, plain, rtol=0, atol=2e-5)
+        torch.testing.assert_close(folded, generic, rtol=1e-4, atol=1e-4)
+    # the affine first level folds inside its kernel: against the per-neighbour feature evaluation
+    B, N, S, K = 2, 5000, 600, 32
+    xyz = d(torch.rand(B, N, 3, generator=gen) * 2 - 1)
+    ctr, idx = xyz[:, :S].contiguous(), d(torch.randint(0, N, (B, S, K), generator=gen).int())
+    W0, b0 = d(torch.randn(16, 3, 1, generator=gen)), d(0.1 * torch.randn(16, generator=gen))
+    W = d(torch.randn(32, 19, 1, 1, generator=gen) / 19 ** 0.5)
+    bias, gm, bt = d(0.1 * torch.randn(32, generator=gen)), d(1 + 0.1 * torch.randn(32, generator=gen)), d(0.1 * torch.randn(32, generator=gen))
+    a = ops.group_mlp_max_from_xyz(xyz, W0, b0, ctr, idx, W, bias, gm, bt, 0.05)
+    b = ops.group_mlp_max_from_xyz(xyz, W0, b0, ctr, idx, W, bias, gm, bt, 0.05, fused=True)
+    torch.testing.assert_close(a, b, rtol=0, atol=5e-5)
+
+
 def test_weight_derived_tensors_follow_the_weights(ops):
     """ops caches what depends on weights alone (packed feature columns, the stage-0 affine map).  In-place updates,
     and a new weight tensor that lands on a freed one's address, must both be seen."""
