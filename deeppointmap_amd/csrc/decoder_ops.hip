@@ -100,7 +100,7 @@ __device__ __forceinline__ float rows4_sum(float v) {
 // tiles each).  The keys are cut into `nsplit` ranges of whole tiles, gridDim.x = query tiles x nsplit; a block writes its
 // range's UNNORMALISED output rows (relative to its own running max) into part_o (nsplit, B, M, heads*HD) and
 // (max, sum) into part_ml (nsplit, B, heads, M, 2); attention_merge_kernel rescales and adds the ranges.
-template <bool VEC, int QT, bool MASK = false, bool SPLIT = false>
+template <bool VEC, int QT, bool MASK = false, bool SPLIT = false, int NWV = 4>
 #ifndef DPM_ATT_WAVES
 #define DPM_ATT_WAVES 0
 #endif
@@ -109,7 +109,7 @@ template <bool VEC, int QT, bool MASK = false, bool SPLIT = false>
 #else
 #define DPM_ATT_OCC
 #endif
-__global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
+__global__ __launch_bounds__(64 * NWV) DPM_ATT_OCC void attention_kernel(const float *__restrict__ Q, int ldq, long long sq,
                                                         const float *__restrict__ Kp, int ldk, long long sk,
                                                         const float *__restrict__ V, int ldv, long long sv,
                                                         float *__restrict__ O, int ldo, long long so, int M,
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
     const int b = bid / (gridDim.x * gridDim.y), h = (bid / gridDim.x) % gridDim.y;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4;
     const int qtiles = SPLIT ? gridDim.x / nsplit : gridDim.x, split = SPLIT ? (bid % gridDim.x) / qtiles : 0;
-    const int q0 = ((bid % gridDim.x) % qtiles) * (64 * QT) + w * (16 * QT);
+    const int q0 = ((bid % gridDim.x) % qtiles) * (16 * NWV * QT) + w * (16 * QT);
     // key range of this block: whole tiles, the same count for every range but the last
     const int chunk = SPLIT ? ((N + TK * nsplit - 1) / (TK * nsplit)) * TK : N;
     const int n_begin = split * chunk, n_end = SPLIT ? min(N, n_begin + chunk) : N;
@@ -182,11 +182,12 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
     // K / V tiles: 64 rows x 32 floats each = 512 float4 per matrix, 2 per thread.  The next tile is fetched into
     // registers (branch-free: rows beyond N re-read the last key; their scores are masked to -inf below, so the
     // probabilities that multiply those V rows are exactly 0) while the current one feeds the MFMAs.
-    float4 kreg[2], vreg[2];
+    constexpr int PT = 512 / (64 * NWV);  // float4 per thread and matrix
+    float4 kreg[PT], vreg[PT];
     auto fetch = [&](int n0) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int e = t + p * 256, kr = min(n0 + (e >> 3), N - 1), c4 = (e & 7) * 4;
+        for (int p = 0; p < PT; ++p) {
+            const int e = t + p * (64 * NWV), kr = min(n0 + (e >> 3), N - 1), c4 = (e & 7) * 4;
             const float *kp = Kb + (size_t)kr * ldk + c4, *vp = Vb + (size_t)kr * ldv + c4;
             if (VEC) {
                 kreg[p] = *reinterpret_cast<const float4 *>(kp), vreg[p] = *reinterpret_cast<const float4 *>(vp);
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(256) DPM_ATT_OCC void attention_kernel(const float 
     for (int n0 = n_begin; n0 < n_end; n0 += TK) {
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int e = t + p * 256, kr = e >> 3, c4 = (e & 7) * 4;
+        for (int p = 0; p < PT; ++p) {
+            const int e = t + p * (64 * NWV), kr = e >> 3, c4 = (e & 7) * 4;
             unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
             split3(kreg[p].x, h0, m0, l0), split3(kreg[p].y, h1, m1, l1), split3(kreg[p].z, h2, m2, l2), split3(kreg[p].w, h3, m3, l3);
             *reinterpret_cast<u32x2 *>(&Ks3[0][kr][b3_col(kr, c4)]) = u32x2{pack2(h0, h1), pack2(h2, h3)};
@@ -1374,6 +1375,22 @@ static int attention_launch(const float *Q, int ldq, long long sq, const float *
         else
             hipLaunchKernelGGL((attention_kernel<false, 1, true>), dim3(dpm_cdiv(M, 64), heads, B), dim3(256), 0, (hipStream_t)stream,
                                Q, ldq, sq, K, ldk, sk, V, ldv, sv, out, ldo, so, M, N, scale, kv_shift, key_mask);
+        return dpm_launch_status();
+    }
+#ifndef DPM_ATT_BLOCK8
+#define DPM_ATT_BLOCK8 1
+#endif
+#ifndef DPM_ATT_BLOCK8_MIN_M
+#define DPM_ATT_BLOCK8_MIN_M 1024
+#endif
+    // Eight waves per workgroup (128 queries): a K / V tile is fetched, split and staged once per 128 queries instead of 64.
+    // Alone it wins at every size (128 x 256 x 256: 65.4 -> 61.0 us; 2 x 4096 x 4096: 264 -> 233 us); in the pipelined step,
+    // where the 256-token sequences run between the other stages' workgroups, 512-thread workgroups find their place later
+    // and the step is 1.6 % LONGER (4.04 / 4.03 / 4.05 -> 4.09 / 4.12 / 4.11 ms).  So: map-sized query sets only (the
+    // rank-0 registrations against a map tile run alone on their stream).
+    if (DPM_ATT_BLOCK8 && vec && !wide && M % 128 == 0 && M >= DPM_ATT_BLOCK8_MIN_M) {
+        hipLaunchKernelGGL((attention_kernel<true, 1, false, false, 8>), dim3(M / 128, heads, B), dim3(512), 0, (hipStream_t)stream,
+                           Q, ldq, sq, K, ldk, sk, V, ldv, sv, out, ldo, so, M, N, scale, kv_shift, nullptr, 1, nullptr, nullptr, seq);
         return dpm_launch_status();
     }
     if (vec && wide) DPM_ATT(true, 2);
