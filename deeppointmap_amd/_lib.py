@@ -52,6 +52,8 @@ SIGNATURES = {
     "dpm_group_gather_ln_max": (I, [P, P, P, P, P, I, P, P, I, I, I, I, I, D, P, P]),
     "dpm_group_gather_ln_max_folded": (I, [P, P, P, P, I, P, P, I, I, I, I, I, D, P, P]),
     "dpm_group_affine_ln_max": (I, [P, P, P, P, P, P, I, P, P, I, I, I, I, I, D, P, P]),
+    "dpm_group_gather_ln_max_centred": (I, [P, P, P, P, I, P, P, I, I, I, I, I, D, P, P]),
+    "dpm_group_affine_ln_max_centred": (I, [P, P, P, P, P, P, I, P, P, I, I, I, I, I, D, P, P]),
     "dpm_linear": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
     "dpm_linear_batched": (I, [P, I, LL, P, I, LL, P, P, I, LL, P, I, LL, I, I, I, I, I, P]),
     "dpm_split_bf16x3": (I, [P, LL, P, P]),

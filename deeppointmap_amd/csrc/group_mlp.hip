@@ -473,7 +473,11 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {
 // projected path gathers no coordinates at all.  The price is cancellation: |W_r' p| is up to |p| / r (20 at the first level)
 // times the term it replaces, i.e. a rounding error of ~1e-6 relative instead of ~1e-7 on the pre-LayerNorm values; measured on
 // the oracle with this arithmetic: descriptors move by 3.3e-6, poses by 4-5e-6 m, inlier counts unchanged.
-template <int COUT, int V, bool AFFINE, bool FOLD = false>
+// CENTRED (round 5, with FOLD): the caller has moved LayerNorm's mean removal into the layer -- (I - 11^T / C) applied to W_f, W_r,
+// the bias (and, AFFINE, to the point map and its constant), so that every pre-LayerNorm row has zero mean over its channels by
+// construction: the row sum, its lane-group reduction and the subtraction (about a third of the instructions per gathered row)
+// are not executed.  What is left of the mean is the rounding of the row's own elements (~1e-7 of their magnitude / sqrt(C)).
+template <int COUT, int V, bool AFFINE, bool FOLD = false, bool CENTRED = false>
 __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
     const float *__restrict__ P_all, const float *__restrict__ A, const float *__restrict__ cvec,
     const float *__restrict__ xyz_all, const float *__restrict__ ctr_all, const int32_t *__restrict__ idx_all,
@@ -590,15 +594,16 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
                     y[v][2] = fmaf(wr[v][2][2], rz, fmaf(wr[v][2][1], ry, fmaf(wr[v][2][0], rx, p4.z)));
                     y[v][3] = fmaf(wr[v][3][2], rz, fmaf(wr[v][3][1], ry, fmaf(wr[v][3][0], rx, p4.w)));
                 }
-                sum += (y[v][0] + y[v][1]) + (y[v][2] + y[v][3]);
+                if (!CENTRED) sum += (y[v][0] + y[v][1]) + (y[v][2] + y[v][3]);
             }
-            const float mean = lane_group_sum<G>(sum) * (1.0f / (float)COUT);
+            float mean = 0.f;
+            if (!CENTRED) mean = lane_group_sum<G>(sum) * (1.0f / (float)COUT);
             float sq = 0.f;
 #pragma unroll
             for (int v = 0; v < V; ++v)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    y[v][e] -= mean;
+                    if (!CENTRED) y[v][e] -= mean;
                     sq = fmaf(y[v][e], y[v][e], sq);
                 }
             // var + eps >= 1e-5 is a normal number: the bare v_rsq_f32 (what rsqrtf issues after its denormal scaling)
@@ -628,14 +633,15 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
     }
 }
 
-template <int COUT, int V, bool AFFINE, bool FOLD = false>
+template <int COUT, int V, bool AFFINE, bool FOLD = false, bool CENTRED = false>
 int launch_gather(const float *P, const float *A, const float *cvec, const float *xyz, const float *centers,
                   const int32_t *idx, const float *Wr, int ldwr, const float *gamma, const float *beta, int B, int N,
                   int S, int K, float inv_r, float *out, hipStream_t st) {
     const long long total = (long long)B * S;
     if (total >= (1LL << 30) || N >= (1 << 24) || (long long)N * COUT * 4 >= (1LL << 31)) return DPM_EUNSUPPORTED;   // 32-bit buffer offsets
     const int cpw = total >= (1 << 16) ? 8 : (total >= (1 << 13) ? 2 : 1);  // centres per wave
-    hipLaunchKernelGGL((group_gather_ln_max_kernel<COUT, V, AFFINE, FOLD>), dim3(dpm_cdiv(total, 4LL * cpw)), dim3(256), (size_t)dpm_knob("DPM_GATHER_LDS_PAD", 0), st, P,
+    static_assert(FOLD || !CENTRED, "the centred form is a folded form");
+    hipLaunchKernelGGL((group_gather_ln_max_kernel<COUT, V, AFFINE, FOLD, CENTRED>), dim3(dpm_cdiv(total, 4LL * cpw)), dim3(256), (size_t)dpm_knob("DPM_GATHER_LDS_PAD", 0), st, P,
                        A, cvec, xyz, centers, idx, Wr, ldwr, gamma, beta, N, S, K, total, cpw, inv_r, out);
     return dpm_launch_status();
 }
@@ -665,15 +671,17 @@ extern "C" int dpm_group_gather_ln_max(const float *P, const float *xyz, const f
 // dpm_group_gather_ln_max for rows P' that ALREADY carry the point half of the relative-coordinate term (P' = fea W_f^T + b +
 // xyz (W_rel / radius)^T: dpm_linear_bf16x3_rank3): the kernel subtracts the centre half, (W_rel / radius) centre, and gathers no
 // coordinates.  Same contract otherwise (xyz is not read).
-extern "C" int dpm_group_gather_ln_max_folded(const float *P, const float *centers, const int32_t *idx, const float *W_rel,
-                                              int ldw_rel, const float *gamma, const float *beta, int B, int N, int S, int K,
-                                              int Cout, double radius, float *out, dpm_stream_t stream) {
+static int gather_folded(const float *P, const float *centers, const int32_t *idx, const float *W_rel, int ldw_rel,
+                         const float *gamma, const float *beta, int B, int N, int S, int K, int Cout, double radius, float *out,
+                         dpm_stream_t stream, bool centred) {
     DPM_CHECK_ARG(P && centers && idx && W_rel && gamma && beta && out);
     DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && ldw_rel >= 3 && radius > 0.0);
     DPM_CHECK_ARG(((uintptr_t)P & 15) == 0 && ((uintptr_t)out & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
     const float inv_r = 1.0f / (float)radius;
-#define DPM_GF(C, V) return launch_gather<C, V, false, true>(P, nullptr, nullptr, centers, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, inv_r, out, st)
+#define DPM_GF(C, V)                                                                                                              \
+    return centred ? launch_gather<C, V, false, true, true>(P, nullptr, nullptr, centers, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, inv_r, out, st) \
+                   : launch_gather<C, V, false, true>(P, nullptr, nullptr, centers, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, inv_r, out, st)
     switch (Cout) {
         case 32: DPM_GF(32, 1);
         case 64: DPM_GF(64, 1);
@@ -685,15 +693,32 @@ extern "C" int dpm_group_gather_ln_max_folded(const float *P, const float *cente
 #undef DPM_GF
 }
 
-extern "C" int dpm_group_affine_ln_max(const float *A, const float *cvec, const float *xyz, const float *centers,
-                                       const int32_t *idx, const float *W_rel, int ldw_rel, const float *gamma,
-                                       const float *beta, int B, int N, int S, int K, int Cout, double radius,
-                                       float *out, dpm_stream_t stream) {
+extern "C" int dpm_group_gather_ln_max_folded(const float *P, const float *centers, const int32_t *idx, const float *W_rel,
+                                              int ldw_rel, const float *gamma, const float *beta, int B, int N, int S, int K,
+                                              int Cout, double radius, float *out, dpm_stream_t stream) {
+    return gather_folded(P, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, Cout, radius, out, stream, false);
+}
+
+// dpm_group_gather_ln_max_folded for a layer whose mean removal sits in its weights: the caller PROMISES that every column of
+// [W_f | W_rel] and the bias have zero mean over the Cout output channels (W' = (I - 11^T / Cout) W), so that the rows of P and
+// the centre term have zero mean over their channels; the kernel then computes LayerNorm's variance from the rows as they are.
+// With weights that do not keep the promise the result is LayerNorm without its mean removal.
+extern "C" int dpm_group_gather_ln_max_centred(const float *P, const float *centers, const int32_t *idx, const float *W_rel,
+                                               int ldw_rel, const float *gamma, const float *beta, int B, int N, int S, int K,
+                                               int Cout, double radius, float *out, dpm_stream_t stream) {
+    return gather_folded(P, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, Cout, radius, out, stream, true);
+}
+
+static int gather_affine(const float *A, const float *cvec, const float *xyz, const float *centers, const int32_t *idx,
+                         const float *W_rel, int ldw_rel, const float *gamma, const float *beta, int B, int N, int S, int K,
+                         int Cout, double radius, float *out, dpm_stream_t stream, bool centred) {
     DPM_CHECK_ARG(A && cvec && xyz && centers && idx && W_rel && gamma && beta && out);
     DPM_CHECK_ARG(B >= 1 && N >= 1 && S >= 1 && K >= 1 && ldw_rel >= 3 && radius > 0.0 && ((uintptr_t)out & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
     const float inv_r = 1.0f / (float)radius;
-#define DPM_GA(C, V) return launch_gather<C, V, true, true>(nullptr, A, cvec, xyz, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, inv_r, out, st)
+#define DPM_GA(C, V)                                                                                                              \
+    return centred ? launch_gather<C, V, true, true, true>(nullptr, A, cvec, xyz, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, inv_r, out, st) \
+                   : launch_gather<C, V, true, true>(nullptr, A, cvec, xyz, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, inv_r, out, st)
     switch (Cout) {
         case 32: DPM_GA(32, 1);
         case 64: DPM_GA(64, 1);
@@ -701,6 +726,22 @@ extern "C" int dpm_group_affine_ln_max(const float *A, const float *cvec, const 
         default: return DPM_EUNSUPPORTED;
     }
 #undef DPM_GA
+}
+
+extern "C" int dpm_group_affine_ln_max(const float *A, const float *cvec, const float *xyz, const float *centers,
+                                       const int32_t *idx, const float *W_rel, int ldw_rel, const float *gamma,
+                                       const float *beta, int B, int N, int S, int K, int Cout, double radius,
+                                       float *out, dpm_stream_t stream) {
+    return gather_affine(A, cvec, xyz, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, Cout, radius, out, stream, false);
+}
+
+// dpm_group_affine_ln_max with the mean removal in the layer (see dpm_group_gather_ln_max_centred): the columns of A and of
+// W_rel and the vector cvec have zero mean over the Cout channels.
+extern "C" int dpm_group_affine_ln_max_centred(const float *A, const float *cvec, const float *xyz, const float *centers,
+                                               const int32_t *idx, const float *W_rel, int ldw_rel, const float *gamma,
+                                               const float *beta, int B, int N, int S, int K, int Cout, double radius,
+                                               float *out, dpm_stream_t stream) {
+    return gather_affine(A, cvec, xyz, centers, idx, W_rel, ldw_rel, gamma, beta, B, N, S, K, Cout, radius, out, stream, true);
 }
 
 // defined in encoder_ops.hip: generic VALU kernel for shapes the MFMA kernel does not cover

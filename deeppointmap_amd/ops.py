@@ -317,6 +317,18 @@ def _derived(tag: str, sources, make):
         return value
 
 
+def _centre_rows(M: torch.Tensor) -> torch.Tensor:
+    """(Cout, n) -> the same with every column's mean over the Cout rows removed (fp64 arithmetic, fp32 result, contiguous)"""
+    Md = M.double()
+    return (Md - Md.mean(0, keepdim=True)).float().contiguous()
+
+
+def _centred_layer(W2: torch.Tensor, bias: torch.Tensor, Cin: int):
+    """(I - 11^T / Cout) applied to a grouping layer: -> (W_f (Cout,Cin), W_r (Cout,3), bias (Cout)), zero mean over Cout"""
+    Wc = _centre_rows(W2)
+    return Wc[:, :Cin].contiguous(), Wc[:, Cin:].contiguous(), _centre_rows(bias.reshape(-1, 1)).reshape(-1)
+
+
 def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, generic: bool = False,
                   fused: bool = False) -> torch.Tensor:
     """xyz (B,N,3), fea (B,N,Cin), centers (B,S,3), idx (B,S,K), W (Cout,Cin+3[,1,1]) -> (B,S,Cout).
@@ -342,6 +354,16 @@ def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, g
             # folded form (csrc/group_mlp.hip, FOLD): the projection's epilogue adds the POINT half of the relative-coordinate
             # term, the gather subtracts the centre half and reads no coordinates.  A property of the layer (its widths and the
             # tensors' layout class), never of the row count.
+            if knobs.CENTRED_GATHER:
+                # LayerNorm's mean removal moved into the layer: (I - 11^T / Cout) applied to the weight and the bias (fp64, once per
+                # weight version), every projected row and centre term then has zero mean over its channels by construction
+                Wfc, Wrc, bc = _derived("centred-layer", (W, bias), lambda: _centred_layer(W2, bias, Cin))
+                P = linear_bf16x3(fea.reshape(B * N, Cin), Wfc, bc, rank3=(xyz.reshape(B * N, 3), Wrc.data_ptr(), 3, 1.0 / float(radius)))
+                if P is not None:
+                    _lib.check(lib.dpm_group_gather_ln_max_centred(_ptr(P), _ptr(centers), _ptr(idx), _ptr(Wrc), 3, _ptr(gamma), _ptr(beta),
+                                                                   B, N, S, K, Cout, float(radius), _ptr(out), _stream(fea)),
+                               "dpm_group_gather_ln_max_centred")
+                    return out
             P = linear_bf16x3(fea.reshape(B * N, Cin), Wf, bias,
                               rank3=(xyz.reshape(B * N, 3), W2.data_ptr() + 4 * Cin, Cin + 3, 1.0 / float(radius)))
             if P is not None:
@@ -383,6 +405,13 @@ def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radi
         A, cvec = _derived("affine-stage0", (W, W0, b0, bias), lambda: (
             linear(W2[:, :Cin], W0.reshape(Cin, 3).t().contiguous(), exact=True),                     # (Cout,3) = W_f W0
             linear(W2[:, :Cin], b0.reshape(1, Cin), residual=bias.reshape(Cout, 1), exact=True)))     # (Cout,1) = W_f b0 + b
+        if knobs.CENTRED_GATHER and knobs.FOLD_GATHER:
+            Ac, cc, Wrc = _derived("affine-stage0-centred", (W, W0, b0, bias), lambda: (
+                _centre_rows(A), _centre_rows(cvec.reshape(Cout, 1)).reshape(Cout), _centre_rows(W2[:, Cin:])))
+            _lib.check(_lib.load().dpm_group_affine_ln_max_centred(_ptr(Ac), _ptr(cc), _ptr(xyz), _ptr(centers), _ptr(idx), _ptr(Wrc), 3,
+                                                                   _ptr(gamma), _ptr(beta), B, N, S, K, Cout, float(radius),
+                                                                   _ptr(out), _stream(xyz)), "dpm_group_affine_ln_max_centred")
+            return out
         _lib.check(_lib.load().dpm_group_affine_ln_max(_ptr(A), _ptr(cvec), _ptr(xyz), _ptr(centers), _ptr(idx),
                                                        W2.data_ptr() + 4 * Cin, Cin + 3, _ptr(gamma), _ptr(beta), B, N, S,
                                                        K, Cout, float(radius), _ptr(out), _stream(xyz)),

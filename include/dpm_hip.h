@@ -223,6 +223,19 @@ int dpm_group_affine_ln_max(const float *A, const float *cvec, const float *xyz,
 int dpm_group_gather_ln_max_folded(const float *P, const float *centers, const int32_t *idx, const float *W_rel, int ldw_rel,
                                    const float *gamma, const float *beta, int B, int N, int S, int K, int Cout, double radius,
                                    float *out, dpm_stream_t stream);
+/* The folded forms for a layer whose LayerNorm mean removal has been moved into its weights (round 5): the caller passes
+ * W' = (I - 11^T / Cout) W -- every column of [W_f | W_rel], the bias, and for the affine form the columns of A and the vector
+ * cvec, have zero mean over the Cout output channels -- so that every pre-LayerNorm row (network/encoder/pointnext.py:52-61: the
+ * grouped features after the 1x1 Conv2d) has zero mean by construction and the kernels compute the variance from the rows as they
+ * are (no row sum, no subtraction: about a third of the per-row instructions).  PRECONDITION, not checked: with other weights the
+ * result is a LayerNorm without its mean removal.  Otherwise as dpm_group_gather_ln_max_folded / dpm_group_affine_ln_max. */
+int dpm_group_gather_ln_max_centred(const float *P, const float *centers, const int32_t *idx, const float *W_rel, int ldw_rel,
+                                    const float *gamma, const float *beta, int B, int N, int S, int K, int Cout, double radius,
+                                    float *out, dpm_stream_t stream);
+int dpm_group_affine_ln_max_centred(const float *A, const float *cvec, const float *xyz, const float *centers,
+                                    const int32_t *idx, const float *W_rel, int ldw_rel, const float *gamma,
+                                    const float *beta, int B, int N, int S, int K, int Cout, double radius, float *out,
+                                    dpm_stream_t stream);
 
 /* 1x1 Conv1d / nn.Linear (build_mlp, network/encoder/utils.py:358-389; decoder heads):
  * out[r, :Cout] = act(x[r,:Cin] W^T + bias + residual[r]); W (Cout,Cin) row-major with leading

@@ -61,20 +61,23 @@ def _victims(dev):
             return out
         return call
 
-    def folded_gather(C, K, radius, seed):
-        """group_gather_ln_max_kernel<C, V, false, FOLD>: the form the encoder runs (rows that carry the point half of the
-        relative-coordinate term; the kernel subtracts the centre half)"""
+    def folded_gather(C, K, radius, seed, centred=False):
+        """group_gather_ln_max_kernel<C, V, false, FOLD[, CENTRED]>: the forms the encoder runs (rows that carry the point half of the
+        relative-coordinate term; the kernel subtracts the centre half; centred: rows and weights with zero mean over the channels)"""
         g = torch.Generator().manual_seed(seed)
         P = torch.randn(B, S, C, generator=g).to(dev)
         Wr = (torch.randn(C, 3, generator=g) / 3).to(dev)
+        if centred:
+            P, Wr = (P - P.mean(-1, keepdim=True)).contiguous(), (Wr - Wr.mean(0, keepdim=True)).contiguous()
+        fn, name = (lib.dpm_group_gather_ln_max_centred, "dpm_group_gather_ln_max_centred") if centred else \
+            (lib.dpm_group_gather_ln_max_folded, "dpm_group_gather_ln_max_folded")
         gm, bt = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
         idx = ops.knn_hybrid(cen, clen, cen, K, radius)
 
         def call():
             out = torch.empty(B, S, C, device=dev)
-            _lib.check(lib.dpm_group_gather_ln_max_folded(P.data_ptr(), cen.data_ptr(), idx.data_ptr(), Wr.data_ptr(), 3, gm.data_ptr(),
-                                                          bt.data_ptr(), B, S, S, K, C, float(radius), out.data_ptr(),
-                                                          torch.cuda.current_stream().cuda_stream), "dpm_group_gather_ln_max_folded")
+            _lib.check(fn(P.data_ptr(), cen.data_ptr(), idx.data_ptr(), Wr.data_ptr(), 3, gm.data_ptr(), bt.data_ptr(), B, S, S, K, C,
+                          float(radius), out.data_ptr(), torch.cuda.current_stream().cuda_stream), name)
             return out
         return call
 
@@ -84,6 +87,8 @@ def _victims(dev):
         "gather <32> (LocalAggregation)": plain_gather(32, 32, 0.1, 1),
         "gather folded <32>": folded_gather(32, 32, 0.1, 6),
         "gather folded <128>": folded_gather(128, 32, 0.2, 7),
+        "gather centred <32>": folded_gather(32, 32, 0.1, 8, centred=True),
+        "gather centred <64>": folded_gather(64, 32, 0.1, 9, centred=True),
         "gather <64>": plain_gather(64, 32, 0.1, 2),
         "gather <128>": plain_gather(128, 32, 0.2, 3),
         "gather <256>, 16 neighbours": plain_gather(256, 16, 0.2, 4),

@@ -534,6 +534,47 @@ def test_folded_grouping_layers_against_the_unfolded_form(ops, monkeypatch):
     torch.testing.assert_close(a, b, rtol=0, atol=5e-5)
 
 
+def test_centred_grouping_layers_against_the_folded_form(ops, monkeypatch):
+    """knobs.CENTRED_GATHER (csrc/group_mlp.hip, CENTRED): LayerNorm's mean removal applied to the layer's weights once
+    ((I - 11^T / C) W, fp64) instead of to every gathered row -- against the folded form that computes the row mean, at every width
+    the encoder uses and for the affine first level; weights and bias with a LARGE common offset over the channels (the part the
+    centring removes) included.  The forms differ by rounding only."""
+    from deeppointmap_amd import knobs
+    gen = torch.Generator().manual_seed(43)
+    d = lambda t: t.to(DEV)
+    for Cin, Cout, K, radius, offset in ((32, 32, 32, 0.05, 0.0), (32, 64, 32, 0.1, 3.0), (64, 128, 32, 0.2, 0.0), (128, 256, 32, 0.4, 1.0),
+                                         (256, 512, 16, 0.8, 0.0)):
+        B, N, S = 2, 3000, 400
+        xyz = d(torch.rand(B, N, 3, generator=gen) * 2 - 1)
+        fea = d(torch.randn(B, N, Cin, generator=gen))
+        ctr = xyz[:, :S].contiguous()
+        idx = d(torch.randint(0, N, (B, S, K), generator=gen).int())
+        W = d(torch.randn(Cout, Cin + 3, 1, 1, generator=gen) / (Cin + 3) ** 0.5 + offset * torch.randn(1, Cin + 3, 1, 1, generator=gen) / (Cin + 3) ** 0.5)
+        bias, gm, bt = d(0.1 * torch.randn(Cout, generator=gen) + offset), d(1 + 0.1 * torch.randn(Cout, generator=gen)), d(0.1 * torch.randn(Cout, generator=gen))
+        monkeypatch.setattr(knobs, "CENTRED_GATHER", True)
+        centred = ops.group_mlp_max(xyz, fea, ctr, idx, W, bias, gm, bt, radius)
+        monkeypatch.setattr(knobs, "CENTRED_GATHER", False)
+        folded = ops.group_mlp_max(xyz, fea, ctr, idx, W, bias, gm, bt, radius)
+        generic = ops.group_mlp_max(xyz, fea, ctr, idx, W, bias, gm, bt, radius, generic=True)
+        assert not torch.equal(centred, folded)                                    # (two different kernels ran)
+        torch.testing.assert_close(centred, folded, rtol=0, atol=2e-5 * (1 + offset))
+        torch.testing.assert_close(centred, generic, rtol=1e-4, atol=1e-4 * (1 + offset))
+    B, N, S, K = 2, 5000, 600, 32
+    xyz = d(torch.rand(B, N, 3, generator=gen) * 2 - 1)
+    ctr, idx = xyz[:, :S].contiguous(), d(torch.randint(0, N, (B, S, K), generator=gen).int())
+    W0, b0 = d(torch.randn(16, 3, 1, generator=gen)), d(0.1 * torch.randn(16, generator=gen))
+    W = d(torch.randn(32, 19, 1, 1, generator=gen) / 19 ** 0.5)
+    bias, gm, bt = d(0.1 * torch.randn(32, generator=gen) + 0.5), d(1 + 0.1 * torch.randn(32, generator=gen)), d(0.1 * torch.randn(32, generator=gen))
+    monkeypatch.setattr(knobs, "CENTRED_GATHER", True)
+    a = ops.group_mlp_max_from_xyz(xyz, W0, b0, ctr, idx, W, bias, gm, bt, 0.05)
+    monkeypatch.setattr(knobs, "CENTRED_GATHER", False)
+    b = ops.group_mlp_max_from_xyz(xyz, W0, b0, ctr, idx, W, bias, gm, bt, 0.05)
+    c = ops.group_mlp_max_from_xyz(xyz, W0, b0, ctr, idx, W, bias, gm, bt, 0.05, fused=True)
+    assert not torch.equal(a, b)
+    torch.testing.assert_close(a, b, rtol=0, atol=5e-5)
+    torch.testing.assert_close(a, c, rtol=0, atol=5e-5)
+
+
 def test_weight_derived_tensors_follow_the_weights(ops):
     """ops caches what depends on weights alone (packed feature columns, the stage-0 affine map).  In-place updates,
     and a new weight tensor that lands on a freed one's address, must both be seen."""
