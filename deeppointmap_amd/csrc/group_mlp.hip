@@ -477,6 +477,10 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {
 // the bias (and, AFFINE, to the point map and its constant), so that every pre-LayerNorm row has zero mean over its channels by
 // construction: the row sum, its lane-group reduction and the subtraction (about a third of the instructions per gathered row)
 // are not executed.  What is left of the mean is the rounding of the row's own elements (~1e-7 of their magnitude / sqrt(C)).
+// The same caller multiplies channel c of the layer by sign(gamma_c): gamma (y rs) + beta = |gamma| (sign(gamma) y rs) + beta is
+// then a non-decreasing function of the gathered value, and a non-decreasing function commutes with the maximum over the
+// neighbours bit for bit -- the kernel keeps the running maximum of y rs and applies |gamma|, beta and the ReLU once per centre
+// (a multiply-add per channel and gathered row less; sign flips are exact, so the result equals the per-row form's).
 template <int COUT, int V, bool AFFINE, bool FOLD = false, bool CENTRED = false>
 __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
     const float *__restrict__ P_all, const float *__restrict__ A, const float *__restrict__ cvec,
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
 #pragma unroll
         for (int v = 0; v < V; ++v)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mx[v][e] = 0.f;  // ReLU floor
+            for (int e = 0; e < 4; ++e) mx[v][e] = CENTRED ? -__builtin_inff() : 0.f;  // ReLU floor (CENTRED: applied at the end)
         float kc[FOLD ? V : 1][4];   // FOLD: the centre half, W_r' c (AFFINE: minus the point map's constant, so that one add serves both)
         if (FOLD) {
 #pragma unroll
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
 #pragma unroll
             for (int v = 0; v < V; ++v)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mx[v][e] = vmax_raw(mx[v][e], fmaf(y[v][e] * rs, gm[v][e], bt[v][e]));
+                for (int e = 0; e < 4; ++e) mx[v][e] = vmax_raw(mx[v][e], CENTRED ? y[v][e] * rs : fmaf(y[v][e] * rs, gm[v][e], bt[v][e]));
                     }
         }
         // max over the row groups of the wave (lanes with equal gl), then the first group stores
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
                 float m = mx[v][e];
 #pragma unroll
                 for (int off = G; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-                mx[v][e] = m;
+                mx[v][e] = CENTRED ? fmaxf(fmaf(m, fabsf(gm[v][e]), bt[v][e]), 0.f) : m;
             }
         if (gr == 0) {
 #pragma unroll
@@ -702,7 +706,9 @@ extern "C" int dpm_group_gather_ln_max_folded(const float *P, const float *cente
 // dpm_group_gather_ln_max_folded for a layer whose mean removal sits in its weights: the caller PROMISES that every column of
 // [W_f | W_rel] and the bias have zero mean over the Cout output channels (W' = (I - 11^T / Cout) W), so that the rows of P and
 // the centre term have zero mean over their channels; the kernel then computes LayerNorm's variance from the rows as they are.
-// With weights that do not keep the promise the result is LayerNorm without its mean removal.
+// AND that channel c of [W_f | W_rel | bias] has been multiplied by sign(gamma_c) (+1 for gamma_c = 0): the kernel applies
+// |gamma|, beta and the ReLU to the maximum over the neighbours.  With weights that do not keep the promises the result is a
+// LayerNorm without its mean removal / with |gamma| in place of gamma.
 extern "C" int dpm_group_gather_ln_max_centred(const float *P, const float *centers, const int32_t *idx, const float *W_rel,
                                                int ldw_rel, const float *gamma, const float *beta, int B, int N, int S, int K,
                                                int Cout, double radius, float *out, dpm_stream_t stream) {

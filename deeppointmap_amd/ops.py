@@ -323,10 +323,17 @@ def _centre_rows(M: torch.Tensor) -> torch.Tensor:
     return (Md - Md.mean(0, keepdim=True)).float().contiguous()
 
 
-def _centred_layer(W2: torch.Tensor, bias: torch.Tensor, Cin: int):
-    """(I - 11^T / Cout) applied to a grouping layer: -> (W_f (Cout,Cin), W_r (Cout,3), bias (Cout)), zero mean over Cout"""
-    Wc = _centre_rows(W2)
-    return Wc[:, :Cin].contiguous(), Wc[:, Cin:].contiguous(), _centre_rows(bias.reshape(-1, 1)).reshape(-1)
+def _gamma_sign(gamma: torch.Tensor) -> torch.Tensor:
+    """(Cout, 1): +1 where gamma >= 0, -1 where gamma < 0"""
+    return torch.where(gamma < 0, -torch.ones_like(gamma), torch.ones_like(gamma)).reshape(-1, 1)
+
+
+def _centred_layer(W2: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, Cin: int):
+    """diag(sign gamma) (I - 11^T / Cout) applied to a grouping layer (csrc/group_mlp.hip, CENTRED):
+    -> (W_f (Cout,Cin), W_r (Cout,3), bias (Cout)): zero mean over Cout, then channel c times sign(gamma_c)"""
+    sg = _gamma_sign(gamma)
+    Wc = _centre_rows(W2) * sg
+    return Wc[:, :Cin].contiguous(), Wc[:, Cin:].contiguous(), (_centre_rows(bias.reshape(-1, 1)) * sg).reshape(-1).contiguous()
 
 
 def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, generic: bool = False,
@@ -357,7 +364,7 @@ def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, g
             if knobs.CENTRED_GATHER:
                 # LayerNorm's mean removal moved into the layer: (I - 11^T / Cout) applied to the weight and the bias (fp64, once per
                 # weight version), every projected row and centre term then has zero mean over its channels by construction
-                Wfc, Wrc, bc = _derived("centred-layer", (W, bias), lambda: _centred_layer(W2, bias, Cin))
+                Wfc, Wrc, bc = _derived("centred-layer", (W, bias, gamma), lambda: _centred_layer(W2, bias, gamma, Cin))
                 P = linear_bf16x3(fea.reshape(B * N, Cin), Wfc, bc, rank3=(xyz.reshape(B * N, 3), Wrc.data_ptr(), 3, 1.0 / float(radius)))
                 if P is not None:
                     _lib.check(lib.dpm_group_gather_ln_max_centred(_ptr(P), _ptr(centers), _ptr(idx), _ptr(Wrc), 3, _ptr(gamma), _ptr(beta),
@@ -406,8 +413,10 @@ def group_mlp_max_from_xyz(xyz, W0, b0, centers, idx, W, bias, gamma, beta, radi
             linear(W2[:, :Cin], W0.reshape(Cin, 3).t().contiguous(), exact=True),                     # (Cout,3) = W_f W0
             linear(W2[:, :Cin], b0.reshape(1, Cin), residual=bias.reshape(Cout, 1), exact=True)))     # (Cout,1) = W_f b0 + b
         if knobs.CENTRED_GATHER and knobs.FOLD_GATHER:
-            Ac, cc, Wrc = _derived("affine-stage0-centred", (W, W0, b0, bias), lambda: (
-                _centre_rows(A), _centre_rows(cvec.reshape(Cout, 1)).reshape(Cout), _centre_rows(W2[:, Cin:])))
+            Ac, cc, Wrc = _derived("affine-stage0-centred", (W, W0, b0, bias, gamma), lambda: (
+                (_centre_rows(A) * _gamma_sign(gamma)).contiguous(),
+                (_centre_rows(cvec.reshape(Cout, 1)) * _gamma_sign(gamma)).reshape(Cout).contiguous(),
+                (_centre_rows(W2[:, Cin:]) * _gamma_sign(gamma)).contiguous()))
             _lib.check(_lib.load().dpm_group_affine_ln_max_centred(_ptr(Ac), _ptr(cc), _ptr(xyz), _ptr(centers), _ptr(idx), _ptr(Wrc), 3,
                                                                    _ptr(gamma), _ptr(beta), B, N, S, K, Cout, float(radius),
                                                                    _ptr(out), _stream(xyz)), "dpm_group_affine_ln_max_centred")

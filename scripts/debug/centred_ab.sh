@@ -1,8 +1,8 @@
 mkdir -p gpurun_out/r05i
-python -m pytest tests -q -m gpu -x 2>&1 | tail -5
-python scripts/gather_time.py 2>&1 | grep -v amdgpu.ids | tail -12
-run() { tag=$1; shift; env "$@" python bench.py --steps 60 --warmup 10 --allow-knobs --no-extras > gpurun_out/r05i/$tag.json 2>gpurun_out/r05i/$tag.err; python -c "import json; d=json.loads(open('gpurun_out/r05i/$tag.json').read().strip().splitlines()[-1]); print('$tag', d['value'], d.get('ms_per_step'), d.get('parity_gate'), d.get('error'))"; }
-for i in 1 2; do
+python -m pytest tests/test_gpu_ops.py tests/test_gpu_encoder.py tests/test_gpu_corun_stress.py tests/test_gpu_pipeline.py -q -m gpu -x 2>&1 | tail -5
+python scripts/gather_time.py 2>&1 | grep -v amdgpu.ids | tail -3
+run() { tag=$1; shift; env "$@" python bench.py --steps 60 --warmup 10 --allow-knobs --no-extras > gpurun_out/r05i/$tag.json 2>gpurun_out/r05i/$tag.err; python -c "import json; d=json.loads(open('gpurun_out/r05i/$tag.json').read().strip().splitlines()[-1]); g=d.get('parity_gate',{}); print('$tag', d['value'], d.get('ms_per_step'), g.get('ok'), g.get('max_dT_m'), g.get('descriptor_max_err'), d.get('error'))"; }
+for i in 1 2 3; do
 run centred_$i DPM_FOLD_GATHER=1
 run plain_$i DPM_CENTRED_GATHER=0
 done

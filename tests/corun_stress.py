@@ -68,7 +68,7 @@ def _victims(dev):
         P = torch.randn(B, S, C, generator=g).to(dev)
         Wr = (torch.randn(C, 3, generator=g) / 3).to(dev)
         if centred:
-            P, Wr = (P - P.mean(-1, keepdim=True)).contiguous(), (Wr - Wr.mean(0, keepdim=True)).contiguous()
+            P, Wr = (P - P.mean(-1, keepdim=True)).contiguous(), (Wr - Wr.mean(0, keepdim=True)).contiguous()  # (gamma > 0 here: no signs to fold)
         fn, name = (lib.dpm_group_gather_ln_max_centred, "dpm_group_gather_ln_max_centred") if centred else \
             (lib.dpm_group_gather_ln_max_folded, "dpm_group_gather_ln_max_folded")
         gm, bt = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)

@@ -538,7 +538,8 @@ def test_centred_grouping_layers_against_the_folded_form(ops, monkeypatch):
     """knobs.CENTRED_GATHER (csrc/group_mlp.hip, CENTRED): LayerNorm's mean removal applied to the layer's weights once
     ((I - 11^T / C) W, fp64) instead of to every gathered row -- against the folded form that computes the row mean, at every width
     the encoder uses and for the affine first level; weights and bias with a LARGE common offset over the channels (the part the
-    centring removes) included.  The forms differ by rounding only."""
+    centring removes) included, LayerNorm scales of BOTH signs (the centred form folds sign(gamma) into the layer and applies |gamma|,
+    beta and the ReLU after the maximum; an exact zero among them).  The forms differ by rounding only."""
     from deeppointmap_amd import knobs
     gen = torch.Generator().manual_seed(43)
     d = lambda t: t.to(DEV)
@@ -550,7 +551,8 @@ def test_centred_grouping_layers_against_the_folded_form(ops, monkeypatch):
         ctr = xyz[:, :S].contiguous()
         idx = d(torch.randint(0, N, (B, S, K), generator=gen).int())
         W = d(torch.randn(Cout, Cin + 3, 1, 1, generator=gen) / (Cin + 3) ** 0.5 + offset * torch.randn(1, Cin + 3, 1, 1, generator=gen) / (Cin + 3) ** 0.5)
-        bias, gm, bt = d(0.1 * torch.randn(Cout, generator=gen) + offset), d(1 + 0.1 * torch.randn(Cout, generator=gen)), d(0.1 * torch.randn(Cout, generator=gen))
+        bias, gm, bt = d(0.1 * torch.randn(Cout, generator=gen) + offset), d(torch.randn(Cout, generator=gen)), d(0.3 * torch.randn(Cout, generator=gen))
+        gm[3] = 0.0
         monkeypatch.setattr(knobs, "CENTRED_GATHER", True)
         centred = ops.group_mlp_max(xyz, fea, ctr, idx, W, bias, gm, bt, radius)
         monkeypatch.setattr(knobs, "CENTRED_GATHER", False)
@@ -564,7 +566,7 @@ def test_centred_grouping_layers_against_the_folded_form(ops, monkeypatch):
     ctr, idx = xyz[:, :S].contiguous(), d(torch.randint(0, N, (B, S, K), generator=gen).int())
     W0, b0 = d(torch.randn(16, 3, 1, generator=gen)), d(0.1 * torch.randn(16, generator=gen))
     W = d(torch.randn(32, 19, 1, 1, generator=gen) / 19 ** 0.5)
-    bias, gm, bt = d(0.1 * torch.randn(32, generator=gen) + 0.5), d(1 + 0.1 * torch.randn(32, generator=gen)), d(0.1 * torch.randn(32, generator=gen))
+    bias, gm, bt = d(0.1 * torch.randn(32, generator=gen) + 0.5), d(torch.randn(32, generator=gen)), d(0.3 * torch.randn(32, generator=gen))
     monkeypatch.setattr(knobs, "CENTRED_GATHER", True)
     a = ops.group_mlp_max_from_xyz(xyz, W0, b0, ctr, idx, W, bias, gm, bt, 0.05)
     monkeypatch.setattr(knobs, "CENTRED_GATHER", False)
