@@ -70,6 +70,9 @@ SIGNATURES = {
     "dpm_attention_masked": (I, [P, I, LL, P, I, LL, P, I, LL, P, I, LL, I, I, I, I, I, I, P, P]),
     "dpm_attention_indexed": (I, [P, I, LL, P, I, LL, P, I, LL, P, I, LL, I, I, I, I, I, I, P, P]),
     "dpm_attention_split_workspace_bytes": (c_size_t, [I, I, I, I, I]),
+    "dpm_attention_planes_bytes": (c_size_t, [I, I, I]),
+    "dpm_attention_planes": (I, [P, I, LL, P, P, I, LL, I, I, I, I, I, P, P]),
+    "dpm_linear_bf16x3_kvplanes": (I, [P, I, P, I, LL, P, P, I, I, I, I, I, I, I, P, P]),
     "dpm_attention_split": (I, [P, I, LL, P, I, LL, P, I, LL, P, I, LL, I, I, I, I, I, I, I, P, P]),
     "dpm_l2_normalize": (I, [P, I, I, P, P]),
     "dpm_match_workspace_bytes": (c_size_t, [I, I, I, I]),

@@ -45,6 +45,12 @@ constexpr float LOG2E = 1.44269504088896340736f;
 #ifndef DPM_ATT_WIDE_MIN
 #define DPM_ATT_WIDE_MIN 0
 #endif
+#ifndef DPM_ATT_BLOCK8
+#define DPM_ATT_BLOCK8 1
+#endif
+#ifndef DPM_ATT_BLOCK8_MIN_M
+#define DPM_ATT_BLOCK8_MIN_M 1024
+#endif
 constexpr int RES_HDR = 20;  // floats before the inlier-confidence list in a Kabsch `result`
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -100,7 +106,7 @@ __device__ __forceinline__ float rows4_sum(float v) {
 // tiles each).  The keys are cut into `nsplit` ranges of whole tiles, gridDim.x = query tiles x nsplit; a block writes its
 // range's UNNORMALISED output rows (relative to its own running max) into part_o (nsplit, B, M, heads*HD) and
 // (max, sum) into part_ml (nsplit, B, heads, M, 2); attention_merge_kernel rescales and adds the ranges.
-template <bool VEC, int QT, bool MASK = false, bool SPLIT = false, int NWV = 4>
+template <bool VEC, int QT, bool MASK = false, bool SPLIT = false, int NWV = 4, bool PRE = false>
 #ifndef DPM_ATT_WAVES
 #define DPM_ATT_WAVES 0
 #endif
@@ -117,7 +123,12 @@ __global__ __launch_bounds__(64 * NWV) DPM_ATT_OCC void attention_kernel(const f
                                                         const uint8_t *__restrict__ key_mask = nullptr, int nsplit = 1,
                                                         float *__restrict__ part_o = nullptr,
                                                         float *__restrict__ part_ml = nullptr,
-                                                        const int32_t *__restrict__ seq = nullptr) {
+                                                        const int32_t *__restrict__ seq = nullptr,
+                                                        const uint16_t *__restrict__ kvp = nullptr) {
+    // PRE (round 5): the keys and values arrive as the bf16 planes this kernel would otherwise make of them, one 24 KB image
+    // per (stored sequence, head, 64-key tile) in exactly the layout of Ks3 | Vt3 below -- written once by the q | k | v
+    // projection's epilogue (gemm_b3.hip, KvPlanes) instead of being split by every query block that reads the tile: staging is
+    // a straight copy (N % 64 == 0; Kp / V are not read).
     constexpr int TK = 64;                 // keys per tile
     // A operand of S^T = K Q^T, which runs as an exact bf16x3 product (round 4; gemm_b3.hip has the arithmetic: both operands
     // split into three bf16 terms, six term products per score, fp32 accumulate -- 3/8 of the exact-fp32 instruction's
@@ -157,6 +168,8 @@ __global__ __launch_bounds__(64 * NWV) DPM_ATT_OCC void attention_kernel(const f
     if (seq) bk = seq[bk];
     const float *Kb = Kp + (size_t)bk * sk + h * HD;
     const float *Vb = V + (size_t)bk * sv + h * HD;
+    constexpr int IMG = 2 * 3 * TK * HD;   // uint16 per (sequence, head, tile): K planes, then the transposed V planes
+    const uint16_t *img = PRE ? kvp + ((size_t)bk * gridDim.y + h) * (size_t)(N / TK) * IMG : nullptr;
 
     // Q^T fragments (B operand: B[k = 8 g + e][j = lane&15] = Q[query lane&15][d = 8 g + e]), pre-scaled, split once
     bf16x8 qb[QT][3];
@@ -183,8 +196,16 @@ __global__ __launch_bounds__(64 * NWV) DPM_ATT_OCC void attention_kernel(const f
     // registers (branch-free: rows beyond N re-read the last key; their scores are masked to -inf below, so the
     // probabilities that multiply those V rows are exactly 0) while the current one feeds the MFMAs.
     constexpr int PT = 512 / (64 * NWV);  // float4 per thread and matrix
-    float4 kreg[PT], vreg[PT];
+    constexpr int PC = PRE ? IMG / 8 / (64 * NWV) : 1;   // 16-byte pieces of an image per thread
+    float4 kreg[PRE ? 1 : PT], vreg[PRE ? 1 : PT];
+    u32x4 preg[PC];
     auto fetch = [&](int n0) {
+        if (PRE) {
+            const uint16_t *src = img + (size_t)(n0 / TK) * IMG;
+#pragma unroll
+            for (int i = 0; i < PC; ++i) preg[i] = *reinterpret_cast<const u32x4 *>(src + (size_t)(t + i * (64 * NWV)) * 8);
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             const int e = t + p * (64 * NWV), kr = min(n0 + (e >> 3), N - 1), c4 = (e & 7) * 4;
@@ -199,8 +220,16 @@ __global__ __launch_bounds__(64 * NWV) DPM_ATT_OCC void attention_kernel(const f
     fetch(n_begin);
     for (int n0 = n_begin; n0 < n_end; n0 += TK) {
         __syncthreads();
+        if (PRE) {
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
+            for (int i = 0; i < PC; ++i) {
+                const int c = t + i * (64 * NWV);   // piece of the image: the K planes are its first half
+                uint16_t *dst = c < IMG / 16 ? &Ks3[0][0][0] + c * 8 : &Vt3[0][0][0] + (c - IMG / 16) * 8;
+                *reinterpret_cast<u32x4 *>(dst) = preg[i];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < (PRE ? 0 : PT); ++p) {
             const int e = t + p * (64 * NWV), kr = e >> 3, c4 = (e & 7) * 4;
             unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
             split3(kreg[p].x, h0, m0, l0), split3(kreg[p].y, h1, m1, l1), split3(kreg[p].z, h2, m2, l2), split3(kreg[p].w, h3, m3, l3);
@@ -1421,6 +1450,31 @@ extern "C" int dpm_attention_indexed(const float *Q, int ldq, long long sq, cons
     DPM_CHECK_ARG(seq_index);
     return attention_launch(Q, ldq, sq, K, ldk, sk, V, ldv, sv, out, ldo, so, B, M, N, heads, head_dim, kv_shift, nullptr,
                             seq_index, stream);
+}
+
+// Keys and values as pre-split planes (attention_kernel<PRE>): kv_planes holds, per (stored sequence, head, 64-key tile), the 24 KB
+// image dpm_linear_bf16x3_kvplanes writes (K planes in the swizzled rows of the score product's A operand, then the transposed V
+// planes).  head_dim 32, N % 64 == 0, no key mask.  seq_index as in dpm_attention_indexed (NULL: element b is stored sequence b).
+extern "C" size_t dpm_attention_planes_bytes(int n_sequences, int N, int heads) {
+    if (n_sequences <= 0 || N <= 0 || heads <= 0 || N % 64 != 0) return 0;
+    return (size_t)n_sequences * heads * (N / 64) * (2 * 3 * 64 * HD * sizeof(uint16_t));
+}
+
+extern "C" int dpm_attention_planes(const float *Q, int ldq, long long sq, const void *kv_planes, float *out, int ldo, long long so,
+                                    int B, int M, int N, int heads, int kv_shift, const int32_t *seq_index, dpm_stream_t stream) {
+    DPM_CHECK_ARG(Q && kv_planes && out && B >= 1 && M >= 1 && N >= 64 && N % 64 == 0 && heads >= 1 && kv_shift >= 0 && kv_shift < B);
+    DPM_CHECK_ARG(ldq >= heads * HD && ldo >= heads * HD);
+    if (ldo % 4 != 0 || so % 4 != 0 || ((uintptr_t)out & 15) != 0 || ((uintptr_t)kv_planes & 15) != 0) return DPM_EUNSUPPORTED;
+    const float scale = (float)(1.0 / sqrt((double)HD));
+    hipStream_t st = (hipStream_t)stream;
+    const uint16_t *kvp = (const uint16_t *)kv_planes;
+    if (DPM_ATT_BLOCK8 && M % 128 == 0 && M >= DPM_ATT_BLOCK8_MIN_M)
+        hipLaunchKernelGGL((attention_kernel<true, 1, false, false, 8, true>), dim3(M / 128, heads, B), dim3(512), 0, st, Q, ldq, sq, Q, 0,
+                           0LL, Q, 0, 0LL, out, ldo, so, M, N, scale, kv_shift, nullptr, 1, nullptr, nullptr, seq_index, kvp);
+    else
+        hipLaunchKernelGGL((attention_kernel<true, 1, false, false, 4, true>), dim3(dpm_cdiv(M, 64), heads, B), dim3(256), 0, st, Q, ldq, sq,
+                           Q, 0, 0LL, Q, 0, 0LL, out, ldo, so, M, N, scale, kv_shift, nullptr, 1, nullptr, nullptr, seq_index, kvp);
+    return dpm_launch_status();
 }
 
 // Key-split form (few queries, many keys; see attention_kernel<SPLIT>): same arguments as dpm_attention_shifted plus the

@@ -61,12 +61,24 @@ constexpr int B3_KT = 32, B3_LD = B3_KT;       // K-tile; LDS rows of 64 bytes, 
 // registers of a deeper ring cost occupancy (measured: 97 -> 99.9 / 99.4 / 106.5 us at 2 / 3 / 4 on 32 768 x 256 -> 768) --,
 // 4 for small launches (at most a few workgroups per CU: the registration of ONE pair, the encoder's lower levels), where every
 // trip of the K loop otherwise waits out a whole L2 / HBM round trip.  Same instructions per output element: same bits.
-template <int BM, int BN, bool XVEC, int PF = 1>
-__global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ Wp, int ldw,
-                                                      long long plane, const float *__restrict__ bias,
-                                                      const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo,
-                                                      int R, int Cin, int Cout, int act, const float *__restrict__ r3x = nullptr,
-                                                      const float *__restrict__ r3w = nullptr, int ldr3 = 0, float r3s = 0.f) {
+// Output columns >= col0 leave the kernel as the attention kernel's operand planes instead of fp32 rows (round 5; decoder_ops.hip,
+// attention_kernel<PRE>): the layer is a q | k | v projection over sequences of `tokens` rows (a multiple of 64), columns col0 ..
+// are K then V, `heads` heads of 32 each, and a 64-row tile is exactly one 64-key tile of one sequence.  Per (sequence, head, tile)
+// one image of 2 x 6144 uint16 at p: the three bf16 planes of K[key][d] in b3_col-swizzled 64-byte rows, then the three planes of
+// V TRANSPOSED, [d][slot] in 128-byte rows with the chunk swizzle and the key <-> slot order of the attention kernel's P V product.
+// The values split are the ones the fp32 path would have stored (accumulator + bias): the attention kernel's own staging makes
+// the same planes of them, bit for bit.
+struct KvPlanes {
+    uint16_t *p;
+    int col0, tokens, heads;
+};
+
+template <int BM, int BN, bool XVEC, int PF, bool KVP>
+__device__ __forceinline__ void gemm_b3_body(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ Wp, int ldw,
+                                             long long plane, const float *__restrict__ bias,
+                                             const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo,
+                                             int R, int Cin, int Cout, int act, const float *__restrict__ r3x,
+                                             const float *__restrict__ r3w, int ldr3, float r3s, KvPlanes kv) {
     // r3x / r3w (round 5): a rank-3 term in the epilogue, out += r3s * (r3x[row, 0:3] . r3w[col, 0:3]) in fp32 -- the relative-
     // coordinate columns of a grouping layer applied to the POINT's own coordinates (group_mlp.hip, "folded" gather)
     constexpr int LDC = BN + 4, MB = BM / 32, NB = BN / 32, PX = BM / 32, WT = BN * 4, PW = (WT + 255) / 256;   // WT: 16-byte pieces of a W plane tile
@@ -176,6 +188,45 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
             *reinterpret_cast<float4 *>(&ct[(wm * (BM / 2) + i * 16 + (lane & 15)) * LDC + wn * (BN / 2) + j * 16 + (lane >> 4) * 4]) =
                 make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     __syncthreads();
+    if (KVP && BM == 64 && BN % 32 == 0 && col0 >= kv.col0) {   // (uniform) this tile is K or V of BN / 32 heads: planes, not rows
+        const int E = kv.heads * 32, colk = col0 - kv.col0, isV = colk >= E ? 1 : 0, head0 = (colk - isV * E) >> 5;
+        const int sq_ = row0 / kv.tokens, kt = (row0 - sq_ * kv.tokens) >> 6, ntile = kv.tokens >> 6;
+#pragma unroll 1
+        for (int hh = 0; hh < BN / 32; ++hh) {
+            uint16_t *img = kv.p + ((((size_t)sq_ * kv.heads + head0 + hh) * ntile + kt) * 2 + isV) * 6144;
+            const float *bh = bias ? bias + col0 + hh * 32 : nullptr;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int e = t + p * 256;
+                if (!isV) {   // K[key kr][d = c4 .. c4 + 3]: the attention kernel's staging, from the tile instead of from memory
+                    const int kr = e >> 3, c4 = (e & 7) * 4;
+                    float4 v = *reinterpret_cast<const float4 *>(&ct[kr * LDC + hh * 32 + c4]);
+                    if (bh) {
+                        const float4 bv = *reinterpret_cast<const float4 *>(bh + c4);
+                        v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                    }
+                    unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+                    split3(v.x, h0, m0, l0), split3(v.y, h1, m1, l1), split3(v.z, h2, m2, l2), split3(v.w, h3, m3, l3);
+                    uint16_t *o = img + kr * 32 + b3_col(kr, c4);
+                    *reinterpret_cast<u32x2 *>(o) = u32x2{pack2(h0, h1), pack2(h2, h3)};
+                    *reinterpret_cast<u32x2 *>(o + 2048) = u32x2{pack2(m0, m1), pack2(m2, m3)};
+                    *reinterpret_cast<u32x2 *>(o + 4096) = u32x2{pack2(l0, l1), pack2(l2, l3)};
+                } else {      // V^T[d][slots slot0 .. slot0 + 3] = four consecutive keys of channel d
+                    const int d = e & 31, slot0 = (e >> 5) * 4;
+                    const int key0 = 32 * (slot0 >> 5) + 16 * ((slot0 & 7) >> 2) + 4 * ((slot0 >> 3) & 3);
+                    const float b = bh ? bh[d] : 0.f;
+                    unsigned hq[4], mq[4], lq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) split3(ct[(key0 + q) * LDC + hh * 32 + d] + b, hq[q], mq[q], lq[q]);
+                    uint16_t *o = img + d * 64 + (((((slot0 >> 3) ^ (d >> 1)) & 7) << 3) | (slot0 & 7));
+                    *reinterpret_cast<u32x2 *>(o) = u32x2{pack2(hq[0], hq[1]), pack2(hq[2], hq[3])};
+                    *reinterpret_cast<u32x2 *>(o + 2048) = u32x2{pack2(mq[0], mq[1]), pack2(mq[2], mq[3])};
+                    *reinterpret_cast<u32x2 *>(o + 4096) = u32x2{pack2(lq[0], lq[1]), pack2(lq[2], lq[3])};
+                }
+            }
+        }
+        return;
+    }
     constexpr int TPR = BN / 4, RPS = 256 / TPR;   // threads per tile row, rows per store pass
     const int cr = t / TPR, cc = (t % TPR) * 4, c = col0 + cc;
     if (c < Cout) {   // Cout % 4 == 0 (dispatch): a thread's four columns exist together
@@ -209,6 +260,26 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ 
             *reinterpret_cast<float4 *>(out + (size_t)r * ldo + c) = v;
         }
     }
+}
+
+template <int BM, int BN, bool XVEC, int PF = 1>
+__global__ __launch_bounds__(256) void gemm_b3_kernel(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ Wp, int ldw,
+                                                      long long plane, const float *__restrict__ bias,
+                                                      const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo,
+                                                      int R, int Cin, int Cout, int act, const float *__restrict__ r3x = nullptr,
+                                                      const float *__restrict__ r3w = nullptr, int ldr3 = 0, float r3s = 0.f) {
+    gemm_b3_body<BM, BN, XVEC, PF, false>(X, ldx, Wp, ldw, plane, bias, res, ldr, out, ldo, R, Cin, Cout, act, r3x, r3w, ldr3, r3s,
+                                          KvPlanes{nullptr, 0, 0, 0});
+}
+
+// the q | k | v projection with its K / V columns as planes (KvPlanes).  Held to the register budget of four waves per SIMD: the
+// plain 64 x 128 kernel needs 122 registers, this one asked for 130 (three waves) before it was told
+template <int BN, int PF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF == 1 ? 4 : 3, PF == 1 ? 4 : 3))) void gemm_b3_kvp_kernel(
+    const float *__restrict__ X, int ldx, const uint16_t *__restrict__ Wp, int ldw, long long plane, const float *__restrict__ bias,
+    float *__restrict__ out, int ldo, int R, int Cin, int Cout, KvPlanes kv) {
+    gemm_b3_body<64, BN, true, PF, true>(X, ldx, Wp, ldw, plane, bias, nullptr, 0, out, ldo, R, Cin, Cout, DPM_ACT_NONE, nullptr, nullptr, 0,
+                                         0.f, kv);
 }
 
 // GEMM + LayerNorm in one kernel on the bf16x3 product (the fp32 form: gemm_ln_kernel, gemm.hip): out = act(LN(X W^T + bias +
@@ -599,6 +670,32 @@ extern "C" int dpm_linear_bf16x3_rank3(const float *x, int ldx, const void *w_pl
         else DPM_B3_LAUNCH(32, 32, false, 1);
     }
 #undef DPM_B3_LAUNCH
+    return dpm_launch_status();
+}
+
+// dpm_linear_bf16x3 for a q | k | v projection whose K and V go straight to the attention kernel (KvPlanes above): columns
+// [0, kv_col0) are written to `out` as fp32 rows, columns [kv_col0, Cout) = K (heads x 32) then V (heads x 32) are written to
+// kv_planes as the per-(sequence, head, 64-key tile) images of dpm_attention_planes -- sequence = row / tokens.  Needs
+// tokens % 64 == 0, R % tokens == 0, kv_col0 % 64 == 0, Cout - kv_col0 == 64 heads, 16-byte aligned operands; no residual, no
+// activation.  DPM_EUNSUPPORTED otherwise (the caller runs dpm_linear_bf16x3 + dpm_attention_*: same results bit for bit).
+extern "C" int dpm_linear_bf16x3_kvplanes(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride,
+                                          const float *bias, float *out, int ldo, int R, int Cin, int Cout, int kv_col0, int tokens,
+                                          int heads, void *kv_planes, dpm_stream_t stream) {
+    DPM_CHECK_ARG(x && w_planes && out && kv_planes && R >= 1 && Cin >= 1 && Cout >= 1 && ldx >= Cin && ldw >= Cin && heads >= 1);
+    DPM_CHECK_ARG(kv_col0 >= 0 && kv_col0 < Cout && ldo >= kv_col0 && tokens >= 64 && plane_stride >= (long long)Cout * ldw);
+    auto al = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+    if (Cin % B3_KT != 0 || ldw % 8 != 0 || plane_stride % 8 != 0 || ldo % 4 != 0 || !al(w_planes) || !al(out) || !al(bias) || !al(kv_planes) ||
+        ldx % 4 != 0 || !al(x) || tokens % 64 != 0 || R % tokens != 0 || kv_col0 % 64 != 0 || Cout - kv_col0 != 64 * heads)
+        return DPM_EUNSUPPORTED;
+    const KvPlanes kv{(uint16_t *)kv_planes, kv_col0, tokens, heads};
+#define DPM_B3_KV(TN, PF)                                                                                                       \
+    hipLaunchKernelGGL((gemm_b3_kvp_kernel<TN, PF>), dim3(dpm_cdiv(Cout, TN), R / 64), dim3(256), 0, (hipStream_t)stream, x, ldx,   \
+                       (const uint16_t *)w_planes, ldw, plane_stride, bias, out, ldo, R, Cin, Cout, kv)
+    // 64-row tiles always (a tile is a key tile); the width by dpm_linear_bf16x3's rule -- the bits do not depend on it
+    if (DPM_B3_WIDE && Cout % 128 == 0 && kv_col0 % 128 == 0 && (long long)(R / 64) * (Cout / 128) >= DPM_B3_WIDE) DPM_B3_KV(128, 1);
+    else if ((long long)(R / 64) * dpm_cdiv(Cout, 64) <= DPM_B3_DEEP) DPM_B3_KV(64, 4);
+    else DPM_B3_KV(64, 1);
+#undef DPM_B3_KV
     return dpm_launch_status();
 }
 

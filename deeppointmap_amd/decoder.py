@@ -115,8 +115,10 @@ class Decoder(ParamTree):
         """x + MHA(x, x, x) (norm None) or LN_norm(x + MHA(x, x, x)) + post, the out-projection carrying the norm;
         mask (B,M) uint8 = key_padding_mask"""
         E = self.model_channel
-        qkv = ops.linear(xp, self.p(pre + ".in_proj_weight"), self.p(pre + ".in_proj_bias"))
-        a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, M, M, HEADS, key_mask=mask)
+        a = ops.qkv_attention(xp, self.p(pre + ".in_proj_weight"), self.p(pre + ".in_proj_bias"), B, M, HEADS) if mask is None else None
+        if a is None:
+            qkv = ops.linear(xp, self.p(pre + ".in_proj_weight"), self.p(pre + ".in_proj_bias"))
+            a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, M, M, HEADS, key_mask=mask)
         if norm is not None:
             return self._lin_ln(pre + ".out_proj", norm, a, xp, post)
         return ops.linear(a, self.p(pre + ".out_proj.weight"), self.p(pre + ".out_proj.bias"), residual=xp)
@@ -240,14 +242,18 @@ class Decoder(ParamTree):
             # attention kernel picks a pair's sequences through `order` (row-wise kernel: the same rows bit for bit)
             ca0 = pre + ".cross_attn"
             # (the indexed attention kernel exists for 32-wide heads without masks; other widths project per pair side)
-            qkv_u = (ops.linear(z1u, self.p(ca0 + ".in_proj_weight"), self.p(ca0 + ".in_proj_bias"))
-                     if self.dedup_frames and E // HEADS == 32 and mask is None else None)
+            a_first = qkv_u = None
+            if self.dedup_frames and E // HEADS == 32 and mask is None:
+                a_first = ops.qkv_attention(z1u, self.p(ca0 + ".in_proj_weight"), self.p(ca0 + ".in_proj_bias"), 2 * B, M, HEADS,
+                                            kv_shift=B, seq_index=order)
+                if a_first is None:
+                    qkv_u = ops.linear(z1u, self.p(ca0 + ".in_proj_weight"), self.p(ca0 + ".in_proj_bias"))
             zp = None
         else:
             z_in = torch.cat([ts, td], dim=0)                       # (2R, 131): [src tokens ; dst tokens]
             pos = ops.posemb(z_in[:, C:C + 3], self._dimt(dev), E)
             zp = ops.linear(z_in[:, :C], self.p("projection.weight"), self.p("projection.bias"), residual=pos)
-            z1_first = qkv_u = None
+            z1_first = qkv_u = a_first = None
         for l in range(self.attention_layers):
             pre = f"descriptor_attention.{l}"
             last = l == self.attention_layers - 1
@@ -258,12 +264,17 @@ class Decoder(ParamTree):
             ca = pre + ".cross_attn"
             # both directions in one launch: sequence b (source of pair b, or target of pair b - B) reads the keys and
             # values of sequence (b + B) mod 2B, its partner
-            if l == 0 and z1_first is not None and qkv_u is not None:
+            if l == 0 and z1_first is not None and a_first is not None:
+                a = a_first
+            elif l == 0 and z1_first is not None and qkv_u is not None:
                 a = ops.attention(qkv_u[:, :E], qkv_u[:, E:2 * E], qkv_u[:, 2 * E:], 2 * B, M, M, HEADS, kv_shift=B,
                                   seq_index=order)
             else:
-                qkv = ops.linear(z1, self.p(ca + ".in_proj_weight"), self.p(ca + ".in_proj_bias"))  # q | k | v of every token
-                a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], 2 * B, M, M, HEADS, kv_shift=B, key_mask=mask)
+                a = ops.qkv_attention(z1, self.p(ca + ".in_proj_weight"), self.p(ca + ".in_proj_bias"), 2 * B, M, HEADS,
+                                      kv_shift=B) if mask is None else None
+                if a is None:
+                    qkv = ops.linear(z1, self.p(ca + ".in_proj_weight"), self.p(ca + ".in_proj_bias"))  # q | k | v of every token
+                    a = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], 2 * B, M, M, HEADS, kv_shift=B, key_mask=mask)
             z2 = self._lin_ln(ca + ".out_proj", pre + ".norm2", a, z1)
             zp = self._lin_ln(pre + ".mlp.2", pre + ".norm3", self._lin(pre + ".mlp.0", z2, ops.ACT_RELU), z2,
                               None if last else pos)

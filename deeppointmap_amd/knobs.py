@@ -38,9 +38,13 @@ FOLD_GATHER = True
 CENTRED_GATHER = True
 FUSED_PWCONV = True    # InvResMLP's pw_conv pair of the first level (C = 32) as one kernel (csrc/gemm_b3.hip, pwconv_pair_b3_kernel); False: two fused GEMM + LayerNorm kernels
 FUSED_MATCH = True     # similarity -> dual softmax -> top-k as one operator (csrc/match.hip) where it applies; False: the five-launch form
+# the decoder's q | k | v projections hand K and V to the attention kernel as its bf16 operand planes (csrc/gemm_b3.hip KvPlanes,
+# csrc/decoder_ops.hip attention_kernel<PRE>): split once by the projection's epilogue instead of by every query block that reads
+# a key tile.  Bit-identical to the fp32 hand-over (False).
+KV_PLANES = True
 DEDUP_FRAMES = True    # False: per-frame decoder work once per pair side instead of once per frame (new Decoder objects)
 
-_ENV = {"DPM_CENTRED_GATHER": ("CENTRED_GATHER", lambda v: v != "0"), "DPM_FPS_ALGO": ("FPS_ALGO", int), "DPM_NO_FUSED_LN": ("FUSED_LN", lambda v: v != "1"),
+_ENV = {"DPM_KV_PLANES": ("KV_PLANES", lambda v: v != "0"), "DPM_CENTRED_GATHER": ("CENTRED_GATHER", lambda v: v != "0"), "DPM_FPS_ALGO": ("FPS_ALGO", int), "DPM_NO_FUSED_LN": ("FUSED_LN", lambda v: v != "1"),
         "DPM_DEDUP_FRAMES": ("DEDUP_FRAMES", lambda v: v != "0"), "DPM_GEMM_BF16X3": ("GEMM_BF16X3", lambda v: v == "1"), "DPM_BF16X3_MAX_K": ("BF16X3_MAX_K", int), "DPM_BF16X3_LN_MIN_K": ("BF16X3_LN_MIN_K", int), "DPM_FUSED_LN_SMALL_ROWS": ("FUSED_LN_SMALL_ROWS", int), "DPM_GEMM_LN_BF16X3": ("GEMM_LN_BF16X3", lambda v: v == "1"),
         "DPM_FUSED_MATCH": ("FUSED_MATCH", lambda v: v != "0"), "DPM_FUSED_PWCONV": ("FUSED_PWCONV", lambda v: v != "0"), "DPM_FOLD_GATHER": ("FOLD_GATHER", lambda v: v != "0")}
 

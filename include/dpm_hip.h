@@ -329,6 +329,24 @@ int dpm_attention_split(const float *Q, int ldq, long long sq, const float *K, i
                         int ldv, long long sv, float *out, int ldo, long long so, int B, int M, int N, int heads,
                         int head_dim, int kv_shift, int nsplit, void *workspace, dpm_stream_t stream);
 
+/* nn.MultiheadAttention's in_proj followed by its attention (descriptor_attention.py:33-44) with K and V handed over as the
+ * attention kernel's operand planes instead of fp32 rows (round 5).  dpm_linear_bf16x3_kvplanes is dpm_linear_bf16x3 for a
+ * q | k | v projection over sequences of `tokens` rows: columns [0, kv_col0) go to `out` as fp32 rows (Q), columns [kv_col0, Cout) =
+ * K (heads x 32) then V (heads x 32) go to kv_planes as one 24 576-byte image per (sequence = row / tokens, head, 64-key tile):
+ * the three bf16 planes of the K tile in the swizzled rows the score product reads, then the three planes of the V tile
+ * transposed in the order the P V product reads -- exactly what the attention kernel's own staging makes of the fp32 rows, so
+ * dpm_attention_planes returns dpm_attention_shifted / _indexed's result bit for bit while each K / V element is split once
+ * instead of once per 64-query block that reads it.  kv_planes: dpm_attention_planes_bytes(sequences, tokens, heads) bytes,
+ * 16-byte aligned.  Needs tokens % 64 == 0, R % tokens == 0, kv_col0 % 64 == 0, Cout - kv_col0 == 64 * heads, 16-byte aligned
+ * x / bias / out with ldx % 4 == 0; DPM_EUNSUPPORTED otherwise (callers then run dpm_linear_bf16x3 + dpm_attention_*).
+ * dpm_attention_planes: head_dim 32, N % 64 == 0, no key mask; seq_index as in dpm_attention_indexed or NULL. */
+size_t dpm_attention_planes_bytes(int n_sequences, int N, int heads);
+int dpm_linear_bf16x3_kvplanes(const float *x, int ldx, const void *w_planes, int ldw, long long plane_stride,
+                               const float *bias, float *out, int ldo, int R, int Cin, int Cout, int kv_col0, int tokens,
+                               int heads, void *kv_planes, dpm_stream_t stream);
+int dpm_attention_planes(const float *Q, int ldq, long long sq, const void *kv_planes, float *out, int ldo, long long so,
+                         int B, int M, int N, int heads, int kv_shift, const int32_t *seq_index, dpm_stream_t stream);
+
 /* The same contraction as dpm_linear (Conv1d(k=1) / nn.Linear: network/encoder/utils.py:358-389, the decoder's projections
  * and heads) on the bf16 matrix pipe with every fp32 operand split exactly into three bf16 terms and six of the nine term
  * products accumulated in fp32 (the three dropped ones are below 2^-23 of the product): fp32-accumulation accuracy at 3/8 of

@@ -548,3 +548,29 @@ def test_registration_forward_replays_a_captured_graph_bit_for_bit(cfg_full):
     dec.graph_min_hits = 0
     want = dec.registration_forward(s, d, num_sample=0.5)
     assert torch.equal(after[0], want[0]) and torch.equal(after[1], want[1]) and not torch.equal(before[2], after[2])
+
+
+def test_qkv_attention_planes_equal_the_fp32_hand_over(ops, monkeypatch):
+    """ops.qkv_attention (dpm_linear_bf16x3_kvplanes -> dpm_attention_planes: K / V split into the attention kernel's operand planes
+    by the projection's epilogue) against linear() + attention() on the same rows: bit-identical -- self attention, both directions
+    of a cross attention in one launch (kv_shift), sequences drawn from stored frames (seq_index), one pair, a map-sized tile."""
+    from deeppointmap_amd import knobs
+    gen = torch.Generator().manual_seed(77)
+    E, H = 256, 8
+    W = (torch.randn(3 * E, E, generator=gen) / 16).to(DEV)
+    b = (0.1 * torch.randn(3 * E, generator=gen)).to(DEV)
+    monkeypatch.setattr(ops, "KV_PLANES_MIN_ROWS", 0)
+    for U, B, M, shift, indexed in ((6, 6, 256, 0, False), (8, 8, 256, 4, False), (5, 8, 256, 4, True), (2, 2, 64, 1, False),
+                                    (2, 2, 4096, 1, False), (3, 3, 192, 0, False)):
+        x = torch.randn(U * M, E, generator=gen).to(DEV)
+        seq = torch.randint(0, U, (B,), generator=gen).int().to(DEV) if indexed else None
+        got = ops.qkv_attention(x, W, b, B, M, H, kv_shift=shift, seq_index=seq)
+        assert got is not None
+        qkv = ops.linear(x, W, b)
+        want = ops.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, M, M, H, kv_shift=shift, seq_index=seq)
+        assert torch.equal(got, want), (U, B, M, shift, indexed, float((got - want).abs().max()))
+    # shapes the planes do not cover fall back (None): ragged token counts, key ranges (1024 tokens: attention_key_splits)
+    assert ops.qkv_attention(torch.randn(2 * 100, E, device=DEV), W, b, 2, 100, H) is None
+    assert ops.qkv_attention(torch.randn(2 * 1024, E, device=DEV), W, b, 2, 1024, H) is None
+    monkeypatch.setattr(knobs, "KV_PLANES", False)
+    assert ops.qkv_attention(torch.randn(2 * 256, E, device=DEV), W, b, 2, 256, H) is None
