@@ -685,14 +685,15 @@ extern "C" int dpm_linear_bf16x3_kvplanes(const float *x, int ldx, const void *w
     DPM_CHECK_ARG(kv_col0 >= 0 && kv_col0 < Cout && ldo >= kv_col0 && tokens >= 64 && plane_stride >= (long long)Cout * ldw);
     auto al = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
     if (Cin % B3_KT != 0 || ldw % 8 != 0 || plane_stride % 8 != 0 || ldo % 4 != 0 || !al(w_planes) || !al(out) || !al(bias) || !al(kv_planes) ||
-        ldx % 4 != 0 || !al(x) || tokens % 64 != 0 || R % tokens != 0 || kv_col0 % 64 != 0 || Cout - kv_col0 != 64 * heads)
+        ldx % 4 != 0 || !al(x) || tokens % 64 != 0 || R % tokens != 0 || kv_col0 % 64 != 0 || Cout - kv_col0 != 64 * heads ||
+        heads % 2 != 0)   // (a 64-column tile must not straddle the K | V boundary)
         return DPM_EUNSUPPORTED;
     const KvPlanes kv{(uint16_t *)kv_planes, kv_col0, tokens, heads};
 #define DPM_B3_KV(TN, PF)                                                                                                       \
     hipLaunchKernelGGL((gemm_b3_kvp_kernel<TN, PF>), dim3(dpm_cdiv(Cout, TN), R / 64), dim3(256), 0, (hipStream_t)stream, x, ldx,   \
                        (const uint16_t *)w_planes, ldw, plane_stride, bias, out, ldo, R, Cin, Cout, kv)
     // 64-row tiles always (a tile is a key tile); the width by dpm_linear_bf16x3's rule -- the bits do not depend on it
-    if (DPM_B3_WIDE && Cout % 128 == 0 && kv_col0 % 128 == 0 && (long long)(R / 64) * (Cout / 128) >= DPM_B3_WIDE) DPM_B3_KV(128, 1);
+    if (DPM_B3_WIDE && Cout % 128 == 0 && kv_col0 % 128 == 0 && heads % 4 == 0 && (long long)(R / 64) * (Cout / 128) >= DPM_B3_WIDE) DPM_B3_KV(128, 1);
     else if ((long long)(R / 64) * dpm_cdiv(Cout, 64) <= DPM_B3_DEEP) DPM_B3_KV(64, 4);
     else DPM_B3_KV(64, 1);
 #undef DPM_B3_KV
