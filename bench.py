@@ -346,6 +346,24 @@ def run(args, guard, rank, world):
         return out
 
     ops.linear = timed_linear
+    # (since round 5 that projection hands K / V to the attention kernel as operand planes: ops.linear_kvplanes, same contraction)
+    orig_kvplanes = ops.linear_kvplanes
+    gemm_kvp = [False]
+
+    def timed_kvplanes(x, W, *a, **k):
+        if W.shape[0] != 768 or x.shape[0] != 2 * F * 256:
+            return orig_kvplanes(x, W, *a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_kvplanes(x, W, *a, **k)
+        e1.record()
+        if out is not None:
+            gemm_events.append((e0, e1))
+            gemm_flops[0] = 2 * x.shape[0] * W.shape[0] * W.shape[1]
+            gemm_kvp[0] = True
+        return out
+
+    ops.linear_kvplanes = timed_kvplanes
 
     last_gathered = [None]
 
@@ -455,7 +473,10 @@ def run(args, guard, rank, world):
             rows = gemm_flops[0] // (2 * 768 * 256)
             gx, gw, gb = torch.randn(rows, 256, device=dev), torch.randn(768, 256, device=dev) / 16, torch.randn(768, device=dev)
             go = torch.empty(rows, 768, device=dev)
-            alone["gemm_ms"] = alone_ms(lambda: orig_linear(gx, gw, gb, out=go), 20)
+            if gemm_kvp[0]:
+                alone["gemm_ms"] = alone_ms(lambda: orig_kvplanes(gx, gw, gb, 256), 20)
+            else:
+                alone["gemm_ms"] = alone_ms(lambda: orig_linear(gx, gw, gb, out=go), 20)
             del gx, gw, gb, go
         del xyz0, len0
     if not args.no_extras:
@@ -634,8 +655,10 @@ def run(args, guard, rank, world):
                 # term products per fp32 product.  `achieved` counts the EXECUTED bf16 flops against the dense bf16 peak;
                 # `fp32_equivalent` is the fp32 product it delivers against the fp32 matrix peak it would otherwise run at.
                 PEAK, mult = 2500.0, 6
-                kern = ("gemm_b3_kernel<64,128> (csrc/gemm_b3.hip: fp32 GEMM as an exact three-way bf16 split, 6 products, fp32 "
-                        f"accumulate) on the decoder's 256->768 attention projections ({rows} token rows per launch)")
+                kern = (("gemm_b3_kvp_kernel<128,1>" if gemm_kvp[0] else "gemm_b3_kernel<64,128>") +
+                        " (csrc/gemm_b3.hip: fp32 GEMM as an exact three-way bf16 split, 6 products, fp32 "
+                        f"accumulate) on the decoder's 256->768 attention projections ({rows} token rows per launch" +
+                        ("; K / V leave the epilogue as the attention kernel's bf16 operand planes" if gemm_kvp[0] else "") + ")")
                 note = ("v_mfma_f32_16x16x32_bf16, dense bf16 peak ~2500 TFLOP/s; achieved = 6 x the fp32 product's flops; timed "
                         "with HIP events on its launch stream while the other pipeline stages share the chip")
             else:

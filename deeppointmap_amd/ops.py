@@ -765,32 +765,19 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, M: int,
 KV_PLANES_MIN_ROWS = 2048
 
 
-def qkv_attention(x: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, B: int, M: int, heads: int = 8, kv_shift: int = 0,
-                  seq_index: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-    """attention(q, k, v) with q | k | v = x W^T + bias in one hand-over: x (U*M, E) holds U stored sequences of M tokens, W (3E, E)
-    is nn.MultiheadAttention's in_proj_weight; batch element b is stored sequence seq_index[b] (None: b, U == B) and attends the
-    keys / values of element (b + kv_shift) mod B.  The projection writes Q as fp32 rows and K / V as the attention kernel's bf16
-    operand planes (dpm_linear_bf16x3_kvplanes -> dpm_attention_planes): the same values split the same way as
-    linear() + attention() would, once per key tile instead of once per query block -- identical results.
-    Returns None when the shape is not covered (32-wide heads, M % 64 == 0, no mask, no key ranges; the caller runs
-    linear() + attention())."""
+def linear_kvplanes(x: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, M: int, heads: int = 8):
+    """The q | k | v projection half of qkv_attention: x (U*M, E) -> (q (U*M, E) fp32 rows, kv planes (uint8, one 24 KB image per
+    (sequence, head, 64-key tile))), or None when the shape is not covered (dpm_linear_bf16x3_kvplanes)."""
     E = x.shape[-1]
     if (not knobs.KV_PLANES or not knobs.GEMM_BF16X3 or E != heads * 32 or M % 64 != 0 or tuple(W.shape) != (3 * E, E) or
             E > knobs.BF16X3_MAX_K or x.dim() != 2 or x.shape[0] % M != 0 or x.dtype != torch.float32 or not x.is_cuda or
-            x.stride(1) != 1 or bias is None or bias.data_ptr() % 16 or attention_key_splits(B, M, M, heads, 32) > 1 or
-            x.shape[0] < KV_PLANES_MIN_ROWS):
+            x.stride(1) != 1 or bias is None or bias.data_ptr() % 16 or x.shape[0] < KV_PLANES_MIN_ROWS):
         return None
     wp = _weight_planes(W)
     if wp is None:
         return None
     planes, off, n = wp
     U = x.shape[0] // M
-    if seq_index is not None:
-        _chk(seq_index, torch.int32, "seq_index")
-        if seq_index.numel() != B:
-            raise ValueError("seq_index must hold B entries")
-    elif U != B:
-        raise ValueError("x must hold B sequences when seq_index is not given")
     lib = _lib.load()
     q = torch.empty(U * M, E, device=x.device, dtype=torch.float32)
     kv = torch.empty(lib.dpm_attention_planes_bytes(U, M, heads), device=x.device, dtype=torch.uint8)
@@ -799,10 +786,40 @@ def qkv_attention(x: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, B: int, 
     if st == -2:
         return None
     _lib.check(st, "dpm_linear_bf16x3_kvplanes")
-    out = torch.empty(B * M, E, device=x.device, dtype=torch.float32)
-    _lib.check(lib.dpm_attention_planes(_ptr(q), E, M * E, _ptr(kv), _ptr(out), E, M * E, B, M, M, heads, int(kv_shift), _ptr(seq_index),
-                                        _stream(x)), "dpm_attention_planes")
+    return q, kv
+
+
+def attention_planes(q: torch.Tensor, kv: torch.Tensor, B: int, M: int, heads: int = 8, kv_shift: int = 0,
+                     seq_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The attention half of qkv_attention: q (U*M, E) rows and the planes linear_kvplanes made of K / V -> (B*M, E)."""
+    E = q.shape[1]
+    out = torch.empty(B * M, E, device=q.device, dtype=torch.float32)
+    _lib.check(_lib.load().dpm_attention_planes(_ptr(q), E, M * E, _ptr(kv), _ptr(out), E, M * E, B, M, M, heads, int(kv_shift),
+                                                _ptr(seq_index), _stream(q)), "dpm_attention_planes")
     return out
+
+
+def qkv_attention(x: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, B: int, M: int, heads: int = 8, kv_shift: int = 0,
+                  seq_index: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """attention(q, k, v) with q | k | v = x W^T + bias in one hand-over: x (U*M, E) holds U stored sequences of M tokens, W (3E, E)
+    is nn.MultiheadAttention's in_proj_weight; batch element b is stored sequence seq_index[b] (None: b, U == B) and attends the
+    keys / values of element (b + kv_shift) mod B.  The projection writes Q as fp32 rows and K / V as the attention kernel's bf16
+    operand planes (dpm_linear_bf16x3_kvplanes -> dpm_attention_planes): the same values split the same way as
+    linear() + attention() would, once per key tile instead of once per query block -- identical results.
+    Returns None when the shape is not covered (32-wide heads, M % 64 == 0, no mask, no key ranges, at least KV_PLANES_MIN_ROWS rows;
+    the caller runs linear() + attention())."""
+    if x.dim() != 2 or M <= 0 or x.shape[0] % M != 0 or attention_key_splits(B, M, M, heads, 32) > 1:
+        return None
+    if seq_index is not None:
+        _chk(seq_index, torch.int32, "seq_index")
+        if seq_index.numel() != B:
+            raise ValueError("seq_index must hold B entries")
+    elif x.shape[0] // M != B:
+        raise ValueError("x must hold B sequences when seq_index is not given")
+    made = linear_kvplanes(x, W, bias, M, heads)
+    if made is None:
+        return None
+    return attention_planes(made[0], made[1], B, M, heads, kv_shift, seq_index)
 
 
 def l2_normalize(x: torch.Tensor) -> torch.Tensor:
