@@ -468,11 +468,12 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {
 // FOLD (round 5): the relative-coordinate term is linear in the POINT and in the CENTRE separately,
 //   W_r (p_n - c) / r  =  W_r' p_n  -  W_r' c,      W_r' = W_r / r,
 // so its point half is folded into what is gathered -- the projection GEMM's epilogue adds W_r' p_n to the projected row
-// (dpm_linear_bf16x3_rank3), the affine first level merges it into its point map (A + W_r') -- and the centre half is ONE
-// vector per centre, subtracted per row: 4 subtractions instead of 3 + 12 operations per gathered row and lane, and the
-// projected path gathers no coordinates at all.  The price is cancellation: |W_r' p| is up to |p| / r (20 at the first level)
-// times the term it replaces, i.e. a rounding error of ~1e-6 relative instead of ~1e-7 on the pre-LayerNorm values; measured on
-// the oracle with this arithmetic: descriptors move by 3.3e-6, poses by 4-5e-6 m, inlier counts unchanged.
+// (dpm_linear_bf16x3_rank3) -- and the centre half is ONE vector per centre, subtracted per row: 4 subtractions instead of 3 + 12
+// operations per gathered row and lane, and the projected path gathers no coordinates at all.  The price is cancellation:
+// |W_r' p| is up to |p| / r (17 at the projected layers of radius 0.1, which carry most of it) times the term it replaces, i.e. a
+// rounding error of ~1e-6 relative instead of ~1e-7 on the pre-LayerNorm values: feature error against the oracle 1.5e-5 median
+// instead of 4e-6, poses unchanged (DESIGN.md section 2 has the figures per radius).  The affine first level does not pay it: see
+// `FOLD && AFFINE` below.
 // CENTRED (round 5, with FOLD): the caller has moved LayerNorm's mean removal into the layer -- (I - 11^T / C) applied to W_f, W_r,
 // the bias (and, AFFINE, to the point map and its constant), so that every pre-LayerNorm row has zero mean over its channels by
 // construction: the row sum, its lane-group reduction and the subtraction (about a third of the instructions per gathered row)
@@ -507,13 +508,18 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
                 for (int d = 0; d < 3; ++d) am[v][e][d] = A[3 * c + d];
             }
         }
-    if (FOLD && AFFINE) {   // the point map takes the point half of the relative-coordinate term
+    if (FOLD && AFFINE) {
+        // The first level is affine in the point: A p + c + W_r' (p - centre) = (A centre + c) + (A + W_r') (p - centre) -- one
+        // constant per CENTRE and one 3-term chain per row on the RELATIVE coordinates: 15 operations per row and lane instead of 27,
+        // and none of the projected form's cancellation (|p| / r is 20-35 at this level, its largest: folding W_r' p into the point
+        // map and subtracting W_r' centre, as the other levels must, cost 3 operations less and most of the path's rounding error).
+        // wr <- A + W_r' (the per-row map), am stays A (the per-centre constant)
 #pragma unroll
         for (int v = 0; v < V; ++v)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int d = 0; d < 3; ++d) am[v][e][d] += wr[v][e][d];
+                for (int d = 0; d < 3; ++d) wr[v][e][d] += am[v][e][d];
     }
     const int first = (int)((xcd_chunked_id(blockIdx.x, gridDim.x) * 4 + w) * (unsigned)cpw);
     const int last = (int)min((long long)first + cpw, total);
@@ -537,8 +543,8 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
             for (int v = 0; v < V; ++v)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float k = fmaf(wr[v][e][2], cz, fmaf(wr[v][e][1], cy, wr[v][e][0] * cx));
-                    kc[v][e] = AFFINE ? cv[v][e] - k : k;
+                    if (AFFINE) kc[v][e] = fmaf(am[v][e][2], cz, fmaf(am[v][e][1], cy, fmaf(am[v][e][0], cx, cv[v][e])));   // A centre + c
+                    else kc[v][e] = fmaf(wr[v][e][2], cz, fmaf(wr[v][e][1], cy, wr[v][e][0] * cx));
                 }
         }
         // UG row passes at a time: their UG index loads go out together, then the UG x (xyz, projected row) gathers,
@@ -581,11 +587,16 @@ __global__ __launch_bounds__(256) void group_gather_ln_max_kernel(
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 float4 p4;
-                if (AFFINE) {   // FOLD: am = A + W_r', kc = c - W_r' centre
-                    p4.x = fmaf(am[v][0][2], pz, fmaf(am[v][0][1], py, fmaf(am[v][0][0], px, FOLD ? kc[v][0] : cv[v][0])));
-                    p4.y = fmaf(am[v][1][2], pz, fmaf(am[v][1][1], py, fmaf(am[v][1][0], px, FOLD ? kc[v][1] : cv[v][1])));
-                    p4.z = fmaf(am[v][2][2], pz, fmaf(am[v][2][1], py, fmaf(am[v][2][0], px, FOLD ? kc[v][2] : cv[v][2])));
-                    p4.w = fmaf(am[v][3][2], pz, fmaf(am[v][3][1], py, fmaf(am[v][3][0], px, FOLD ? kc[v][3] : cv[v][3])));
+                if (AFFINE && FOLD) {   // wr = A + W_r' on the relative coordinates, kc = A centre + c
+                    p4.x = fmaf(wr[v][0][2], rz, fmaf(wr[v][0][1], ry, fmaf(wr[v][0][0], rx, kc[v][0])));
+                    p4.y = fmaf(wr[v][1][2], rz, fmaf(wr[v][1][1], ry, fmaf(wr[v][1][0], rx, kc[v][1])));
+                    p4.z = fmaf(wr[v][2][2], rz, fmaf(wr[v][2][1], ry, fmaf(wr[v][2][0], rx, kc[v][2])));
+                    p4.w = fmaf(wr[v][3][2], rz, fmaf(wr[v][3][1], ry, fmaf(wr[v][3][0], rx, kc[v][3])));
+                } else if (AFFINE) {
+                    p4.x = fmaf(am[v][0][2], pz, fmaf(am[v][0][1], py, fmaf(am[v][0][0], px, cv[v][0])));
+                    p4.y = fmaf(am[v][1][2], pz, fmaf(am[v][1][1], py, fmaf(am[v][1][0], px, cv[v][1])));
+                    p4.z = fmaf(am[v][2][2], pz, fmaf(am[v][2][1], py, fmaf(am[v][2][0], px, cv[v][2])));
+                    p4.w = fmaf(am[v][3][2], pz, fmaf(am[v][3][1], py, fmaf(am[v][3][0], px, cv[v][3])));
                 } else {
                     p4 = pg[u][v];
                 }

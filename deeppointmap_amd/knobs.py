@@ -33,6 +33,7 @@ FUSED_LN_SMALL_ROWS = 0
 # projection GEMM's epilogue, the centre half one vector per centre.  False: the round-4 form (the relative coordinates formed per
 # gathered row).  Moves descriptors by ~3e-6 and poses by ~5e-6 m (cancellation).
 FOLD_GATHER = True
+FOLD_MIN_RADIUS = 0.0   # grouping layers with a smaller radius keep the unfolded form (|p| / r is what the fold's rounding error scales with)
 # ... with LayerNorm's mean removal moved into the layer's weights ((I - 11^T / C) W, made once per weight version): the gather
 # computes the variance from the rows as they are.  False: the folded form with the mean computed per gathered row.
 CENTRED_GATHER = True
@@ -44,7 +45,7 @@ FUSED_MATCH = True     # similarity -> dual softmax -> top-k as one operator (cs
 KV_PLANES = True
 DEDUP_FRAMES = True    # False: per-frame decoder work once per pair side instead of once per frame (new Decoder objects)
 
-_ENV = {"DPM_KV_PLANES": ("KV_PLANES", lambda v: v != "0"), "DPM_CENTRED_GATHER": ("CENTRED_GATHER", lambda v: v != "0"), "DPM_FPS_ALGO": ("FPS_ALGO", int), "DPM_NO_FUSED_LN": ("FUSED_LN", lambda v: v != "1"),
+_ENV = {"DPM_FOLD_MIN_RADIUS": ("FOLD_MIN_RADIUS", float), "DPM_KV_PLANES": ("KV_PLANES", lambda v: v != "0"), "DPM_CENTRED_GATHER": ("CENTRED_GATHER", lambda v: v != "0"), "DPM_FPS_ALGO": ("FPS_ALGO", int), "DPM_NO_FUSED_LN": ("FUSED_LN", lambda v: v != "1"),
         "DPM_DEDUP_FRAMES": ("DEDUP_FRAMES", lambda v: v != "0"), "DPM_GEMM_BF16X3": ("GEMM_BF16X3", lambda v: v == "1"), "DPM_BF16X3_MAX_K": ("BF16X3_MAX_K", int), "DPM_BF16X3_LN_MIN_K": ("BF16X3_LN_MIN_K", int), "DPM_FUSED_LN_SMALL_ROWS": ("FUSED_LN_SMALL_ROWS", int), "DPM_GEMM_LN_BF16X3": ("GEMM_LN_BF16X3", lambda v: v == "1"),
         "DPM_FUSED_MATCH": ("FUSED_MATCH", lambda v: v != "0"), "DPM_FUSED_PWCONV": ("FUSED_PWCONV", lambda v: v != "0"), "DPM_FOLD_GATHER": ("FOLD_GATHER", lambda v: v != "0")}
 

@@ -357,7 +357,7 @@ def group_mlp_max(xyz, fea, centers, idx, W, bias, gamma, beta, radius: float, g
         W2 = W.reshape(Cout, Cin + 3)
         # a packed copy of the feature columns (rows of the Conv2d weight are Cin+3 floats: not 16-byte aligned)
         Wf = _derived("feature-columns", (W,), lambda: W2[:, :Cin].contiguous())
-        if knobs.FOLD_GATHER and knobs.GEMM_BF16X3 and Cin % 32 == 0 and Cin <= knobs.BF16X3_MAX_K:
+        if knobs.FOLD_GATHER and knobs.GEMM_BF16X3 and Cin % 32 == 0 and Cin <= knobs.BF16X3_MAX_K and radius >= knobs.FOLD_MIN_RADIUS:
             # folded form (csrc/group_mlp.hip, FOLD): the projection's epilogue adds the POINT half of the relative-coordinate
             # term, the gather subtracts the centre half and reads no coordinates.  A property of the layer (its widths and the
             # tensors' layout class), never of the row count.

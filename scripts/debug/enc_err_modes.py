@@ -13,13 +13,14 @@ cfg = reduced_args()
 enc = init_procedural(Encoder(cfg)).to("cuda:0")
 sd = {k: v.detach().cpu() for k, v in enc.flat().items()}
 rng = random.Random(7)
-errs = {"plain": [], "folded": [], "centred": []}
+errs = {"plain": [], "folded": [], "centred": [], "centred r>=0.1": [], "centred r>=0.2": [], "centred r>=0.4": []}
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     B, N, start = rng.randint(1, 3), rng.randint(600, 6000), rng.randint(0, 10_000)
     pts, pad = synthetic.frames(B, N, start=start)
     _, of, _ = O.encoder_forward(sd, cfg, pts, pad, fast_fps=False)
-    for mode, (f, c) in (("plain", (False, False)), ("folded", (True, False)), ("centred", (True, True))):
-        knobs.FOLD_GATHER, knobs.CENTRED_GATHER = f, c
+    for mode, (f, c, rmin) in (("plain", (False, False, 0.0)), ("folded", (True, False, 0.0)), ("centred", (True, True, 0.0)),
+                               ("centred r>=0.1", (True, True, 0.09)), ("centred r>=0.2", (True, True, 0.19)), ("centred r>=0.4", (True, True, 0.39))):
+        knobs.FOLD_GATHER, knobs.CENTRED_GATHER, knobs.FOLD_MIN_RADIUS = f, c, rmin
         _, fea, _ = enc(pts, pad)
         errs[mode].append(float((fea.cpu() - of).abs().max()))
 for mode, e in errs.items():
