@@ -227,10 +227,11 @@ int dpm_group_gather_ln_max_folded(const float *P, const float *centers, const i
  * W' = (I - 11^T / Cout) W -- every column of [W_f | W_rel], the bias, and for the affine form the columns of A and the vector
  * cvec, have zero mean over the Cout output channels -- so that every pre-LayerNorm row (network/encoder/pointnext.py:52-61: the
  * grouped features after the 1x1 Conv2d) has zero mean by construction and the kernels compute the variance from the rows as they
- * are (no row sum, no subtraction: about a third of the per-row instructions).  The caller also multiplies channel c of the layer
+ * are (no row sum, no subtraction: about a third of the per-row instructions).  The caller THEN multiplies channel c of the layer
  * (its row of [W_f | W_rel], bias_c; A, cvec) by sign(gamma_c) (+1 for 0): gamma y + beta = |gamma| (sign(gamma) y) + beta is then
  * non-decreasing in the gathered value and commutes with the maximum over the neighbours bit for bit, so |gamma|, beta and the ReLU
- * are applied once per centre (gamma is passed as stored; the kernels take its magnitude).  PRECONDITIONS, not checked: with other
+ * are applied once per centre (gamma is passed as stored; the kernels take its magnitude; the signs leave the sum of squares, all the
+ * variance needs, as it was).  tests/test_centred_algebra.py states the identities in fp64.  PRECONDITIONS, not checked: with other
  * weights the result is a LayerNorm without its mean removal / with |gamma| for gamma.  Otherwise as dpm_group_gather_ln_max_folded / dpm_group_affine_ln_max. */
 int dpm_group_gather_ln_max_centred(const float *P, const float *centers, const int32_t *idx, const float *W_rel, int ldw_rel,
                                     const float *gamma, const float *beta, int B, int N, int S, int K, int Cout, double radius,
