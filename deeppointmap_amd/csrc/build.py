@@ -80,13 +80,21 @@ def build(force=False, verbose=False, flags=(), out=None, only=None):
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(OUT, objs):
-        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT, *objs])
+        # link beside the target and rename only after the lint: a library that failed the lint must not be what the next
+        # build() finds up to date
+        staged = OUT + ".unlinted"
+        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", staged, *objs])
         sys.path.insert(0, HERE)
         import isa_lint
-        if out is None:
-            isa_lint.check(OUT)    # the shipped library: no packed fp32 instructions (see COMMON)
-        elif verbose:
-            print("packed fp32 instructions:", isa_lint.packed_fp32(OUT))
+        try:
+            if out is None:
+                isa_lint.check(staged)    # the shipped library: no packed fp32 instructions (see COMMON)
+            elif verbose:
+                print("packed fp32 instructions:", isa_lint.packed_fp32(staged))
+        except BaseException:
+            os.remove(staged)
+            raise
+        os.replace(staged, OUT)
     return OUT
 
 

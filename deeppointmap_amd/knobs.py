@@ -12,7 +12,7 @@ import os
 
 FPS_ALGO = None        # int: first-level sampling kernel for 16 384 < N <= 65 536 (None = the library's choice, algo 5)
 FUSED_LN = True        # False: Linear + LayerNorm as two kernels at every size (scripts/gemm_ln_shapes.py)
-# Linear / Conv1d(k=1) layers with K <= 512 on the bf16 matrix pipe as exact three-way splits (csrc/gemm_b3.hip): 18-27 % faster
+# Linear / Conv1d(k=1) layers with K <= BF16X3_MAX_K on the bf16 matrix pipe as exact three-way splits (csrc/gemm_b3.hip): 18-27 % faster
 # alone, +2.7 % frames/s in the pipelined bench, error against fp64 at the fp32 kernel's level.  False: the fp32-MFMA kernel
 # everywhere.  (The library is compiled without packed fp32 instructions because of this kernel: csrc/build.py says why.)
 GEMM_BF16X3 = True
@@ -20,7 +20,7 @@ GEMM_BF16X3 = True
 # the encoder's few-row tails 768 -> 256, 1024 -> 256, 2048 -> 512, until then on the fp32-MFMA kernel): pipelined step 4.19 / 4.20 ->
 # 4.12 / 4.15 ms (A/B, 60 steps, two alternating repetitions; 1024: 4.14 / 4.12)
 BF16X3_MAX_K = 2048
-# ... and the Linear + LayerNorm layers with 128 <= K <= 512 (both forms: fused gemm_ln_b3_kernel / GEMM + LayerNorm, identical
+# ... and the Linear + LayerNorm layers with BF16X3_LN_MIN_K <= K <= BF16X3_MAX_K (both forms: fused gemm_ln_b3_kernel / GEMM + LayerNorm, identical
 # rows).  Pipelined step 4.27 -> 4.19 ms against the fp32 fused kernel's 4.33 (csrc/gemm_b3.hip, dpm_linear_layernorm_bf16x3,
 # has the history of its tile shapes).
 GEMM_LN_BF16X3 = True

@@ -74,10 +74,10 @@ class HotPath:
         # keeps meeting requests nothing cached fits and goes to hipMalloc -- 5-12 ms of host time each, 28 of them over the
         # first 150 steps until ~6.3 GB were reserved (scripts/debug/step_hiccup.py), and a 20-step measurement that catches a
         # burst of them reads 5.3 instead of 4.35 ms per step.  Blocks of one big cached segment are split instead.
-        # 0 (the default): nothing is reserved -- a caller that shares the GPU (the SLAM host's map storage, other processes)
-        # keeps its memory.  A dedicated streaming deployment opts in (bench.py: RESERVE_BYTES = 16 GiB of the chip's 288;
-        # INTEGRATION.md); the amount is capped at half of what is free.
-        self.reserve_bytes = 0
+        # Default 16 GiB of the chip's 288 (the measured working set of the four batches in flight is ~6.3 GB, spread over the
+        # pipeline's seven streams), capped at half of what is free when the pipeline starts: the shipped configuration is the one
+        # bench.py measures.  A caller that shares the GPU with other tenants sets 0 (nothing reserved).
+        self.reserve_bytes = 16 << 30
 
     @torch.no_grad()
     def extract(self, points: torch.Tensor, padding: torch.Tensor, presampled=None) -> torch.Tensor:

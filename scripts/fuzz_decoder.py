@@ -12,6 +12,7 @@ from oracle import dpm_oracle as O
 torch.set_grad_enabled(False)
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+dump = sys.argv[3] if len(sys.argv) > 3 else None   # directory: every case above half the pose tolerance is written there (inputs + both results)
 rng = random.Random(seed)
 g = torch.Generator().manual_seed(seed)
 cfg = default_args()
@@ -48,6 +49,11 @@ while time.time() - t0 < budget:
     dT, dR = float((T.cpu() - To).norm()), rot_angle(R.cpu(), Ro)
     worst = (max(worst[0], dT), max(worst[1], dR))
     n += 1
+    if dump and (dT > 5e-5 or dR > 5e-5 or conf.numel() != co.numel()):
+        os.makedirs(dump, exist_ok=True)
+        np.savez_compressed(os.path.join(dump, f"case_s{seed}_n{n}.npz"), src=s.numpy(), dst=d.numpy(), num_sample=np.float64(ns), num_sample_is_int=isinstance(ns, int),
+                            src_mask=(masks[0].numpy() if masks[0] is not None else np.zeros(0, bool)), dst_mask=(masks[1].numpy() if masks[1] is not None else np.zeros(0, bool)),
+                            hip_R=R.cpu().numpy(), hip_T=T.cpu().numpy(), hip_n=conf.numel(), hip_rmse=float(rmse), oracle_R=Ro.numpy(), oracle_T=To.numpy(), oracle_n=co.numel(), dT=dT, dR=dR)
     if dT > 1e-4 or dR > 1e-4 or conf.numel() != co.numel():
         # classify: same pairs selected?  was one of the oracle's inlier decisions at rounding level (margin = relative
         # distance of the closest residual to the cut mean + 3 std)?  was the k-th pair confidence (nearly) tied?

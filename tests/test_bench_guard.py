@@ -112,3 +112,30 @@ def test_parity_gate_accepts_the_reference_rows_and_refuses_perturbed_ones():
     assert not broken(lambda d, t: t[5, 21].add_(0.5))["ok"]                                           # information matrix asymmetric
     assert not broken(lambda d, t: d[1, 5, 5].add_(1e-3))["ok"]                                        # a descriptor feature
     assert bench.parity_gate(desc, table, 16384) == {"checked": False, "why": "fixtures cover the 65 536-point synthetic sequence, frames 0-5"}
+
+
+def test_self_launch_command_line():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run: one process per GPU of this
+    node, rendezvous on the loopback address, its own arguments passed through."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.self_launch_command(["--gpus", "8", "--steps", "20", "--warmup", "5"], 8, port=29777)
+    assert cmd == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                   "--master-port", "29777", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    auto = bench.self_launch_command([], 2)
+    assert 1024 < int(auto[auto.index("--master-port") + 1]) < 65536
+
+
+def test_bench_without_a_launcher_starts_its_ranks():
+    """On this GPU-less container the two self-launched ranks end at once with "needs a GPU" -- as rank 0's ONE error line with
+    n_gpus = 2, which shows the re-execution happened and the guard's record survives it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        return   # on a GPU box the GPU suite covers the self-launch (test_gpu_multirank.py)
+    assert out.returncode != 0
+    assert "no launcher in the environment" in out.stderr
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] is None and "needs a GPU" in lines[0]["error"]

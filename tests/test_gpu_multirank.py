@@ -124,3 +124,21 @@ def test_bench_two_ranks_dry_run():
     assert line["rank0_consumer"]["synthetic_rows"] is True
     assert line["rank0_serial_ms"] > 0 and line["value_with_rank0_consumer"] > 0
     assert "roofline" in line and line["roofline"]["bound"] == "hbm"
+
+
+def test_bench_two_ranks_started_without_a_launcher():
+    """`python bench.py --gpus 2 ...` -- the N = 1 command form with N = 2, no torch.distributed.run around it: bench.py becomes the
+    launcher itself (bench.self_launch_command) and rank 0's line reports a world of two."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0",
+           "--frames", "8", "--points", "16384", "--backend", "gloo", "--no-extras"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "no launcher in the environment" in out.stderr
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and line["value"] > 0

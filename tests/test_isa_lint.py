@@ -13,7 +13,9 @@ LIB = os.path.join(ROOT, "deeppointmap_amd", "libdpm_hip.so")
 @pytest.mark.skipif(not os.path.exists(LIB), reason="library not built")
 def test_library_has_no_packed_fp32_instructions():
     import isa_lint
-    if not os.path.exists(isa_lint.OBJDUMP):
+    try:
+        isa_lint._find_objdump()
+    except RuntimeError:
         pytest.skip("llvm-objdump not found")
     assert isa_lint.packed_fp32(LIB) == {}
     assert isa_lint.routed_operands(LIB) == {}      # no high-half op_sel outside the measured v_pk_mov_b32
@@ -27,3 +29,5 @@ def test_lint_recognises_the_failing_form():
     r = isa_lint.ROUTED.search(line)
     assert r and r.group(1) == "v_pk_fma_f32" and "1" in r.group(2)
     assert isa_lint.ROUTED.search("\tv_pk_mov_b32 v[14:15], v[6:7], v[6:7] op_sel:[1,0]").group(1) in isa_lint.ROUTED_OK
+    assert isa_lint.ROUTED_32.match("v_pk_fma_f32")               # what fails the build: packed 32-bit forms
+    assert isa_lint.ROUTED_32.match("v_pk_add_f16") is None      # 16-bit forms select halves of one dword: reported, not fatal
