@@ -10,6 +10,7 @@
 // products gives a matrix that depends on ten moments (n, sum x, y, z, xx, yy, zz, xy, xz, yz);
 // they are accumulated in fp64 and rounded once to the fp32 6x6 the reference returns.
 #include "dpm_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -364,38 +365,54 @@ __global__ __launch_bounds__(256) void nn1_match_kernel(PairArgs A, float r2, in
     const float k2 = cs * cs * (1.f - 1e-5f);
     constexpr int NR = 5;  // rows of the largest block (H <= 2), visited nearest first: 0, -1, +1, -2, +2
     int win[4] = {-1, -1, -1, -1};  // original index of the match of the quad's j-th query (-1: none within the radius)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = blk * 256 + j * 64 + quad;
-        if (i >= N1) break;  // uniform inside a quad
+    // Everything about a query that does not depend on the candidates -- the transformed point, its cell, the ten range ends of
+    // the rows around it -- is prepared ONCE, by lane j of the quad for the quad's j-th query (round 6; until then all four lanes
+    // prepared all four queries: ~80 of the kernel's ~160 vector instructions per query and lane, and four times the range-end
+    // loads), and handed to the other three lanes with quad-permute DPP moves when the query's turn comes.
+    const int i_own = blk * 256 + ql * 64 + quad;
+    float o_qx, o_qy, o_qz, o_below, o_above;
+    int o_rlo[NR], o_rhi[NR];
+    {
+        const int ic = min(i_own, N1 - 1);   // lanes past the end prepare a copy of the last query; their turn never comes
         float x, y, z;
         if (qsorted) {
-            const float4 q4 = qsorted[i];
+            const float4 q4 = qsorted[ic];
             x = q4.x, y = q4.y, z = q4.z;
         } else {
-            x = p1[i], y = p1[(size_t)N1 + i], z = p1[2 * (size_t)N1 + i];
+            x = p1[ic], y = p1[(size_t)N1 + ic], z = p1[2 * (size_t)N1 + ic];
         }
         // R @ pcd1 + T in fp32 (sgemm k-order fma chain, then the broadcast add)
-        const float qx = fmaf(Rt[2], z, fmaf(Rt[1], y, Rt[0] * x)) + Rt[9];
-        const float qy = fmaf(Rt[5], z, fmaf(Rt[4], y, Rt[3] * x)) + Rt[10];
-        const float qz = fmaf(Rt[8], z, fmaf(Rt[7], y, Rt[6] * x)) + Rt[11];
-        const float fx = (qx - lox) * inv_cs, fy = (qy - loy) * inv_cs;  // position in cell units
+        o_qx = fmaf(Rt[2], z, fmaf(Rt[1], y, Rt[0] * x)) + Rt[9];
+        o_qy = fmaf(Rt[5], z, fmaf(Rt[4], y, Rt[3] * x)) + Rt[10];
+        o_qz = fmaf(Rt[8], z, fmaf(Rt[7], y, Rt[6] * x)) + Rt[11];
+        const float fx = (o_qx - lox) * inv_cs, fy = (o_qy - loy) * inv_cs;  // position in cell units
         const float flx = floorf(fx), fly = floorf(fy);
         const int cx = (int)fmaxf(fminf(flx, 1e6f), -1e6f), cy = (int)fmaxf(fminf(fly, 1e6f), -1e6f);
         // range ends of the rows, all requested before the first is used.  Columns outside the grid collapse through the
         // clamp, rows outside the grid are empty.
         const int xa = min(max(cx - H, 0), gx), xb = min(max(cx + H + 1, 0), gx);
-        int rlo[NR], rhi[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int k = (r + 1) / 2 * ((r & 1) ? -1 : 1);  // 0, -1, +1, -2, +2
             const int yy = cy + k;
             const bool in = yy >= 0 && yy < gy && (r < 3 || H > 1);
             const int yc = min(max(yy, 0), gy - 1);
-            rlo[r] = in ? start[yc * gx + xa] : 0, rhi[r] = in ? start[yc * gx + xb] : 0;
+            o_rlo[r] = in ? start[yc * gx + xa] : 0, o_rhi[r] = in ? start[yc * gx + xb] : 0;
         }
+        o_below = fy - fly, o_above = fly + 1.f - fy;  // cell units to the lower / upper edge of the query's row
+    }
+    auto one_query = [&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        constexpr int BC = j * 0x55;  // quad_perm:[j,j,j,j]
+        const int i = blk * 256 + j * 64 + quad;
+        if (i >= N1) return;  // uniform inside a quad
+        auto from_j = [&](int v) { return __builtin_amdgcn_update_dpp(v, v, BC, 0xF, 0xF, false); };
+        auto from_jf = [&](float v) { return __int_as_float(from_j(__float_as_int(v))); };
+        const float qx = from_jf(o_qx), qy = from_jf(o_qy), qz = from_jf(o_qz);
+        int rlo[NR], rhi[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) rlo[r] = from_j(o_rlo[r]), rhi[r] = from_j(o_rhi[r]);
         const float mg = 1e-3f;
-        const float below = fy - fly, above = fly + 1.f - fy;  // cell units to the lower / upper edge of the query's row
         unsigned long long best = ~0ull;
         auto offer = [&](const float4 t, bool ok) {
             const float dx = qx - t.x, dy = qy - t.y, dz = qz - t.z;
@@ -433,6 +450,7 @@ __global__ __launch_bounds__(256) void nn1_match_kernel(PairArgs A, float r2, in
         // the rows two cells away, pruned by an exact lower bound of the distance to anything stored there
         if (H > 1) {
             const float bd = best == ~0ull ? r2 : fminf(__uint_as_float((unsigned)(best >> 32)), r2);
+            const float below = from_jf(o_below), above = from_jf(o_above);
             const float g0 = fmaxf(below + 1.f - mg, 0.f), g1 = fmaxf(above + 1.f - mg, 0.f);
             const int h3 = (g0 * g0 * k2 > bd) ? 0 : rhi[3], h4 = (g1 * g1 * k2 > bd) ? 0 : rhi[4];
             const int p3 = rlo[3] + ql, p4 = rlo[4] + ql;
@@ -451,7 +469,11 @@ __global__ __launch_bounds__(256) void nn1_match_kernel(PairArgs A, float r2, in
             best = o < best ? o : best;
         }
         win[j] = (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= r2) ? (int)(unsigned)best : -1;
-    }
+    };
+    one_query(std::integral_constant<int, 0>{});
+    one_query(std::integral_constant<int, 1>{});
+    one_query(std::integral_constant<int, 2>{});
+    one_query(std::integral_constant<int, 3>{});
     // The matched target points of the lane's (up to) four queries, fetched together.  Their moments are summed as INTEGERS
     // (coordinates rounded to 2^-qexp: 21 significant bits of the scan's largest coordinate, 3e-5 m on a 60 m scan, with
     // errors that average out over tens of thousands of terms; the reference itself sums in fp32): integer addition is

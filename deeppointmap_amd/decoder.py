@@ -403,10 +403,18 @@ class Decoder(ParamTree):
                 e["graph"] = None            # the weights moved or changed: capture again
             if self.graph_min_hits <= 0 or e["hits"] <= self.graph_min_hits or threading.active_count() > 1:
                 return None
-            live = [k for k, v in self._graphs.items() if v["graph"] is not None]
-            if len(live) >= self.graph_max:  # make room: drop the least recently used graph (its private pool is freed)
-                old = min(live, key=lambda k: self._graphs[k]["used"])
-                self._graphs.pop(old)
+            self._make_room()
+        return self._capture(e, M, N, num_sample, dev)
+
+    def _make_room(self):
+        """(under the lock) drop the least recently used graph of the calling kind (its private pool is freed); graphs captured
+        ahead of time by capture_registration_graphs are the caller's and stay"""
+        live = [k for k, v in self._graphs.items() if v["graph"] is not None and not v.get("pinned")]
+        if len(live) >= self.graph_max:
+            old = min(live, key=lambda k: self._graphs[k]["used"])
+            self._graphs.pop(old)
+
+    def _capture(self, e: dict, M: int, N: int, num_sample, dev):
         src = torch.zeros(1, self.in_channel + 3, M, device=dev, dtype=torch.float32)
         dst = torch.zeros(1, self.in_channel + 3, N, device=dev, dtype=torch.float32)
         side = torch.cuda.Stream(device=dev)
@@ -421,6 +429,43 @@ class Decoder(ParamTree):
             return None
         torch.cuda.current_stream(dev).wait_stream(side)
         e.update(graph=g, src=src, dst=dst, res=res, stamp=self._weights_stamp())
+        return e
+
+    @torch.no_grad()
+    def capture_registration_graphs(self, shapes) -> int:
+        """Capture the one-pair registration of every (M, N, num_sample) in `shapes` NOW, for replay from ANY thread -- what a caller
+        that is about to start worker threads does first (the reference's multi-thread mode drives one Decoder from several threads,
+        system/core.py:54-57, 82-109): on this runtime a capture in progress makes other threads' synchronising calls fail, so
+        captures never happen once a second thread exists, and without this call such a process runs every registration eagerly
+        (~51 launches, 0.86-1.0 ms of host time per 256 x 256 pair against 0.46 ms replayed).  Replays of one graph from different
+        threads are put in order on the device (an event per graph), results are bit-identical to the eager path.  Returns the number
+        of graphs captured.  Graphs captured here are not subject to `graph_max`; `invalidate_caches()` / new weights drop them
+        like the others (they are not captured again behind the caller's back: call this again)."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("deeppointmap_amd.Decoder runs on the GPU only (there is no CPU fallback)")
+        if threading.active_count() > 1:
+            raise RuntimeError("capture_registration_graphs must run before the process starts its worker threads")
+        n = 0
+        with torch.cuda.device(dev):
+            for M, N, num_sample in shapes:
+                k = self._num_pairs(num_sample, M, N)
+                if k < 1:
+                    continue
+                key = (M, N, k, dev.index, None)        # None: no owner thread
+                with self._graph_lock:
+                    e = self._graphs.get(key)
+                    if e is not None and e.get("graph") is not None and e["stamp"] == self._weights_stamp():
+                        continue
+                    e = self._graphs[key] = dict(hits=0, graph=None, used=0, pinned=True, lock=threading.Lock(), done=None)
+                if self._capture(e, M, N, num_sample, dev) is not None:
+                    n += 1
+        return n
+
+    def _shared_graph(self, M: int, N: int, k: int, dev):
+        e = self._graphs.get((M, N, k, dev.index, None))
+        if e is None or e.get("graph") is None or e["stamp"] != self._weights_stamp():
+            return None
         return e
 
     @torch.no_grad()
@@ -444,8 +489,20 @@ class Decoder(ParamTree):
                 M, N = src_descriptor.shape[2], dst_descriptor.shape[2]
                 k = self._num_pairs(num_sample, M, N)   # raises on an unsupported num_sample, as the eager path does
                 if k >= 1:
-                    entry = self._graph_entry((M, N, k, dev.index, threading.get_ident()), M, N, num_sample, dev)
-            if entry is not None:
+                    entry = self._shared_graph(M, N, k, dev)    # captured ahead of time for every thread, or ...
+                    if entry is None:                           # ... this thread's own, captured when the shape keeps coming back
+                        entry = self._graph_entry((M, N, k, dev.index, threading.get_ident()), M, N, num_sample, dev)
+            if entry is not None and entry.get("lock") is not None:
+                with entry["lock"]:   # one graph, several threads on their own streams: replays in order on the device too
+                    st = torch.cuda.current_stream(dev)
+                    if entry["done"] is not None:
+                        st.wait_event(entry["done"])
+                    entry["src"].copy_(src_descriptor, non_blocking=True)
+                    entry["dst"].copy_(dst_descriptor, non_blocking=True)
+                    entry["graph"].replay()
+                    res = entry["res"][0].clone()
+                    entry["done"] = st.record_event()
+            elif entry is not None:
                 entry["src"].copy_(src_descriptor, non_blocking=True)
                 entry["dst"].copy_(dst_descriptor, non_blocking=True)
                 entry["graph"].replay()

@@ -1,0 +1,129 @@
+"""The pipelined step taken apart by TIMING on the real pipeline (HotPath.submit; nothing profiled, nothing re-implemented):
+stages are switched off by handing back a cached result of theirs (wrong data flow, right timing of what remains), so every row
+is the throughput of the remaining stages in the shipped stream layout.  Then the feature + registration stages next to resident
+do-nothing workgroups with the sampling kernels' footprint (scripts/micro/occupy.hip): what the sampling stage costs the others by
+being RESIDENT (wave slots, LDS) as opposed to by what it does.  Timing waits for the pipeline's own streams only.
+Output: a markdown table (profiles/r06_step_model.md).  Needs deeppointmap_amd/csrc/build/libocc.so
+(hipcc --offload-arch=gfx950 -O3 -shared -fPIC scripts/micro/occupy.hip)."""
+import ctypes, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from deeppointmap_amd import synthetic
+from deeppointmap_amd import pipeline as pipeline_mod
+from deeppointmap_amd.config import default_args
+from deeppointmap_amd.encoder import Encoder
+from deeppointmap_amd.decoder import Decoder
+from deeppointmap_amd.pipeline import HotPath
+from deeppointmap_amd.weights import init_procedural
+
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+cfg = default_args()
+hot = HotPath(init_procedural(Encoder(cfg)).to(dev), init_procedural(Decoder(cfg)).to(dev))
+F = 64
+N_STEPS = int(os.environ.get("STEPS", "40"))
+pts, pad = synthetic.frames(F, 65536)
+pts, pad = pts.to(dev), pad.to(dev)
+pcd = (pts * 60).contiguous()
+main = torch.cuda.current_stream(dev)
+
+# ---- originals, and one cached result of each stage (taken from a normal run)
+orig = dict(presample=hot.encoder.presample, first=hot.encoder.sample_first_level, grids=pipeline_mod.ops.information_matrix_grids,
+            extract=hot.extract, register=hot.register)
+cache = {}
+
+
+def caching(name, fn):
+    def f(*a, **k):
+        out = fn(*a, **k)
+        if name not in cache:
+            cache[name] = deep_clone(out) if name == "presample" else out   # before the feature stage touches it
+        return out
+    return f
+
+
+hot.encoder.presample = caching("presample", orig["presample"])
+pipeline_mod.ops.information_matrix_grids = caching("grids", orig["grids"])
+hot.extract = caching("extract", orig["extract"])
+hot.register = caching("register", orig["register"])
+for _ in range(6):
+    hot.submit(pts, pad, pcd)
+hot.flush()
+torch.cuda.synchronize()
+
+
+def deep_clone(x):
+    """a private copy of a stage result: the feature stage consumes parts of the sampling result (tie / todo queues of the search
+    grids), so a cached one is handed out as a copy (~70 MB of device copies per batch, ~20 us)"""
+    if isinstance(x, torch.Tensor):
+        return x.clone()
+    if isinstance(x, dict):
+        return {k: deep_clone(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(deep_clone(v) for v in x)
+    return x
+
+
+def configure(G=True, Fs=True, R=True):
+    hot.encoder.presample = orig["presample"] if G else (lambda *a, **k: deep_clone(cache["presample"]))
+    hot.encoder.sample_first_level = orig["first"] if G else (lambda pl, pd: [None] * len(pl))
+    pipeline_mod.ops.information_matrix_grids = orig["grids"] if G else (lambda *a, **k: cache["grids"])
+    hot.extract = orig["extract"] if Fs else (lambda points, padding, presampled=None: cache["extract"])
+    hot.register = orig["register"] if R else (lambda *a, **k: cache["register"])
+
+
+def wait_pipeline():
+    main.synchronize()
+    for s in hot._side["geo"] + [hot._side["reg"]]:
+        s.synchronize()
+
+
+rows = []
+
+
+def timed(label, n=N_STEPS, warm=6):
+    for _ in range(warm):
+        hot.submit(pts, pad, pcd)
+    hot.flush()
+    wait_pipeline()
+    t = time.perf_counter()
+    th = 0.0
+    for _ in range(n):
+        h = time.perf_counter()
+        hot.submit(pts, pad, pcd)
+        th += time.perf_counter() - h
+    hot.flush()
+    wait_pipeline()
+    dt = (time.perf_counter() - t) / n * 1e3
+    rows.append((label, dt, th / n * 1e3))
+    print(f"{label}: {dt:.3f} ms per step (host: {th / n * 1e3:.3f} ms per submit)", flush=True)
+    return dt
+
+
+configure()
+timed("G | F | R: the whole pipeline")
+configure(R=False); timed("G | F (registration switched off)")
+configure(Fs=False); timed("G | R (features switched off)")
+configure(G=False); timed("F | R (sampling + grids switched off)")
+configure(G=False, R=False); timed("F alone")
+configure(G=False, Fs=False); timed("R alone")
+configure(Fs=False, R=False); timed("G alone (two passes in flight)")
+
+occ = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deeppointmap_amd", "csrc", "build", "libocc.so"))
+occ.launch_occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
+so = torch.cuda.Stream(device=dev)
+configure(G=False)
+for wgs, threads, lds in ((128, 1024, 33408), (128, 1024, 4736), (128, 512, 33408), (128, 512, 4736), (128, 256, 4736), (64, 1024, 33408), (256, 512, 4736)):
+    torch.cuda.synchronize()
+    n = 24
+    # resident for the whole measurement (~(6 + 24) steps of ~4 ms): ONE launch of 200 ms on a side stream, not waited for by the timing
+    occ.launch_occupy(wgs, threads, 20_000_000, lds, so.cuda_stream)
+    timed(f"F | R next to {wgs} idle workgroups of {threads} threads holding {lds} B of LDS each", n=n)
+torch.cuda.synchronize()
+configure()
+timed("G | F | R once more")
+print()
+print("| configuration | ms per 64-frame step | host ms per submit |")
+print("|---|---|---|")
+for label, dt, th in rows:
+    print(f"| {label} | {dt:.3f} | {th:.3f} |")

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import T, idx_rows_equal_as_sets, load_golden
+from conftest import T, assert_features_close, idx_rows_equal_as_sets, load_golden
 from oracle import dpm_oracle as O
 from deeppointmap_amd import synthetic
 
@@ -44,8 +44,8 @@ def test_encoder_reduced_per_stage_vs_reference(fixture, cfg_reduced):
             # every row, as a set: ties at the K-th place are resolved the way torch.topk resolves them (topk_emulate.h)
             assert idx_rows_equal_as_sets(got.reshape(-1, v.shape[-1]), v.reshape(-1, v.shape[-1])).all(), k
         elif k.endswith(".out"):
-            np.testing.assert_allclose(tr[k].cpu().numpy(), v, rtol=0, atol=3e-4, err_msg=k)
-    np.testing.assert_allclose(fea.cpu().numpy(), g["fea"], rtol=0, atol=3e-4)
+            assert_features_close(tr[k].cpu().numpy(), v, f"{fixture} {k}")
+    assert_features_close(fea.cpu().numpy(), g["fea"], f"{fixture} descriptors")
 
 
 @pytest.mark.parametrize("tag", ["synthetic0", "synthetic1", "kitti0", "kitti1"])
@@ -59,7 +59,7 @@ def test_encoder_full_descriptors_vs_reference(tag, cfg_full):
     coor, fea, mask = enc(p.to(DEV), torch.zeros(1, p.shape[2], dtype=torch.bool, device=DEV))
     assert tuple(coor.shape) == (1, 3, 256) and tuple(fea.shape) == (1, 128, 256) and not bool(mask.any())
     assert np.array_equal(coor[0].cpu().numpy(), g[tag + ".coor"])
-    np.testing.assert_allclose(fea[0].cpu().numpy(), g[tag + ".fea"], rtol=0, atol=3e-4)
+    assert_features_close(fea[0].cpu().numpy(), g[tag + ".fea"], f"encoder_full {tag} descriptors")
 
 
 def test_encoder_batch_equals_single_frames(cfg_full):
@@ -140,7 +140,7 @@ def test_encoder_extra_input_channels_vs_oracle(cfg_reduced):
     coor, fea, mask = enc(pts, pad)
     wc, wf, wm = O.encoder_forward(sd, cfg, pts, pad)
     assert torch.equal(coor.cpu(), wc) and torch.equal(mask.cpu(), wm)
-    np.testing.assert_allclose(fea.cpu().numpy(), wf.numpy(), rtol=0, atol=3e-4)
+    assert_features_close(fea.cpu().numpy(), wf.numpy(), "in_channel=4 descriptors vs oracle")
     # the extra channel really reaches the descriptors
     pts2 = pts.clone()
     pts2[:, 3] = 1.0 - pts2[:, 3]

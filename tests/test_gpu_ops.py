@@ -506,6 +506,8 @@ def test_folded_grouping_layers_against_the_unfolded_form(ops, monkeypatch):
     from deeppointmap_amd import knobs
     gen = torch.Generator().manual_seed(41)
     d = lambda t: t.to(DEV)
+    shipped_min_radius = knobs.FOLD_MIN_RADIUS
+    monkeypatch.setattr(knobs, "FOLD_MIN_RADIUS", 0.0)     # the fold at EVERY radius (shipped: only radii >= 0.2, knobs.py)
     for Cin, Cout, K, radius in ((32, 32, 32, 0.05), (32, 64, 32, 0.1), (64, 128, 32, 0.2), (128, 256, 32, 0.4), (256, 512, 16, 0.8)):
         B, N, S = 2, 3000, 400
         xyz = d(torch.rand(B, N, 3, generator=gen) * 2 - 1)                      # coordinates in the unit box, as the encoder's
@@ -522,6 +524,12 @@ def test_folded_grouping_layers_against_the_unfolded_form(ops, monkeypatch):
         assert not torch.equal(folded, plain)                                      # (two different kernels ran)
         torch.testing.assert_close(folded, plain, rtol=0, atol=2e-5)
         torch.testing.assert_close(folded, generic, rtol=1e-4, atol=1e-4)
+        # ... and the shipped threshold keeps the small radii on the unfolded form, bit for bit
+        monkeypatch.setattr(knobs, "FOLD_GATHER", True)
+        monkeypatch.setattr(knobs, "FOLD_MIN_RADIUS", shipped_min_radius)
+        shipped = ops.group_mlp_max(xyz, fea, ctr, idx, W, bias, gm, bt, radius)
+        assert torch.equal(shipped, folded if radius >= shipped_min_radius else plain)
+        monkeypatch.setattr(knobs, "FOLD_MIN_RADIUS", 0.0)
     # the affine first level folds inside its kernel: against the per-neighbour feature evaluation
     B, N, S, K = 2, 5000, 600, 32
     xyz = d(torch.rand(B, N, 3, generator=gen) * 2 - 1)
@@ -543,6 +551,7 @@ def test_centred_grouping_layers_against_the_folded_form(ops, monkeypatch):
     from deeppointmap_amd import knobs
     gen = torch.Generator().manual_seed(43)
     d = lambda t: t.to(DEV)
+    monkeypatch.setattr(knobs, "FOLD_MIN_RADIUS", 0.0)     # the centred form exists on folded layers: fold at every radius here
     for Cin, Cout, K, radius, offset in ((32, 32, 32, 0.05, 0.0), (32, 64, 32, 0.1, 3.0), (64, 128, 32, 0.2, 0.0), (128, 256, 32, 0.4, 1.0),
                                          (256, 512, 16, 0.8, 0.0)):
         B, N, S = 2, 3000, 400
