@@ -470,6 +470,24 @@ def run(args, guard, rank, world):
     # ---- extra measurements, outside the timed region and never part of `value` ---------------------------------
     extras = {}
     alone = {}
+    if not args.no_extras and not args.no_pipeline:
+        # (-1) the same steps again for a few seconds (round-5 review: the timed region of the default run is 0.09 s, too short for a
+        #      device monitor sampling beside the run to see a busy GPU): frames/s over >= 2.5 s with the parity gate on its last step.
+        #      Every rank runs it (the steps carry the gather).
+        n_sus = max(args.steps, int(2.5 / max(dt / args.steps, 1e-4)) + 1)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        drain()
+        fence()
+        sus = time.perf_counter() - t1
+        if rank == 0:
+            gd2, gt2 = last_gathered[0] if last_gathered[0] is not None else (None, None)
+            g2 = parity_gate(gd2, gt2, N) if gd2 is not None else {"checked": False}
+            extras["sustained"] = {"steps": n_sus, "seconds": round(sus, 2), "value": round(world * F * n_sus / sus, 1), "unit": "frames/s",
+                                   "ms_per_step": round(sus / n_sus * 1e3, 3), "clock": "rank 0", "parity_gate_ok": g2.get("ok"),
+                                   "max_dT_m": g2.get("max_dT_m"), "descriptor_max_err": g2.get("descriptor_max_err")}
     if not args.no_extras and rank == 0:
         # (0) the two roofline kernels ALONE on the chip (the figures inside the timed region include what the other
         #     pipeline stages cost them): first-stage sampling of one 64-frame batch, and the 256 -> 768 projection

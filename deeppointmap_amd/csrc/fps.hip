@@ -232,6 +232,13 @@ __global__ __launch_bounds__(FB) void fps_bucket_sort_kernel(const float *__rest
 // parallel, each wave working only on its OWN buckets -- no work list, no atomics, and one barrier per round
 // (the cross-wave arg-max exchange, double-buffered by round parity).
 // ------------------------------------------------------------------------------------------
+// REGCL (experiment of round 6, -DDPM_FPS_REGCL=1; profiles/r06_fps.md): the running `closest` of the wave's 64 buckets in 64 registers
+// per lane (bucket slot l of the wave = register l, wave-uniform index) instead of the workspace array: one global load per touched
+// bucket instead of two, no store.
+#ifndef DPM_FPS_REGCL
+#define DPM_FPS_REGCL 0
+#endif
+template <bool REGCL>
 __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict__ xyz_all,
                                                         const int32_t *__restrict__ lengths, int N, int K,
                                                         const float4 *__restrict__ pts_all,
@@ -280,6 +287,23 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
         x1 = wave_max_dpp(x1), y1 = wave_max_dpp(y1), z1 = wave_max_dpp(z1);
         if (lane == l) bx0 = x0, by0 = y0, bz0 = z0, bx1 = x1, by1 = y1, bz1 = z1;
     }
+    // two 32-wide register vectors (a C array indexed by a run-time value goes to scratch memory; a vector element addressed by a
+    // wave-uniform index is one v_movrels / v_movreld through M0)
+    typedef float f32x32 __attribute__((ext_vector_type(32)));
+    f32x32 cl_lo, cl_hi;
+    if (REGCL) {
+#pragma unroll
+        for (int l = 0; l < 32; ++l) {
+            const int qa = (l * NW + w) * 64 + lane, qb = ((l + 32) * NW + w) * 64 + lane;
+            cl_lo[l] = qa < len ? closest[qa] : -1.f;   // +inf for points, -1 for the packing's unused slots (written by the sort)
+            cl_hi[l] = qb < len ? closest[qb] : -1.f;
+        }
+    }
+    auto cl_get = [&](int l) -> float { return l < 32 ? cl_lo[l & 31] : cl_hi[l & 31]; };   // l is wave-uniform: a scalar branch
+    auto cl_put = [&](int l, float v) {
+        if (l < 32) cl_lo[l & 31] = v;
+        else cl_hi[l & 31] = v;
+    };
     const int s0 = start ? min(max(start[b], 0), max(true_len - 1, 0)) : 0;  // `random_start_point` (utils.py:248)
     if (t == 0) {
         idx[0] = s0;  // slot 0 is index 0 even for an empty frame (utils.py:249-250)
@@ -334,11 +358,11 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
             // lanes are masked out of the values below): no exec-mask juggling around the four loads
             const int q0c = min(q0, len - 1), q1c = min(q1, len - 1);
             const float4 p0 = pts[q0c];
-            const float c0 = closest[q0c];
+            const float c0 = REGCL ? cl_get(l0) : closest[q0c];
             float4 p1;
             float c1;
-            if (two) p1 = pts[q1c], c1 = closest[q1c];  // wave-uniform: a scalar branch; an unused load would still
-                                                        // have to be waited for before its registers are reused
+            if (two) p1 = pts[q1c], c1 = REGCL ? cl_get(l1) : closest[q1c];  // wave-uniform: a scalar branch; an unused load would still
+                                                                        // have to be waited for before its registers are reused
             if (first && !keep) {
                 // ... and while they are in flight: the best among this wave's UNCHANGED buckets
                 wl = wave_argbest(act ? -1.f : bmax, bidx, wv);
@@ -349,7 +373,8 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                 const int o0 = ok0 ? __float_as_int(p0.w) : 0x7fffffff;
                 const float d = sqdist(sx, sy, sz, p0.x, p0.y, p0.z);
                 const bool lt = ok0 && d < c0;
-                if (lt) closest[q0] = d;
+                if (REGCL) cl_put(l0, lt ? d : c0);
+                else if (lt) closest[q0] = d;
                 const float v0 = lt ? d : (ok0 ? c0 : -1.f);
                 float vmax;
                 const int L = wave_argbest(v0, o0, vmax);
@@ -362,7 +387,8 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                 const int o1 = ok1 ? __float_as_int(p1.w) : 0x7fffffff;
                 const float d = sqdist(sx, sy, sz, p1.x, p1.y, p1.z);
                 const bool lt = ok1 && d < c1;
-                if (lt) closest[q1] = d;
+                if (REGCL) cl_put(l1, lt ? d : c1);
+                else if (lt) closest[q1] = d;
                 const float v1 = lt ? d : (ok1 ? c1 : -1.f);
                 float vmax;
                 const int L = wave_argbest(v1, o1, vmax);
@@ -469,7 +495,7 @@ static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t 
         float4 *tmp = (float4 *)(((uintptr_t)(closest + (size_t)B * slots) + 255) & ~(uintptr_t)255);
         const int rc = dpm_fps_str_bucket_sort(xyz, lengths, B, N, pts, closest, tmp, st);
         if (rc != DPM_OK) return rc;
-        hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
+        hipLaunchKernelGGL(fps_bucket_kernel<DPM_FPS_REGCL != 0>, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
                            new_lengths, slots, start);
         return dpm_launch_status();
     }
@@ -483,7 +509,7 @@ static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t 
 #endif
         float *closest = (float *)(pts + (size_t)B * N);
         hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, pts, closest);
-        hipLaunchKernelGGL(fps_bucket_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx,
+        hipLaunchKernelGGL(fps_bucket_kernel<DPM_FPS_REGCL != 0>, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx,
                            new_xyz, new_lengths, 0, start);
         return dpm_launch_status();
     }

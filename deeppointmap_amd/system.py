@@ -159,10 +159,10 @@ class SlamSystem:
     def MT_Init(self):
         # the one device-side preparation of the mode: registrations replay captured graphs, and captures cannot happen once the
         # worker threads exist (Decoder.capture_registration_graphs) -- the odometer's pair and scan-to-map against 1 .. 16 scans
-        if threading.active_count() == 1 and getattr(self.decoder, "graph_min_hits", 0) > 0:
+        if threading.active_count() == 1 and getattr(self.dpm_decoder, "graph_min_hits", 0) > 0:
             enc = self.args.encoder
             P, a = enc.npoint[len(enc.npoint) - 1 - enc.upsample_layers], self.backend.args   # descriptors per scan (256)
-            self.decoder.capture_registration_graphs(
+            self.dpm_decoder.capture_registration_graphs(
                 [(P, P, a["registration_sample_odometer"])] + [(P * j, P, a["registration_sample_mapping"]) for j in range(1, 17)])
         q_in, q_mid = Queue(), Queue()
         errors: List[BaseException] = []

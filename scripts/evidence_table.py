@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
 """Per-kernel evidence table: duration (kernel trace), L2-fabric bytes (PMC FETCH_SIZE / WRITE_SIZE passes) -> GB/s,
 MFMA busy cycles -> utilisation.  usage: evidence_table.py <trace.db> <fetch.db> <write.db> <mfma.db> <steps_in_trace>"""
+import os
 import re
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _steady import steady_clause
+
 trace, fetch, write, mfma = (sqlite3.connect(p) for p in sys.argv[1:5])
 short = lambda n: re.sub(r"\(.*$", "", re.sub(r"\(anonymous namespace\)::", "", n))[:48]
-dur = {short(n): (c, t) for n, c, t in trace.execute("select name, count(*), sum(duration) from kernels group by name")}
+dur = {short(n): (c, t) for n, c, t in trace.execute(f"select name, count(*), sum(duration) from kernels where 1 {steady_clause(trace)} group by name")}
 
 
 def pmc(db, ctr):
     """name -> (dispatches in that PMC run, rows, summed value)"""
     return {short(n): (d, c, v) for n, d, c, v in db.execute(
-        "select name, count(distinct dispatch_id), count(*), sum(counter_value) from pmc_events where counter_name=? "
+        f"select name, count(distinct dispatch_id), count(*), sum(counter_value) from pmc_events where counter_name=? {steady_clause(db, 'pmc_events')} "
         "group by name", (ctr,))}
 
 

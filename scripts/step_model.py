@@ -33,6 +33,18 @@ orig = dict(presample=hot.encoder.presample, first=hot.encoder.sample_first_leve
 cache = {}
 
 
+def deep_clone(x):
+    """a private copy of a stage result: the feature stage consumes parts of the sampling result (tie / todo queues of the search
+    grids), so a cached one is handed out as a copy (~70 MB of device copies per batch, ~20 us)"""
+    if isinstance(x, torch.Tensor):
+        return x.clone()
+    if isinstance(x, dict):
+        return {k: deep_clone(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(deep_clone(v) for v in x)
+    return x
+
+
 def caching(name, fn):
     def f(*a, **k):
         out = fn(*a, **k)
@@ -50,18 +62,6 @@ for _ in range(6):
     hot.submit(pts, pad, pcd)
 hot.flush()
 torch.cuda.synchronize()
-
-
-def deep_clone(x):
-    """a private copy of a stage result: the feature stage consumes parts of the sampling result (tie / todo queues of the search
-    grids), so a cached one is handed out as a copy (~70 MB of device copies per batch, ~20 us)"""
-    if isinstance(x, torch.Tensor):
-        return x.clone()
-    if isinstance(x, dict):
-        return {k: deep_clone(v) for k, v in x.items()}
-    if isinstance(x, (list, tuple)):
-        return type(x)(deep_clone(v) for v in x)
-    return x
 
 
 def configure(G=True, Fs=True, R=True):
