@@ -238,6 +238,27 @@ __global__ __launch_bounds__(FB) void fps_bucket_sort_kernel(const float *__rest
 #ifndef DPM_FPS_REGCL
 #define DPM_FPS_REGCL 0
 #endif
+// DPM_FPS_NT (round 6, profiles/r06_step_model.md): the rounds' re-reads of the frame state with the non-temporal cache policy.  A frame's
+// state is 1.3 MB, sixteen frames share an XCD's 4 MB L2 while two launches are in flight, and the rounds stream through all of it
+// every few tens of microseconds: with the default policy they keep evicting what the feature and registration kernels re-use.
+//   bit 0: the point loads (16 B x 64 per touched bucket), bit 1: the `closest` loads and stores.
+#ifndef DPM_FPS_NT
+#define DPM_FPS_NT 0
+#endif
+typedef float fps_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 fps_load_point(const float4 *p) {
+    if (DPM_FPS_NT & 1) {
+        const fps_f4 v = __builtin_nontemporal_load((const fps_f4 *)p);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+__device__ __forceinline__ float fps_load_closest(const float *p) { return (DPM_FPS_NT & 2) ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void fps_store_closest(float *p, float v) {
+    if (DPM_FPS_NT & 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 template <bool REGCL>
 __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict__ xyz_all,
                                                         const int32_t *__restrict__ lengths, int N, int K,
@@ -357,11 +378,11 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
             // unconditional loads from a clamped slot (a ragged last bucket re-reads the frame's last point; its
             // lanes are masked out of the values below): no exec-mask juggling around the four loads
             const int q0c = min(q0, len - 1), q1c = min(q1, len - 1);
-            const float4 p0 = pts[q0c];
-            const float c0 = REGCL ? cl_get(l0) : closest[q0c];
+            const float4 p0 = fps_load_point(pts + q0c);
+            const float c0 = REGCL ? cl_get(l0) : fps_load_closest(closest + q0c);
             float4 p1;
             float c1;
-            if (two) p1 = pts[q1c], c1 = REGCL ? cl_get(l1) : closest[q1c];  // wave-uniform: a scalar branch; an unused load would still
+            if (two) p1 = fps_load_point(pts + q1c), c1 = REGCL ? cl_get(l1) : fps_load_closest(closest + q1c);  // wave-uniform: a scalar branch; an unused load would still
                                                                         // have to be waited for before its registers are reused
             if (first && !keep) {
                 // ... and while they are in flight: the best among this wave's UNCHANGED buckets
@@ -374,7 +395,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                 const float d = sqdist(sx, sy, sz, p0.x, p0.y, p0.z);
                 const bool lt = ok0 && d < c0;
                 if (REGCL) cl_put(l0, lt ? d : c0);
-                else if (lt) closest[q0] = d;
+                else if (lt) fps_store_closest(closest + q0, d);
                 const float v0 = lt ? d : (ok0 ? c0 : -1.f);
                 float vmax;
                 const int L = wave_argbest(v0, o0, vmax);
@@ -388,7 +409,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                 const float d = sqdist(sx, sy, sz, p1.x, p1.y, p1.z);
                 const bool lt = ok1 && d < c1;
                 if (REGCL) cl_put(l1, lt ? d : c1);
-                else if (lt) closest[q1] = d;
+                else if (lt) fps_store_closest(closest + q1, d);
                 const float v1 = lt ? d : (ok1 ? c1 : -1.f);
                 float vmax;
                 const int L = wave_argbest(v1, o1, vmax);
@@ -495,6 +516,7 @@ static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t 
         float4 *tmp = (float4 *)(((uintptr_t)(closest + (size_t)B * slots) + 255) & ~(uintptr_t)255);
         const int rc = dpm_fps_str_bucket_sort(xyz, lengths, B, N, pts, closest, tmp, st);
         if (rc != DPM_OK) return rc;
+        if (dpm_knob("DPM_ABLATE_FPS_ROUNDS", 0)) return dpm_launch_status();  // -DDPM_EXPERIMENT builds only: the packing without the rounds (scripts/step_model.py)
         hipLaunchKernelGGL(fps_bucket_kernel<DPM_FPS_REGCL != 0>, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
                            new_lengths, slots, start);
         return dpm_launch_status();

@@ -105,6 +105,51 @@ timed("G | F | R: the whole pipeline")
 configure(R=False); timed("G | F (registration switched off)")
 configure(Fs=False); timed("G | R (features switched off)")
 configure(G=False); timed("F | R (sampling + grids switched off)")
+# the sampling stage split in two: its first-level sampling (Sort-Tile-Recursive packing + the 4095 rounds, 128 latency-bound
+# workgroups in flight) and everything else it launches (staging, lower levels, search grids of the neighbour queries and of the
+# information matrix: ~0.5 ms of kernel time per batch, partly chip-filling)
+import deeppointmap_amd.encoder as enc_mod
+real_fps = enc_mod.ops.fps
+first_level = {}
+
+
+def fps_cached(xyz, lengths, K, algo=0):
+    key = (tuple(xyz.shape), K)
+    if key not in first_level:
+        first_level[key] = real_fps(xyz, lengths, K, algo)
+    return tuple(t.clone() for t in first_level[key]) if xyz.shape[1] == 65536 else real_fps(xyz, lengths, K, algo)
+
+
+configure()
+enc_mod.ops.fps = fps_cached
+timed("G without its first-level sampling | F | R")
+enc_mod.ops.fps = real_fps
+configure(G=False)
+pre0 = cache["presample"]
+
+
+def presample_sampling_only(*a, **k):
+    real_fps(pre0["xyz"], pre0["lengths"], cfg.encoder.npoint[0])
+    return deep_clone(cache["presample"])
+
+
+hot.encoder.presample = presample_sampling_only
+timed("first-level sampling only | F | R")
+for nf in (32, 16, 8):   # fewer sampling workgroups in flight: how the price scales with their number
+    xs, ls = pre0["xyz"][:nf].contiguous(), pre0["lengths"][:nf].contiguous()
+
+    def presample_some(*a, _xs=xs, _ls=ls, **k):
+        real_fps(_xs, _ls, cfg.encoder.npoint[0])
+        return deep_clone(cache["presample"])
+
+    hot.encoder.presample = presample_some
+    timed(f"first-level sampling of {nf} of the 64 frames only | F | R")
+hot.encoder.presample = presample_sampling_only
+from deeppointmap_amd import _lib
+if _lib.experimental():   # DPM_LIB = a -DDPM_EXPERIMENT build: the packing kernels without the 4095 rounds
+    os.environ["DPM_ABLATE_FPS_ROUNDS"] = "1"
+    timed("first-level packing only (no rounds) | F | R")
+    del os.environ["DPM_ABLATE_FPS_ROUNDS"]
 configure(G=False, R=False); timed("F alone")
 configure(G=False, Fs=False); timed("R alone")
 configure(Fs=False, R=False); timed("G alone (two passes in flight)")
@@ -119,6 +164,17 @@ for wgs, threads, lds in ((128, 1024, 33408), (128, 1024, 4736), (128, 512, 3340
     # resident for the whole measurement (~(6 + 24) steps of ~4 ms): ONE launch of 200 ms on a side stream, not waited for by the timing
     occ.launch_occupy(wgs, threads, 20_000_000, lds, so.cuda_stream)
     timed(f"F | R next to {wgs} idle workgroups of {threads} threads holding {lds} B of LDS each", n=n)
+# ... and next to workgroups of the sampling kernel's shape that DO a chosen part of a round every 1.5 us (scripts/micro/occupy.hip):
+# which activity is it that costs the other stages time?
+occ.launch_active.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
+nblk = 128 * 1024                                        # 128 frames x 1024 buckets of 1 KB (+ 256 B of `closest` each)
+state = torch.zeros(nblk * (1024 + 256) // 4, device=dev)
+sink = torch.zeros(4, device=dev)
+for mode, what in ((1, "~40 dependent vector instructions per wave"), (2, "one bucket-sized load + closest load / store per wave"),
+                   (4, "the exchange: LDS write, barrier, two dependent LDS reads"), (7, "all three")):
+    torch.cuda.synchronize()
+    occ.launch_active(128, 1024, 20_000_000, 33408, mode, 150, state.data_ptr(), nblk, sink.data_ptr(), so.cuda_stream)
+    timed(f"F | R next to 128 workgroups of 1024 threads doing, every 1.5 us: {what}", n=24)
 torch.cuda.synchronize()
 configure()
 timed("G | F | R once more")
