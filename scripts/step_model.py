@@ -79,6 +79,33 @@ def wait_pipeline():
 
 
 rows = []
+# ---- probes: four operators of the feature / registration stages timed with HIP events on their own stream INSIDE every
+# configuration: do the kernels themselves get slower next to the sampling stage, or do gaps open between them?
+import deeppointmap_amd.ops as ops_mod
+probe_events = {}
+
+
+def probe(name, pick=lambda *a, **k: True):
+    fn = getattr(ops_mod, name)
+
+    def f(*a, **k):
+        if not probing[0] or not pick(*a, **k):
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a, **k)
+        e1.record()
+        probe_events.setdefault(name, []).append((e0, e1))
+        return out
+    setattr(ops_mod, name, f)
+
+
+probing = [False]
+probe("group_mlp_max_from_xyz")                                                    # F: the first-level gather (1 per batch)
+probe("knn_hybrid", lambda points, lengths, centers, K, *a, **k: points.shape[1] == 65536)   # F: the first-level neighbour search
+probe("linear_kvplanes", lambda x, W, *a, **k: W.shape[0] == 768 and x.shape[0] == 2 * F * 256)  # R: the 256 -> 768 projections
+probe("information_matrix_batched")                                                # R: the nearest-neighbour search + moments
+PROBES = ("group_mlp_max_from_xyz", "knn_hybrid", "linear_kvplanes", "information_matrix_batched")
 
 
 def timed(label, n=N_STEPS, warm=6):
@@ -86,6 +113,8 @@ def timed(label, n=N_STEPS, warm=6):
         hot.submit(pts, pad, pcd)
     hot.flush()
     wait_pipeline()
+    probe_events.clear()
+    probing[0] = True
     t = time.perf_counter()
     th = 0.0
     for _ in range(n):
@@ -95,8 +124,10 @@ def timed(label, n=N_STEPS, warm=6):
     hot.flush()
     wait_pipeline()
     dt = (time.perf_counter() - t) / n * 1e3
-    rows.append((label, dt, th / n * 1e3))
-    print(f"{label}: {dt:.3f} ms per step (host: {th / n * 1e3:.3f} ms per submit)", flush=True)
+    probing[0] = False
+    pr = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) * 1e3 if v else float("nan")) for k, v in ((p, probe_events.get(p, [])) for p in PROBES)}
+    rows.append((label, dt, th / n * 1e3, pr))
+    print(f"{label}: {dt:.3f} ms per step (host: {th / n * 1e3:.3f} ms per submit); probes us: " + ", ".join(f"{k} {v:.0f}" for k, v in pr.items()), flush=True)
     return dt
 
 
@@ -135,6 +166,24 @@ def presample_sampling_only(*a, **k):
 
 hot.encoder.presample = presample_sampling_only
 timed("first-level sampling only | F | R")
+# the same launches at the same places of the host's enqueue order, but on two OTHER streams: the feature stage no longer waits for them
+side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+side_n = [0]
+
+
+def presample_sampling_unordered(*a, **k):
+    st = side[side_n[0] % 2]
+    side_n[0] += 1
+    with torch.cuda.stream(st):
+        real_fps(pre0["xyz"], pre0["lengths"], cfg.encoder.npoint[0])
+    return deep_clone(cache["presample"])
+
+
+hot.encoder.presample = presample_sampling_unordered
+timed("first-level sampling enqueued at the same places but on streams of its own (nothing waits for it) | F | R")
+for s_ in side:
+    s_.synchronize()
+hot.encoder.presample = presample_sampling_only
 for nf in (32, 16, 8):   # fewer sampling workgroups in flight: how the price scales with their number
     xs, ls = pre0["xyz"][:nf].contiguous(), pre0["lengths"][:nf].contiguous()
 
@@ -175,11 +224,27 @@ for mode, what in ((1, "~40 dependent vector instructions per wave"), (2, "one b
     torch.cuda.synchronize()
     occ.launch_active(128, 1024, 20_000_000, 33408, mode, 150, state.data_ptr(), nblk, sink.data_ptr(), so.cuda_stream)
     timed(f"F | R next to 128 workgroups of 1024 threads doing, every 1.5 us: {what}", n=24)
+# ... and next to the REAL first-level sampling, launched back to back on two side streams that nothing waits for: is the price of
+# the sampling stage paid for sharing the chip with it, or for depending on it?
+torch.cuda.synchronize()
+sx, sy = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+for i in range(2 * 22):   # 22 launches of ~6 ms per stream: longer than the measurement
+    with torch.cuda.stream(sx if i % 2 == 0 else sy):
+        real_fps(pre0["xyz"], pre0["lengths"], cfg.encoder.npoint[0])
+timed("F | R next to the real first-level sampling (two launches in flight) that nothing waits for", n=24)
 torch.cuda.synchronize()
 configure()
 timed("G | F | R once more")
+# the sampling stage of batch i is enqueued behind `geo.wait_stream(caller's stream)` (inputs the caller may have produced there):
+# with the feature stage of batch i - 3 at the head of that stream, G(i) cannot start before F(i - 3) has finished.  Without it:
+for g_ in hot._side["geo"]:
+    g_.wait_stream = lambda s: None
+timed("G | F | R, the sampling streams NOT waiting for the caller's stream (inputs resident)")
+configure(R=False); timed("G | F, the same")
+configure(Fs=False); timed("G | R, the same")
+configure()
 print()
-print("| configuration | ms per 64-frame step | host ms per submit |")
-print("|---|---|---|")
-for label, dt, th in rows:
-    print(f"| {label} | {dt:.3f} | {th:.3f} |")
+print("| configuration | ms per 64-frame step | host ms per submit | first-level gather us | first-level neighbour search us | 256 -> 768 projection us | information matrices us |")
+print("|---|---|---|---|---|---|---|")
+for label, dt, th, pr in rows:
+    print(f"| {label} | {dt:.3f} | {th:.3f} | " + " | ".join(f"{pr[p]:.0f}" for p in PROBES) + " |")
