@@ -259,7 +259,13 @@ __device__ __forceinline__ void fps_store_closest(float *p, float v) {
     else *p = v;
 }
 
-template <bool REGCL>
+// Timing-only ablations of a round (-DDPM_FPS_ABLATE=bits, WRONG RESULTS; profiles/r06_step_model.md asks which part of a round the
+// kernels next to it pay for): bit 0 = no bucket updates (no global loads / stores, no per-bucket arg-max), bit 1 = no exchange (no
+// LDS, no barrier: every wave follows its own candidate).  -DDPM_FPS_PACE=n holds every round until n ticks of the 100 MHz clock
+// after the previous one, so that all variants keep their workgroups resident equally long.
+// Both are kernel arguments of the EXPERIMENT instantiation only (run-time values of -DDPM_EXPERIMENT builds: DPM_FPS_ABLATE, DPM_FPS_PACE in
+// the environment); the shipped instantiation has them folded to 0.
+template <bool REGCL, bool EXP = false>
 __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict__ xyz_all,
                                                         const int32_t *__restrict__ lengths, int N, int K,
                                                         const float4 *__restrict__ pts_all,
@@ -267,7 +273,12 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                                                         int32_t *__restrict__ idx_all,
                                                         float *__restrict__ new_xyz_all,
                                                         int32_t *__restrict__ new_len, int slots,
-                                                        const int32_t *__restrict__ start = nullptr) {
+                                                        const int32_t *__restrict__ start = nullptr, int exp_ablate = 0,
+                                                        int exp_pace = 0) {
+    const int DPM_FPS_ABLATE = EXP ? exp_ablate : 0, DPM_FPS_PACE = EXP ? exp_pace : 0;
+#ifdef DPM_FPS_PRIO   // wave priority of the sampling waves (A/B builds; round 3 and round 6 measured no effect on the rounds)
+    __builtin_amdgcn_s_setprio(DPM_FPS_PRIO);
+#endif
     constexpr int NW = FB / 64;
 #ifndef DPM_FPS_OB
 #define DPM_FPS_OB 2048
@@ -344,6 +355,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
 #ifdef DPM_FPS_STATS
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = clock64();
 #endif
+    const long long pace0 = DPM_FPS_PACE ? (long long)wall_clock64() : 0;
     for (int r = 1; r < kn; ++r) {
         FPS_T(5);
         // ---- which of my wave's buckets can change?  box distance with the point-distance expression:
@@ -354,6 +366,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                     cz = __builtin_amdgcn_fmed3f(sz, bz0, bz1);
         const bool act = sqdist(sx, sy, sz, cx, cy, cz) < bmax;
         unsigned long long m = __ballot(act);
+        if (DPM_FPS_ABLATE & 1) m = 0;
         // Bucket maxima only ever fall.  If the bucket that held this wave's best is not touched this round, the
         // wave's best is what it was -- whatever happens to the touched ones -- and nothing needs re-deriving.
         const bool keep = wv >= 0.f && ((m >> wl) & 1ull) == 0;
@@ -421,6 +434,14 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
         } while (m);
         FPS_T(1);
         const int par = r & 1;
+        if (DPM_FPS_ABLATE & 2) {   // timing-only: no exchange, the wave follows its own candidate
+            sx = wbx + 1e-3f * r, sy = wby, sz = wbz;
+            if (DPM_FPS_PACE) {
+                const long long due = pace0 + (long long)r * DPM_FPS_PACE;
+                while ((long long)wall_clock64() < due) __builtin_amdgcn_s_sleep(4);
+            }
+            continue;
+        }
         if (lane == 0) {
             float *ex = &s_ex[par][0][w];
             ex[0] = wv, ex[NW] = __int_as_float(wi), ex[2 * NW] = wbx, ex[3 * NW] = wby, ex[4 * NW] = wbz;
@@ -447,6 +468,10 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
             s_oidx[o] = gi, s_oxyz[o][0] = sx, s_oxyz[o][1] = sy, s_oxyz[o][2] = sz;
         }
         FPS_T(4);
+        if (DPM_FPS_PACE) {
+            const long long due = pace0 + (long long)r * DPM_FPS_PACE;
+            while ((long long)wall_clock64() < due) __builtin_amdgcn_s_sleep(4);
+        }
         if ((r & (OB - 1)) == OB - 1 || r == kn - 1) {  // flush the buffered picks (uniform condition)
             __syncthreads();
             const int r0 = r & ~(OB - 1);
@@ -517,8 +542,13 @@ static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t 
         const int rc = dpm_fps_str_bucket_sort(xyz, lengths, B, N, pts, closest, tmp, st);
         if (rc != DPM_OK) return rc;
         if (dpm_knob("DPM_ABLATE_FPS_ROUNDS", 0)) return dpm_launch_status();  // -DDPM_EXPERIMENT builds only: the packing without the rounds (scripts/step_model.py)
+#ifdef DPM_EXPERIMENT
+        hipLaunchKernelGGL((fps_bucket_kernel<DPM_FPS_REGCL != 0, true>), dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
+                           new_lengths, slots, start, dpm_knob("DPM_FPS_ABLATE", 0), dpm_knob("DPM_FPS_PACE", 0));
+#else
         hipLaunchKernelGGL(fps_bucket_kernel<DPM_FPS_REGCL != 0>, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
-                           new_lengths, slots, start);
+                           new_lengths, slots, start, 0, 0);
+#endif
         return dpm_launch_status();
     }
     if (algo >= 2) {
@@ -532,7 +562,7 @@ static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t 
         float *closest = (float *)(pts + (size_t)B * N);
         hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(B), dim3(FB), 0, st, xyz, lengths, N, pts, closest);
         hipLaunchKernelGGL(fps_bucket_kernel<DPM_FPS_REGCL != 0>, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx,
-                           new_xyz, new_lengths, 0, start);
+                           new_xyz, new_lengths, 0, start, 0, 0);
         return dpm_launch_status();
     }
     float *ws = (float *)workspace;

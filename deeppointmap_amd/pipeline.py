@@ -78,6 +78,10 @@ class HotPath:
         # pipeline's seven streams), capped at half of what is free when the pipeline starts: the shipped configuration is the one
         # bench.py measures.  A caller that shares the GPU with other tenants sets 0 (nothing reserved).
         self.reserve_bytes = 16 << 30
+        # False: the caller guarantees that a batch's inputs are complete (or ordered by an event the geometry streams already wait
+        # for) when submit() is called -- resident scans, inputs staged on a stream of the caller's own that it synchronised with
+        # `for g in hot.geometry_streams(): g.wait_event(ev)` -- and the geometry stage does not wait for the caller's stream.
+        self.inputs_on_caller_stream = True
 
     @torch.no_grad()
     def extract(self, points: torch.Tensor, padding: torch.Tensor, presampled=None) -> torch.Tensor:
@@ -246,7 +250,10 @@ class HotPath:
         sa = self._side["geo"][self._pending["n"] % len(self._side["geo"])]
         self._pending["n"] += 1
         rings = [self._ring_pairs(h[0].shape[0], dev) if h[2] is not None else None for h in hold]  # before the stream switch: a first call copies H2D
-        sa.wait_stream(main)  # inputs the caller produced asynchronously on its stream (H2D copies, GPU pre-processing)
+        if self.inputs_on_caller_stream:
+            # inputs the caller produced asynchronously on its stream (H2D copies, GPU pre-processing).  The feature stage of an
+            # earlier batch sits at the head of that stream, so this also makes G(i) wait for F(i - 3) to finish.
+            sa.wait_stream(main)
         for points, padding, pcd_m in hold:
             # the caller may drop its tensors as soon as submit() returns: every stream that will read them has to be on
             # record with the allocator, or their memory is handed out again while a stage is still reading it

@@ -15,6 +15,7 @@ from deeppointmap_amd.weights import init_procedural
 dev = torch.device("cuda:0")
 cfg = default_args()
 hot = HotPath(init_procedural(Encoder(cfg)).to(dev), init_procedural(Decoder(cfg)).to(dev))
+hot.inputs_on_caller_stream = os.environ.get("INPUTS_RESIDENT", "0") != "1"   # INPUTS_RESIDENT=1: the geometry stage does not wait for the caller's stream
 pts, pad = synthetic.frames(64, 65536)
 pts, pad = pts.to(dev), pad.to(dev)
 pcd = (pts * 60).contiguous()

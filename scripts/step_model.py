@@ -105,7 +105,8 @@ probe("group_mlp_max_from_xyz")                                                 
 probe("knn_hybrid", lambda points, lengths, centers, K, *a, **k: points.shape[1] == 65536)   # F: the first-level neighbour search
 probe("linear_kvplanes", lambda x, W, *a, **k: W.shape[0] == 768 and x.shape[0] == 2 * F * 256)  # R: the 256 -> 768 projections
 probe("information_matrix_batched")                                                # R: the nearest-neighbour search + moments
-PROBES = ("group_mlp_max_from_xyz", "knn_hybrid", "linear_kvplanes", "information_matrix_batched")
+probe("fps", lambda xyz, *a, **k: xyz.shape[1] == 65536)                             # G: packing + the 4095 rounds of one launch
+PROBES = ("group_mlp_max_from_xyz", "knn_hybrid", "linear_kvplanes", "information_matrix_batched", "fps")
 
 
 def timed(label, n=N_STEPS, warm=6):
@@ -184,6 +185,20 @@ timed("first-level sampling enqueued at the same places but on streams of its ow
 for s_ in side:
     s_.synchronize()
 hot.encoder.presample = presample_sampling_only
+# the sampling launch REPLACED by 64 sleeping workgroups of its shape that stay for 6.5 ms, at its place in the pipeline (the feature
+# stage waits for them exactly as it waits for the sampling): is the price paid for what the rounds DO, or for the 6.5 ms in the chain?
+occ_early = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deeppointmap_amd", "csrc", "build", "libocc.so"))
+occ_early.launch_occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
+
+
+def presample_sleepers(*a, **k):
+    occ_early.launch_occupy(64, 1024, 650_000, 33408, torch.cuda.current_stream(dev).cuda_stream)
+    return deep_clone(cache["presample"])
+
+
+hot.encoder.presample = presample_sleepers
+timed("64 SLEEPING workgroups for 6.5 ms in the sampling launch's place | F | R")
+hot.encoder.presample = presample_sampling_only
 for nf in (32, 16, 8):   # fewer sampling workgroups in flight: how the price scales with their number
     xs, ls = pre0["xyz"][:nf].contiguous(), pre0["lengths"][:nf].contiguous()
 
@@ -199,6 +214,14 @@ if _lib.experimental():   # DPM_LIB = a -DDPM_EXPERIMENT build: the packing kern
     os.environ["DPM_ABLATE_FPS_ROUNDS"] = "1"
     timed("first-level packing only (no rounds) | F | R")
     del os.environ["DPM_ABLATE_FPS_ROUNDS"]
+    # ... and the rounds with parts of them switched off (wrong picks -- the feature stage runs on the cached, correct sampling
+    # result), every round held to 1.6 us so that all variants keep their workgroups resident equally long
+    os.environ["DPM_FPS_PACE"] = "160"
+    for bits, what in ((0, "complete rounds"), (1, "rounds without bucket updates (no global loads / stores, no per-bucket arg-max)"),
+                       (2, "rounds without the exchange (no LDS, no barrier)"), (3, "rounds with the box test only")):
+        os.environ["DPM_FPS_ABLATE"] = str(bits)
+        timed(f"first-level sampling only, paced at 1.6 us per round, {what} | F | R")
+    del os.environ["DPM_FPS_PACE"], os.environ["DPM_FPS_ABLATE"]
 configure(G=False, R=False); timed("F alone")
 configure(G=False, Fs=False); timed("R alone")
 configure(Fs=False, R=False); timed("G alone (two passes in flight)")
@@ -244,7 +267,7 @@ configure(R=False); timed("G | F, the same")
 configure(Fs=False); timed("G | R, the same")
 configure()
 print()
-print("| configuration | ms per 64-frame step | host ms per submit | first-level gather us | first-level neighbour search us | 256 -> 768 projection us | information matrices us |")
-print("|---|---|---|---|---|---|---|")
+print("| configuration | ms per 64-frame step | host ms per submit | first-level gather us | first-level neighbour search us | 256 -> 768 projection us | information matrices us | first-level sampling launch us |")
+print("|---|---|---|---|---|---|---|---|")
 for label, dt, th, pr in rows:
     print(f"| {label} | {dt:.3f} | {th:.3f} | " + " | ".join(f"{pr[p]:.0f}" for p in PROBES) + " |")
