@@ -432,7 +432,7 @@ class Decoder(ParamTree):
         return e
 
     @torch.no_grad()
-    def capture_registration_graphs(self, shapes) -> int:
+    def capture_registration_graphs(self, shapes, copies: int = 1) -> int:
         """Capture the one-pair registration of every (M, N, num_sample) in `shapes` NOW, for replay from ANY thread -- what a caller
         that is about to start worker threads does first (the reference's multi-thread mode drives one Decoder from several threads,
         system/core.py:54-57, 82-109): on this runtime a capture in progress makes other threads' synchronising calls fail, so
@@ -440,7 +440,9 @@ class Decoder(ParamTree):
         (~51 launches, 0.86-1.0 ms of host time per 256 x 256 pair against 0.46 ms replayed).  Replays of one graph from different
         threads are put in order on the device (an event per graph), results are bit-identical to the eager path.  Returns the number
         of graphs captured.  Graphs captured here are not subject to `graph_max`; `invalidate_caches()` / new weights drop them
-        like the others (they are not captured again behind the caller's back: call this again)."""
+        like the others (they are not captured again behind the caller's back: call this again).  `copies` > 1 captures that many
+        instances per shape (each with its own static buffers): threads that ask for the same shape at the same time then replay
+        different instances side by side on the device instead of queueing behind one."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("deeppointmap_amd.Decoder runs on the GPU only (there is no CPU fallback)")
@@ -452,21 +454,34 @@ class Decoder(ParamTree):
                 k = self._num_pairs(num_sample, M, N)
                 if k < 1:
                     continue
-                key = (M, N, k, dev.index, None)        # None: no owner thread
-                with self._graph_lock:
-                    e = self._graphs.get(key)
-                    if e is not None and e.get("graph") is not None and e["stamp"] == self._weights_stamp():
-                        continue
-                    e = self._graphs[key] = dict(hits=0, graph=None, used=0, pinned=True, lock=threading.Lock(), done=None)
-                if self._capture(e, M, N, num_sample, dev) is not None:
-                    n += 1
+                for c in range(max(1, int(copies))):
+                    key = (M, N, k, dev.index, None, c)        # None: no owner thread; c: the instance
+                    with self._graph_lock:
+                        e = self._graphs.get(key)
+                        if e is not None and e.get("graph") is not None and e["stamp"] == self._weights_stamp():
+                            continue
+                        e = self._graphs[key] = dict(hits=0, graph=None, used=0, pinned=True, lock=threading.Lock(), done=None)
+                    if self._capture(e, M, N, num_sample, dev) is not None:
+                        n += 1
         return n
 
     def _shared_graph(self, M: int, N: int, k: int, dev):
-        e = self._graphs.get((M, N, k, dev.index, None))
-        if e is None or e.get("graph") is None or e["stamp"] != self._weights_stamp():
-            return None
-        return e
+        """an instance of the ahead-of-time graph of this shape, LOCKED for the caller (an idle one if there is one, else the first)"""
+        first, stamp, c = None, None, 0
+        while True:
+            e = self._graphs.get((M, N, k, dev.index, None, c))
+            if e is None:
+                break
+            if e.get("graph") is not None:
+                stamp = self._weights_stamp() if stamp is None else stamp
+                if e["stamp"] == stamp:
+                    if e["lock"].acquire(blocking=False):
+                        return e
+                    first = e if first is None else first
+            c += 1
+        if first is not None:
+            first["lock"].acquire()
+        return first
 
     @torch.no_grad()
     def registration_forward(self, src_descriptor: torch.Tensor, dst_descriptor: torch.Tensor,
@@ -493,7 +508,7 @@ class Decoder(ParamTree):
                     if entry is None:                           # ... this thread's own, captured when the shape keeps coming back
                         entry = self._graph_entry((M, N, k, dev.index, threading.get_ident()), M, N, num_sample, dev)
             if entry is not None and entry.get("lock") is not None:
-                with entry["lock"]:   # one graph, several threads on their own streams: replays in order on the device too
+                try:   # (locked by _shared_graph) one graph, several threads on their own streams: replays in order on the device too
                     st = torch.cuda.current_stream(dev)
                     if entry["done"] is not None:
                         st.wait_event(entry["done"])
@@ -502,6 +517,8 @@ class Decoder(ParamTree):
                     entry["graph"].replay()
                     res = entry["res"][0].clone()
                     entry["done"] = st.record_event()
+                finally:
+                    entry["lock"].release()
             elif entry is not None:
                 entry["src"].copy_(src_descriptor, non_blocking=True)
                 entry["dst"].copy_(dst_descriptor, non_blocking=True)

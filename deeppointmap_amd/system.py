@@ -164,6 +164,7 @@ class SlamSystem:
             P, a = enc.npoint[len(enc.npoint) - 1 - enc.upsample_layers], self.backend.args   # descriptors per scan (256)
             self.dpm_decoder.capture_registration_graphs(
                 [(P, P, a["registration_sample_odometer"])] + [(P * j, P, a["registration_sample_mapping"]) for j in range(1, 17)])
+            # (one instance per shape: this mode's registrations all come from the back-end thread)
         q_in, q_mid = Queue(), Queue()
         errors: List[BaseException] = []
         end = object()      # behind the last scan (the reference forwards an exit code AHEAD of the scans it was drained with,

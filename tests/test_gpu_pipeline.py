@@ -250,6 +250,19 @@ def test_registration_graphs_captured_ahead_serve_every_thread(cfg_full):
             assert torch.equal(R, Rw) and torch.equal(T_, Tw) and torch.equal(c, cw) and rmse == rw
     print(f"one-pair registration 256 x 256: eager {eager_ms:.3f} ms, replayed {replay_ms:.3f} ms, three threads {mt_ms:.3f} ms per call")
     assert replay_ms < eager_ms
+    # three instances per shape: the threads replay side by side instead of queueing behind one graph; same bits
+    assert dec.capture_registration_graphs([(256, 256, 0.5)], copies=3) == 2       # instance 0 exists
+    got.clear()
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    t0 = time.perf_counter()
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    mt3_ms = (time.perf_counter() - t0) / (4 * sum(len(v) for v in inputs.values())) * 1e3
+    assert not errs, errs
+    for t in range(3):
+        for (R, T_, c, rmse), (Rw, Tw, cw, rw) in zip(got[t], want[t]):
+            assert torch.equal(R, Rw) and torch.equal(T_, Tw) and torch.equal(c, cw) and rmse == rw
+    print(f"   ... with three graph instances per shape: {mt3_ms:.3f} ms per call")
     with pytest.raises(RuntimeError):   # the capture call itself refuses once a thread exists
         ev = threading.Event()
         th = threading.Thread(target=ev.wait)
