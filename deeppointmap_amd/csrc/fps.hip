@@ -245,6 +245,9 @@ __global__ __launch_bounds__(FB) void fps_bucket_sort_kernel(const float *__rest
 #ifndef DPM_FPS_NT
 #define DPM_FPS_NT 0
 #endif
+#ifndef DPM_FPS_XBCAST
+#define DPM_FPS_XBCAST 0
+#endif
 typedef float fps_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 fps_load_point(const float4 *p) {
     if (DPM_FPS_NT & 1) {
@@ -451,6 +454,39 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
         FPS_T(3);
         // cross-wave arg-max: lane reads entry (lane & 15), 16-lane row reduction, winner's fields by broadcast reads
         const int e = lane & (NW - 1);
+#if DPM_FPS_XBCAST
+        // (experiment of round 6, profiles/r06_fps.md) ONE LDS round trip: every lane reads candidate (lane & 15) whole, the winner's
+        // fields are spread over the row with row_newbcast DPP moves -- the lane is an immediate, hence the 16-way scalar branch
+        const float *rec = &s_ex[par][0][e];
+        const float ev = rec[0];
+        const int ei = __float_as_int(rec[NW]);
+        const float ex_ = rec[2 * NW], ey_ = rec[3 * NW], ez_ = rec[4 * NW];
+        const float gv = row16_max_f(ev);
+        unsigned eqm = (unsigned)(__ballot(ev == gv) & 0xFFFFull);
+        if (__popc(eqm) > 1) {  // equal maxima in different waves: smallest original index wins
+            const int imin = row16_min_i(ev == gv ? ei : 0x7fffffff);
+            eqm = (unsigned)(__ballot(ev == gv && ei == imin) & 0xFFFFull);
+        }
+        const int gw = __builtin_ctz(eqm);
+        int gi;
+#define DPM_BC(K)                                                                                                           \
+    case K:                                                                                                                 \
+        gi = __builtin_amdgcn_update_dpp(ei, ei, 0x150 + K, 0xF, 0xF, false);                                               \
+        sx = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ex_), __float_as_int(ex_), 0x150 + K, 0xF, 0xF, false)); \
+        sy = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ey_), __float_as_int(ey_), 0x150 + K, 0xF, 0xF, false)); \
+        sz = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ez_), __float_as_int(ez_), 0x150 + K, 0xF, 0xF, false)); \
+        break;
+        switch (gw) {
+            DPM_BC(0) DPM_BC(1) DPM_BC(2) DPM_BC(3) DPM_BC(4) DPM_BC(5) DPM_BC(6) DPM_BC(7) DPM_BC(8) DPM_BC(9) DPM_BC(10) DPM_BC(11)
+            DPM_BC(12) DPM_BC(13) DPM_BC(14)
+            default:
+                gi = __builtin_amdgcn_update_dpp(ei, ei, 0x15F, 0xF, 0xF, false);
+                sx = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ex_), __float_as_int(ex_), 0x15F, 0xF, 0xF, false));
+                sy = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ey_), __float_as_int(ey_), 0x15F, 0xF, 0xF, false));
+                sz = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ez_), __float_as_int(ez_), 0x15F, 0xF, 0xF, false));
+        }
+#undef DPM_BC
+#else
         const float ev = s_ex[par][0][e];
         const float gv = row16_max_f(ev);
         unsigned eqm = (unsigned)(__ballot(ev == gv) & 0xFFFFull);
@@ -463,6 +499,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
         const float *gx = &s_ex[par][1][gw];
         const int gi = __float_as_int(gx[0]);
         sx = gx[NW], sy = gx[2 * NW], sz = gx[3 * NW];
+#endif
         if (t == 0) {
             const int o = r & (OB - 1);
             s_oidx[o] = gi, s_oxyz[o][0] = sx, s_oxyz[o][1] = sy, s_oxyz[o][2] = sz;
