@@ -277,8 +277,16 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
                                                         float *__restrict__ new_xyz_all,
                                                         int32_t *__restrict__ new_len, int slots,
                                                         const int32_t *__restrict__ start = nullptr, int exp_ablate = 0,
-                                                        int exp_pace = 0) {
+                                                        int exp_pace = 0, int exp_xcds = 0, int exp_xcd_base = 0) {
     const int DPM_FPS_ABLATE = EXP ? exp_ablate : 0, DPM_FPS_PACE = EXP ? exp_pace : 0;
+    // (experiment, EXP builds: DPM_FPS_XCDS = n) the launch is 8 / n times wider and only the workgroups that the dispatcher's
+    // round-robin puts on XCDs base .. base + n - 1 (linear id mod 8) take a frame; the others leave at once
+    int frame = blockIdx.x;
+    if (EXP && exp_xcds > 0) {
+        const int x = (int)(blockIdx.x & 7) - exp_xcd_base;
+        if (x < 0 || x >= exp_xcds) return;
+        frame = (int)(blockIdx.x >> 3) * exp_xcds + x;
+    }
 #ifdef DPM_FPS_PRIO   // wave priority of the sampling waves (A/B builds; round 3 and round 6 measured no effect on the rounds)
     __builtin_amdgcn_s_setprio(DPM_FPS_PRIO);
 #endif
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(FB) void fps_bucket_kernel(const float *__restrict_
     __shared__ int s_oidx[OB];
     __shared__ float s_oxyz[OB][3];
 
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int b = frame, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const float *xyz = xyz_all + (size_t)b * N * 3;
     // slots != 0 (Sort-Tile-Recursive packing, algo 5): every frame owns `slots` point slots; unused ones carry the index
     // INT_MAX and closest = -1 (they never move and never win), so the slot count plays the part of the length below
@@ -580,8 +588,15 @@ static int fps_dispatch(const float *xyz, const int32_t *lengths, const int32_t 
         if (rc != DPM_OK) return rc;
         if (dpm_knob("DPM_ABLATE_FPS_ROUNDS", 0)) return dpm_launch_status();  // -DDPM_EXPERIMENT builds only: the packing without the rounds (scripts/step_model.py)
 #ifdef DPM_EXPERIMENT
-        hipLaunchKernelGGL((fps_bucket_kernel<DPM_FPS_REGCL != 0, true>), dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
-                           new_lengths, slots, start, dpm_knob("DPM_FPS_ABLATE", 0), dpm_knob("DPM_FPS_PACE", 0));
+        {
+            static int launches = 0;
+            int xcds = dpm_knob("DPM_FPS_XCDS", 0);
+            if (xcds > 0 && (B % xcds != 0 || 8 % xcds != 0)) xcds = 0;
+            const int base = xcds > 0 ? (launches++ % (8 / xcds)) * xcds : 0;   // consecutive launches take consecutive XCD groups
+            hipLaunchKernelGGL((fps_bucket_kernel<DPM_FPS_REGCL != 0, true>), dim3(xcds > 0 ? B / xcds * 8 : B), dim3(FB), 0, st, xyz, lengths, N, K,
+                               pts, closest, idx, new_xyz, new_lengths, slots, start, dpm_knob("DPM_FPS_ABLATE", 0), dpm_knob("DPM_FPS_PACE", 0),
+                               xcds, base);
+        }
 #else
         hipLaunchKernelGGL(fps_bucket_kernel<DPM_FPS_REGCL != 0>, dim3(B), dim3(FB), 0, st, xyz, lengths, N, K, pts, closest, idx, new_xyz,
                            new_lengths, slots, start, 0, 0);
