@@ -90,6 +90,18 @@ def test_streaming_pipeline_equals_plain_steps(hot, feature_split):
     torch.cuda.synchronize()
     for (d0, t0), (d1, t1) in zip(plain, outs):
         assert torch.equal(d0, d1) and torch.equal(t0, t1)
+    # resident inputs (complete before submit): the geometry streams need not wait for the caller's stream (round 6)
+    torch.cuda.synchronize()
+    hot.inputs_on_caller_stream = False
+    outs = []
+    for p, m, q in batches:
+        r = hot.submit(p, m, q)
+        if r is not None:
+            outs.append(r)
+    outs.extend(hot.flush())
+    torch.cuda.synchronize()
+    for (d0, t0), (d1, t1) in zip(plain, outs):
+        assert torch.equal(d0, d1) and torch.equal(t0, t1)
 
 
 def test_streaming_pipeline_survives_callers_that_drop_their_inputs(hot):
