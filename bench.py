@@ -527,7 +527,7 @@ def run(args, guard, rank, world):
                     m = p * synthetic.COOR_SCALE
                     ev = up.record_event()
                 torch.cuda.current_stream(dev).wait_event(ev)
-                for g_ in (hot._side["geo"] if hot._side else []):
+                for g_ in hot.geometry_streams():
                     g_.wait_event(ev)
                 hot.submit(p, q, m)
             for _ in range(3):

@@ -361,6 +361,12 @@ class HotPath:
         torch.cuda.current_stream(self.encoder.device).wait_event(done)  # the caller's stream sees finished results
         return desc, table
 
+    def geometry_streams(self):
+        """the streams the geometry stage runs on (empty before the first submit): a caller that stages a batch's inputs on a stream
+        of its own makes these wait for its event, sets `inputs_on_caller_stream = False`, and the geometry stage no longer waits for
+        whatever else sits on the caller's stream"""
+        return list(self._side["geo"]) if self._side is not None else []
+
     @torch.no_grad()
     def flush(self):
         """Drain the pipe: returns the list of (desc, table) still in flight, oldest first."""
