@@ -13,8 +13,9 @@ torch.set_grad_enabled(False)
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 dump = sys.argv[3] if len(sys.argv) > 3 else None   # directory: every case above half the pose tolerance is written there (inputs + both results)
-rng = random.Random(seed)
-g = torch.Generator().manual_seed(seed)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+import margin_cases   # the random stream of a seed lives there: tests/golden/margin.npz refers to its cases by (seed, ordinal)
+stream = margin_cases.Stream(seed)
 cfg = default_args()
 dec = init_procedural(Decoder(cfg)).to("cuda:0")
 sd = {k: v.detach().cpu() for k, v in dec.flat().items()}
@@ -25,30 +26,17 @@ def rot_angle(A, B):
     return float(np.arctan2(float(torch.linalg.norm(M - M.T)) / (2 * 2 ** 0.5), float((torch.trace(M) - 1) / 2)))
 
 
-def desc(n):
-    fea = torch.rand(128, n, generator=g) * rng.choice([0.2, 1.0, 3.0])
-    xyz = torch.cat([(torch.rand(2, n, generator=g) * 2 - 1) * 50, torch.randn(1, n, generator=g) * 2])
-    return torch.cat([fea, xyz], 0)
-
-
 t0, n, bad, worst = time.time(), 0, 0, (0.0, 0.0)
 while time.time() - t0 < budget:
-    M = rng.choice([rng.randint(40, 300), 256, 512, rng.randint(300, 1100)])
-    N = rng.choice([M, rng.randint(40, 300), 256])
-    s, d = desc(M), desc(N)
-    masks = (None, None)
-    if rng.random() < 0.3:
-        ms, md = torch.zeros(1, M, dtype=torch.bool), torch.zeros(1, N, dtype=torch.bool)
-        ms[0, M - rng.randint(1, M // 3):] = True
-        md[0, N - rng.randint(1, N // 3):] = True
-        masks = (ms, md)
-    ns = rng.choice([0.5, 0.5, 0.25, 64])
+    _, s, d, ms_, md_, ns = stream.next()
+    M, N = s.shape[1], d.shape[1]
+    masks = (ms_, md_)
     tr, tro = {}, {}
     R, T, conf, rmse = dec.registration_forward(s, d, masks[0], masks[1], num_sample=ns, trace=tr)
     Ro, To, co, ro = O.registration_forward(sd, cfg, s, d, ns, trace=tro, src_padding_mask=masks[0], dst_padding_mask=masks[1])
     dT, dR = float((T.cpu() - To).norm()), rot_angle(R.cpu(), Ro)
     worst = (max(worst[0], dT), max(worst[1], dR))
-    n += 1
+    n = stream.n
     if dump and (dT > 5e-5 or dR > 5e-5 or conf.numel() != co.numel()):
         os.makedirs(dump, exist_ok=True)
         np.savez_compressed(os.path.join(dump, f"case_s{seed}_n{n}.npz"), src=s.numpy(), dst=d.numpy(), num_sample=np.float64(ns), num_sample_is_int=isinstance(ns, int),
@@ -88,8 +76,8 @@ while time.time() - t0 < budget:
                   f"|x| diff {float((tr['x'].cpu().view(-1) - tro['x'].reshape(-1)).abs().max()):.2e}")
             w = tro["w"]; print(f"   weights: {w.numel()} values, {w.unique().numel()} distinct; 64th/65th largest {w.sort(descending=True)[0][62:66].tolist()}; > 0.5: {int((w > 0.5).sum())}")
     if n % 5 == 0:  # loop detection on a small batch of the same shapes
-        C = rng.randint(1, 5)
-        S, D = torch.stack([desc(M) for _ in range(C)]), torch.stack([desc(N) for _ in range(C)])
+        S, D = stream.loop_batch(M, N)
+        C = S.shape[0]
         p, po = dec.loop_detection_forward(S, D).cpu(), O.loop_detection_forward(sd, cfg, S, D)
         if float((p - po).abs().max()) > 5e-5:
             bad += 1
