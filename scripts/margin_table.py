@@ -24,7 +24,8 @@ def ang(A, B):
 print("| case | class | inliers HIP / ref32 / ref64 | HIP - ref64 (m) | ref32 - ref64 (m) | ref32: 8 threads - 1 thread (m) | HIP - ref32 (m) | HIP - ref64 (rad) | ref32 - ref64 (rad) |")
 print("|---|---|---|---|---|---|---|---|---|")
 rows = [(f"{s}/{n}", cls, f"s{s}_n{n}", inp) for (s, n), cls, inp in margin_cases.all_cases()]
-rows.append(("frames 701 -> 702", "full size", "path701_702", (torch.from_numpy(g["path701_702.desc_src"]), torch.from_numpy(g["path701_702.desc_dst"]), None, None, 0.5)))
+for fa, fb in ((701, 702), (900, 901)):
+    rows.append((f"frames {fa} -> {fb}", "full size", f"path{fa}_{fb}", (torch.from_numpy(g[f"path{fa}_{fb}.desc_src"]), torch.from_numpy(g[f"path{fa}_{fb}.desc_dst"]), None, None, 0.5)))
 sums = [0.0, 0.0, 0]
 for name, cls, k, (s, d, ms, md, ns) in rows:
     R, T, conf, rmse = dec.registration_forward(s, d, ms, md, num_sample=ns)

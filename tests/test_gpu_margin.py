@@ -73,12 +73,12 @@ def test_fuzz_cases_against_the_reference_in_fp64(case, dec):
     assert at_rounding_level, f"{k} is listed as a boundary case but the fp64 evaluation shows no decision near its cut: {m}"
 
 
-def test_full_size_pair_of_the_path_fuzz_against_the_reference_in_fp64(dec):
-    """synthetic frames 701 -> 702 at 65 536 points (scripts/fuzz_path.py's worst pair, 7.6e-5 m from the oracle): the decoder on the
-    REFERENCE's fp32 descriptors of the two frames.  The reference's own three evaluations: fp32 vs fp64 2.5e-4 m, 8 threads vs 1
-    thread 1.1e-4 m, 85 inliers each."""
+@pytest.mark.parametrize("k", ["path701_702", "path900_901"])
+def test_full_size_pair_of_the_path_fuzz_against_the_reference_in_fp64(k, dec):
+    """synthetic frames 701 -> 702 and 900 -> 901 at 65 536 points (scripts/fuzz_path.py's worst pairs: 7.6e-5 m from the oracle in round
+    5, 1.04e-4 m in round 6): the decoder on the REFERENCE's fp32 descriptors of the two frames.  The reference's own three evaluations
+    of 701 -> 702: fp32 vs fp64 2.5e-4 m, 8 threads vs 1 thread 1.1e-4 m, 85 inliers each (900 -> 901: the generator's table)."""
     g = load_golden("margin.npz")
-    k = "path701_702"
     s, d = torch.from_numpy(g[k + ".desc_src"]), torch.from_numpy(g[k + ".desc_dst"])
     R, T, conf, rmse = dec.registration_forward(s, d, num_sample=0.5)
     R, T = R.cpu(), T.cpu()
