@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--feature-streams", type=int, default=None, help="feature-stage streams (pipeline tuning)")
     ap.add_argument("--geometry-knn-from", type=int, default=None, help="first downsampling level whose neighbour queries run in the geometry stage (pipeline tuning; -1 = none)")
     ap.add_argument("--feature-split", type=int, default=None, help="downsampling level at which the feature stage moves to its second stream (pipeline tuning; 0 = one stage)")
+    ap.add_argument("--wait-for-caller-stream", type=int, default=1, choices=(0, 1),
+                    help="HotPath.inputs_on_caller_stream: 1 (the library's default) = the geometry stage of a batch waits for the caller's "
+                         "stream; 0 = the inputs are complete at submit() (true of this benchmark's resident scans) and it does not")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time breakdown to stderr")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend for --gpus > 1; gloo (ranks folded onto the visible GPUs) exists only to dry-run "
@@ -318,6 +321,7 @@ def run(args, guard, rank, world):
     if args.feature_split is not None:
         hot.feature_split = args.feature_split
     # hot.reserve_bytes stays at HotPath's default (16 GiB of allocator segments up front, pipeline.py): the shipped configuration
+    hot.inputs_on_caller_stream = bool(args.wait_for_caller_stream)
     hot.chain = world > 1  # block-boundary edges come from the neighbour rank's last frame (shard.exchange_halo)
     F, N = args.frames, args.points
     pts, pad = synthetic.frames(F, N, start=rank * F)  # every rank owns its own block of the sequence
@@ -650,7 +654,8 @@ def run(args, guard, rank, world):
                                       (" (ONE rank, collectives forced: --force-collectives)" if forced else ""),
                        "pipeline": "none" if args.no_pipeline else "HIP-stream pipeline: geometry (staging+FPS chain) of batches i, i-1 on two alternating streams | features of batch i-2 | registration+information matrices of batch i-3",
                        "weights": "procedural (deeppointmap_amd/weights.py)",
-                       "allocator_reserve_gib": 0 if args.no_pipeline else hot.reserve_bytes >> 30},
+                       "allocator_reserve_gib": 0 if args.no_pipeline else hot.reserve_bytes >> 30,
+                       "geometry_waits_for_caller_stream": bool(hot.inputs_on_caller_stream)},
             "roofline": {"kernel": "str_chunk/str_xoffsets/str_ysort kernels + fps_bucket_kernel (stage-0 farthest point sampling: Sort-Tile-Recursive packing, then the sampling rounds)",
                          "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK / 1e9), 6), "traffic": pmc_traffic_bytes(F),
