@@ -256,6 +256,15 @@ for i in range(2 * 22):   # 22 launches of ~6 ms per stream: longer than the mea
         real_fps(pre0["xyz"], pre0["lengths"], cfg.encoder.npoint[0])
 timed("F | R next to the real first-level sampling (two launches in flight) that nothing waits for", n=24)
 torch.cuda.synchronize()
+if _lib.experimental():   # the same with parts of a round switched off (wrong picks, nobody reads them), unpaced
+    for bits, what in ((1, "without bucket updates"), (2, "without the exchange"), (3, "box test only")):
+        os.environ["DPM_FPS_ABLATE"] = str(bits)
+        for i in range(2 * 22):
+            with torch.cuda.stream(sx if i % 2 == 0 else sy):
+                real_fps(pre0["xyz"], pre0["lengths"], cfg.encoder.npoint[0])
+        timed(f"F | R next to the sampling that nothing waits for, rounds {what}", n=24)
+        torch.cuda.synchronize()
+    del os.environ["DPM_FPS_ABLATE"]
 configure()
 timed("G | F | R once more")
 # the sampling stage of batch i is enqueued behind `geo.wait_stream(caller's stream)` (inputs the caller may have produced there):
