@@ -63,8 +63,8 @@ def parity_gate(desc: torch.Tensor, table: torch.Tensor, n_points: int) -> dict:
     network/encoder/utils.py:232-262):
       * edges 0->1 ... 4->5 vs poses_full.npz: translation < 1e-4 m, rotation < 1e-4 rad, inlier count equal, |rmse| < 1e-3;
       * frame 0's 256 key points bit-equal to the first 256 picks of the reference's farthest point sampling (fps.npz) and to the
-        reference encoder's coordinates (encoder_full.npz); descriptors of frames 0, 1 within 3e-5 of the reference's (ten times what the
-        reference moves by between one and eight torch threads; observed 4e-6; tests/conftest.py FEATURE_TOL);
+        reference encoder's coordinates (encoder_full.npz); descriptors of frames 0, 1 within 1.5e-5 of the reference's (five times what the
+        reference moves by between one and eight torch threads, four times the 3.8e-6 observed; tests/conftest.py FEATURE_TOL);
       * every information matrix of the step finite and symmetric.
     The fixtures exist for the 65 536-point synthetic sequence only; another workload reports `checked: false`."""
     import numpy as np
@@ -90,13 +90,13 @@ def parity_gate(desc: torch.Tensor, table: torch.Tensor, n_points: int) -> dict:
     info = t[:, 20:56].view(-1, 6, 6)
     info_ok = bool(torch.isfinite(info).all()) and bool(((info - info.transpose(1, 2)).abs() <= 1e-5 * info.abs().amax(dim=(1, 2), keepdim=True) + 1e-12).all())
     ok = (max_dt < 1e-4 and max_dr < 1e-4 and max_drmse < 1e-3 and n_conf_equal and fps_prefix_equal and coor_equal
-          and desc_err < 3e-5 and info_ok)
+          and desc_err < 1.5e-5 and info_ok)
     return {"checked": True, "ok": bool(ok), "pairs": 5, "max_dT_m": float(f"{max_dt:.3g}"), "max_dR_rad": float(f"{max_dr:.3g}"),
             "max_drmse": float(f"{max_drmse:.3g}"), "n_conf_equal": bool(n_conf_equal), "fps_prefix_equal": fps_prefix_equal,
             "keypoints_equal_reference": coor_equal, "descriptor_max_err": float(f"{desc_err:.3g}"),
             "information_matrices": int(info.shape[0]), "information_finite_symmetric": info_ok,
             "against": "tests/golden/{poses_full,fps,encoder_full}.npz (made by importing the reference)",
-            "tolerance": "1e-4 m / 1e-4 rad (north_star); rmse 1e-3; descriptors 3e-5; key points and inlier counts exact"}
+            "tolerance": "1e-4 m / 1e-4 rad (north_star); rmse 1e-3; descriptors 1.5e-5; key points and inlier counts exact"}
 
 
 def cpu_baseline(n_frames: int, n_points: int, threads: int):
