@@ -21,10 +21,27 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import signal
 import sys
 import time
 
-import torch
+METRIC = "LiDAR frames/s (encode+match+register), 65 536 pts/frame"
+
+
+def _sigterm_before_start(*_):
+    """A launcher that lost another rank during start-up sends SIGTERM while this process is still importing torch (1-2 s, minutes on
+    a fresh box): rank 0 leaves its ONE error line even then.  Replaced by Guard's handler as soon as the benchmark starts."""
+    if os.environ.get("RANK", "0") == "0":
+        os.write(1, (json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+                                 "higher_is_better": True, "phase": "start",
+                                 "error": "SIGTERM from the launcher before the benchmark had started (another rank failed during start-up)"}) + "\n").encode())
+    os._exit(143)
+
+
+if __name__ == "__main__":
+    signal.signal(signal.SIGTERM, _sigterm_before_start)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -173,9 +190,6 @@ class Guard:
 
     def finish(self) -> None:
         self._done = True
-
-
-METRIC = "LiDAR frames/s (encode+match+register), 65 536 pts/frame"
 
 
 def self_launch_command(argv, n_gpus: int, port: int | None = None) -> list:

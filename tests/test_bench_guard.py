@@ -138,4 +138,25 @@ def test_bench_without_a_launcher_starts_its_ranks():
     assert out.returncode != 0
     assert "no launcher in the environment" in out.stderr
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] is None and "needs a GPU" in lines[0]["error"]
+    # (rank 0 says "needs a GPU" itself, or -- when rank 1 got there first and the launcher's SIGTERM reached rank 0 while it was still
+    # importing torch -- bench.py's start-up handler says so)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] is None
+    assert "needs a GPU" in lines[0]["error"] or "before the benchmark had started" in lines[0]["error"]
+
+
+def test_sigterm_during_start_up_leaves_a_record():
+    """bench.py installs a SIGTERM handler before it imports torch: a launcher that lost another rank during start-up still gets rank
+    0's one error line."""
+    bench_py = os.path.join(ROOT, "bench.py")
+    # the part of bench.py that runs before `import torch`, as the main program
+    code = ("import sys, time; head = open(%r).read().split('import torch  # noqa: E402')[0]; "
+            "exec(compile(head, %r, 'exec'), {'__name__': '__main__', '__file__': %r}); "
+            "print('READY', file=sys.stderr, flush=True); time.sleep(60)") % (bench_py, bench_py, bench_py)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="4")
+    p = subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+    assert "READY" in p.stderr.readline()
+    p.send_signal(signal.SIGTERM)
+    out, _ = p.communicate(timeout=60)
+    assert p.returncode == 143
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 4 and "before the benchmark had started" in line["error"]
